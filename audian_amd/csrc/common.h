@@ -1,0 +1,49 @@
+// Internal definitions shared by the libhip_dsp translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include "../../include/hip_dsp.h"
+
+void hipdsp_set_error(const char *fmt, ...);
+
+struct hipdsp_ctx {
+    int device;
+    hipStream_t stream;
+    int max_segments;      // 0 = auto
+    int n_cus;
+    void *scratch;         // envelope forward-pass intermediate
+    size_t scratch_bytes;
+};
+
+#define HD_CHECK_HIP(expr)                                                        \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess) {                                                   \
+            hipdsp_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                             __FILE__, __LINE__);                                 \
+            return HIPDSP_ERR_HIP;                                                \
+        }                                                                         \
+    } while (0)
+
+#define HD_REQUIRE(cond, ...)                                                     \
+    do {                                                                          \
+        if (!(cond)) {                                                            \
+            hipdsp_set_error(__VA_ARGS__);                                        \
+            return HIPDSP_ERR_INVALID;                                            \
+        }                                                                         \
+    } while (0)
+
+static inline int hd_launch_status(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        hipdsp_set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+        return HIPDSP_ERR_HIP;
+    }
+    return HIPDSP_OK;
+}
+
+int hipdsp_scratch(hipdsp_ctx *ctx, size_t bytes, void **out);

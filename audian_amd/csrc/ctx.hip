@@ -1,0 +1,205 @@
+// Context, error reporting, memory and event helpers of libhip_dsp.
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void hipdsp_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+int hipdsp_version(void) { return HIPDSP_VERSION; }
+
+const char *hipdsp_last_error(void) { return g_err; }
+
+int hipdsp_device_count(int *count)
+{
+    HD_REQUIRE(count != nullptr, "count is NULL");
+    HD_CHECK_HIP(hipGetDeviceCount(count));
+    return HIPDSP_OK;
+}
+
+int hipdsp_ctx_create(int device, void *stream, hipdsp_ctx **out)
+{
+    HD_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    HD_CHECK_HIP(hipGetDeviceCount(&n));
+    HD_REQUIRE(device >= 0 && device < n, "device %d out of range (%d devices)", device, n);
+    HD_CHECK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HD_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        hipdsp_set_error("device %d is %s; libhip_dsp is built for gfx950 (MI355X) only",
+                         device, prop.gcnArchName);
+        return HIPDSP_ERR_UNSUPPORTED;
+    }
+    hipdsp_ctx *ctx = new hipdsp_ctx();
+    ctx->device = device;
+    ctx->stream = (hipStream_t)stream;
+    ctx->max_segments = 0;
+    ctx->n_cus = prop.multiProcessorCount;
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    *out = ctx;
+    return HIPDSP_OK;
+}
+
+int hipdsp_ctx_destroy(hipdsp_ctx *ctx)
+{
+    if (!ctx) return HIPDSP_OK;
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    delete ctx;
+    return HIPDSP_OK;
+}
+
+int hipdsp_ctx_set_stream(hipdsp_ctx *ctx, void *stream)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    ctx->stream = (hipStream_t)stream;
+    return HIPDSP_OK;
+}
+
+int hipdsp_ctx_synchronize(hipdsp_ctx *ctx)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    HD_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return HIPDSP_OK;
+}
+
+int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    HD_REQUIRE(max_segments >= 0, "max_segments must be >= 0");
+    ctx->max_segments = max_segments;
+    return HIPDSP_OK;
+}
+
+int hipdsp_ctx_reserve(hipdsp_ctx *ctx, size_t bytes)
+{
+    void *p;
+    return hipdsp_scratch(ctx, bytes, &p);
+}
+
+int hipdsp_malloc(hipdsp_ctx *ctx, size_t bytes, void **dptr)
+{
+    HD_REQUIRE(ctx != nullptr && dptr != nullptr, "NULL argument");
+    *dptr = nullptr;
+    if (bytes == 0) return HIPDSP_OK;
+    HD_CHECK_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        hipdsp_set_error("hipMalloc(%zu bytes) out of memory", bytes);
+        return HIPDSP_ERR_NOMEM;
+    }
+    HD_CHECK_HIP(e);
+    return HIPDSP_OK;
+}
+
+int hipdsp_free(hipdsp_ctx *ctx, void *dptr)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (dptr) HD_CHECK_HIP(hipFree(dptr));
+    return HIPDSP_OK;
+}
+
+int hipdsp_memset(hipdsp_ctx *ctx, void *dptr, int value, size_t bytes)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (bytes) HD_CHECK_HIP(hipMemsetAsync(dptr, value, bytes, ctx->stream));
+    return HIPDSP_OK;
+}
+
+int hipdsp_memcpy_h2d(hipdsp_ctx *ctx, void *dst, const void *host_src, size_t bytes)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (bytes) {
+        HD_CHECK_HIP(hipMemcpyAsync(dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        HD_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // host buffer may be pageable
+    }
+    return HIPDSP_OK;
+}
+
+int hipdsp_memcpy_d2h(hipdsp_ctx *ctx, void *host_dst, const void *src, size_t bytes)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (bytes) {
+        HD_CHECK_HIP(hipMemcpyAsync(host_dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HD_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return HIPDSP_OK;
+}
+
+int hipdsp_memcpy_d2d(hipdsp_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (bytes) HD_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return HIPDSP_OK;
+}
+
+int hipdsp_event_create(hipdsp_ctx *ctx, void **event)
+{
+    HD_REQUIRE(ctx != nullptr && event != nullptr, "NULL argument");
+    hipEvent_t ev;
+    HD_CHECK_HIP(hipEventCreate(&ev));
+    *event = (void *)ev;
+    return HIPDSP_OK;
+}
+
+int hipdsp_event_destroy(hipdsp_ctx *ctx, void *event)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (event) HD_CHECK_HIP(hipEventDestroy((hipEvent_t)event));
+    return HIPDSP_OK;
+}
+
+int hipdsp_event_record(hipdsp_ctx *ctx, void *event)
+{
+    HD_REQUIRE(ctx != nullptr && event != nullptr, "NULL argument");
+    HD_CHECK_HIP(hipEventRecord((hipEvent_t)event, ctx->stream));
+    return HIPDSP_OK;
+}
+
+int hipdsp_event_elapsed_ms(hipdsp_ctx *ctx, void *start, void *stop, float *ms)
+{
+    HD_REQUIRE(ctx != nullptr && start && stop && ms, "NULL argument");
+    HD_CHECK_HIP(hipEventSynchronize((hipEvent_t)stop));
+    HD_CHECK_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return HIPDSP_OK;
+}
+
+}  // extern "C"
+
+int hipdsp_scratch(hipdsp_ctx *ctx, size_t bytes, void **out)
+{
+    HD_REQUIRE(ctx != nullptr && out != nullptr, "NULL argument");
+    if (bytes > ctx->scratch_bytes) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (ctx->stream) (void)hipStreamIsCapturing(ctx->stream, &st);
+        if (st != hipStreamCaptureStatusNone) {
+            hipdsp_set_error("scratch of %zu bytes needed during stream capture; call "
+                             "hipdsp_ctx_reserve() before capturing", bytes);
+            return HIPDSP_ERR_INVALID;
+        }
+        HD_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch) HD_CHECK_HIP(hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        hipError_t e = hipMalloc(&ctx->scratch, bytes);
+        if (e == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            hipdsp_set_error("scratch hipMalloc(%zu bytes) out of memory", bytes);
+            return HIPDSP_ERR_NOMEM;
+        }
+        HD_CHECK_HIP(e);
+        ctx->scratch_bytes = bytes;
+    }
+    *out = ctx->scratch;
+    return HIPDSP_OK;
+}

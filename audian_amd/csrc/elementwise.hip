@@ -1,0 +1,237 @@
+// Element-wise and layout kernels of libhip_dsp (gfx950): decibel, the
+// (T,C) <-> planar conversions at the drop-in edge, and the synthetic generator.
+#include "common.h"
+#include <cmath>
+
+namespace {
+
+__global__ void decibel_kernel(const float *__restrict__ p, float *__restrict__ out, long long n,
+                               float inv_ref, float min_power)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float v = p[i];
+        out[i] = (v <= min_power) ? -INFINITY : 10.0f * log10f(v * inv_ref);
+    }
+}
+
+// (rows, cols) -> (cols, rows) with optional dB, 32x32 LDS tiles (+1 pad).
+template <bool DB>
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                        long long rows, long long cols, float inv_ref,
+                                                        float min_power)
+{
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const long long r0 = (long long)blockIdx.y * 32, c0 = (long long)blockIdx.x * 32;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        long long r = r0 + ty + 8 * k, c = c0 + tx;
+        float v = 0.f;
+        if (r < rows && c < cols) {
+            v = src[r * cols + c];
+            if (DB) v = (v <= min_power) ? -INFINITY : 10.0f * log10f(v * inv_ref);
+        }
+        tile[ty + 8 * k][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        long long c = c0 + ty + 8 * k, r = r0 + tx;
+        if (r < rows && c < cols) dst[c * rows + r] = tile[tx][ty + 8 * k];
+    }
+}
+
+// (T, C) interleaved -> planar (C, pitch) float32
+template <typename SRC>
+__global__ __launch_bounds__(256) void pack_kernel(const SRC *__restrict__ src, float *__restrict__ dst,
+                                                   long long pitch, long long T, long long C)
+{
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long long t0 = (long long)blockIdx.x * 32, c0 = (long long)blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        long long t = t0 + ty + 8 * k, c = c0 + tx;
+        tile[ty + 8 * k][tx] = (t < T && c < C) ? (float)src[t * C + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        long long c = c0 + ty + 8 * k, t = t0 + tx;
+        if (t < T && c < C) dst[c * pitch + t] = tile[tx][ty + 8 * k];
+    }
+}
+
+// planar (C, pitch) float32 -> (T, C) interleaved float64
+__global__ __launch_bounds__(256) void unpack_kernel(const float *__restrict__ src, long long pitch,
+                                                     double *__restrict__ dst, long long T, long long C)
+{
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long long t0 = (long long)blockIdx.x * 32, c0 = (long long)blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        long long c = c0 + ty + 8 * k, t = t0 + tx;
+        tile[ty + 8 * k][tx] = (t < T && c < C) ? src[c * pitch + t] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        long long t = t0 + ty + 8 * k, c = c0 + tx;
+        if (t < T && c < C) dst[t * C + c] = (double)tile[tx][ty + 8 * k];
+    }
+}
+
+// (C, T', F) float32 -> (T', C, F) float64; one block per (frame, channel) row
+__global__ void unpack_spectrum_kernel(const float *__restrict__ src, double *__restrict__ dst,
+                                       long long frames, long long channels, long long F)
+{
+    const long long t = blockIdx.x, c = blockIdx.y;
+    const float *s = src + (c * frames + t) * F;
+    double *d = dst + (t * channels + c) * F;
+    for (long long f = threadIdx.x; f < F; f += blockDim.x) d[f] = (double)s[f];
+}
+
+__device__ __forceinline__ unsigned int mix64to32(unsigned long long z)
+{
+    z += 0x9E3779B97F4A7C15ULL;                      // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    return (unsigned int)(z >> 32);
+}
+
+__global__ void synth_kernel(float *__restrict__ x, long long pitch, long long frames, double rate,
+                             unsigned long long seed, long long c0, long long c_total)
+{
+    const long long c = blockIdx.y;
+    const double cyc_per_sample = 1000.0 * (1.0 + (double)(c0 + c) / (double)c_total) / rate;
+    float *row = x + c * pitch;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < frames;
+         t += (long long)gridDim.x * blockDim.x) {
+        unsigned int h = mix64to32(seed ^ ((unsigned long long)(c0 + c) << 40) ^ (unsigned long long)t);
+        float u = (float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f;          // [-1, 1)
+        double ph = cyc_per_sample * (double)t;
+        ph -= floor(ph);
+        row[t] = 0.5f * u + 0.5f * sinpif(2.0f * (float)ph);
+    }
+}
+
+inline unsigned grid1d(long long n, int per_block, unsigned cap)
+{
+    long long b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+extern "C" {
+
+int hipdsp_decibel(hipdsp_ctx *ctx, const float *p, float *out, int64_t n, double ref_power,
+                   double min_power)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    HD_REQUIRE(n >= 0, "negative size");
+    HD_REQUIRE(ref_power > 0, "ref_power must be positive");
+    if (n == 0) return HIPDSP_OK;
+    HD_REQUIRE(p != nullptr && out != nullptr, "NULL data pointer");
+    HD_CHECK_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(decibel_kernel, dim3(grid1d(n, 1024, 8192)), dim3(256), 0, ctx->stream, p, out,
+                       (long long)n, (float)(1.0 / ref_power), (float)min_power);
+    return hd_launch_status("decibel_kernel");
+}
+
+int hipdsp_decibel_image(hipdsp_ctx *ctx, const float *spec_tf, float *image_ft, int64_t frames,
+                         int64_t nfreq, double ref_power, double min_power)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    HD_REQUIRE(frames >= 0 && nfreq >= 0, "negative size");
+    HD_REQUIRE(ref_power > 0, "ref_power must be positive");
+    if (frames == 0 || nfreq == 0) return HIPDSP_OK;
+    HD_REQUIRE(spec_tf != nullptr && image_ft != nullptr, "NULL data pointer");
+    HD_REQUIRE((frames + 31) / 32 <= 65535, "too many frames for one image");
+    HD_CHECK_HIP(hipSetDevice(ctx->device));
+    dim3 grid((unsigned)((nfreq + 31) / 32), (unsigned)((frames + 31) / 32));
+    hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, ctx->stream, spec_tf, image_ft,
+                       (long long)frames, (long long)nfreq, (float)(1.0 / ref_power), (float)min_power);
+    return hd_launch_status("transpose_kernel");
+}
+
+static int pack_check(hipdsp_ctx *ctx, const void *a, const void *b, int64_t pitch, int64_t frames,
+                      int64_t channels)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    HD_REQUIRE(frames >= 0 && channels >= 0, "negative size");
+    if (frames == 0 || channels == 0) return HIPDSP_OK;
+    HD_REQUIRE(a != nullptr && b != nullptr, "NULL data pointer");
+    HD_REQUIRE(pitch >= frames, "pitch smaller than frames");
+    HD_REQUIRE((channels + 31) / 32 <= 65535, "too many channels");
+    HD_CHECK_HIP(hipSetDevice(ctx->device));
+    return HIPDSP_OK;
+}
+
+int hipdsp_pack_f64(hipdsp_ctx *ctx, const double *src_tc, float *dst, int64_t dst_pitch, int64_t frames,
+                    int64_t channels)
+{
+    int rc = pack_check(ctx, src_tc, dst, dst_pitch, frames, channels);
+    if (rc != HIPDSP_OK || frames == 0 || channels == 0) return rc;
+    dim3 grid((unsigned)((frames + 31) / 32), (unsigned)((channels + 31) / 32));
+    hipLaunchKernelGGL(pack_kernel<double>, grid, dim3(256), 0, ctx->stream, src_tc, dst,
+                       (long long)dst_pitch, (long long)frames, (long long)channels);
+    return hd_launch_status("pack_kernel<double>");
+}
+
+int hipdsp_pack_f32(hipdsp_ctx *ctx, const float *src_tc, float *dst, int64_t dst_pitch, int64_t frames,
+                    int64_t channels)
+{
+    int rc = pack_check(ctx, src_tc, dst, dst_pitch, frames, channels);
+    if (rc != HIPDSP_OK || frames == 0 || channels == 0) return rc;
+    dim3 grid((unsigned)((frames + 31) / 32), (unsigned)((channels + 31) / 32));
+    hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(256), 0, ctx->stream, src_tc, dst,
+                       (long long)dst_pitch, (long long)frames, (long long)channels);
+    return hd_launch_status("pack_kernel<float>");
+}
+
+int hipdsp_unpack_f64(hipdsp_ctx *ctx, const float *src, int64_t src_pitch, double *dst_tc, int64_t frames,
+                      int64_t channels)
+{
+    int rc = pack_check(ctx, src, dst_tc, src_pitch, frames, channels);
+    if (rc != HIPDSP_OK || frames == 0 || channels == 0) return rc;
+    dim3 grid((unsigned)((frames + 31) / 32), (unsigned)((channels + 31) / 32));
+    hipLaunchKernelGGL(unpack_kernel, grid, dim3(256), 0, ctx->stream, src, (long long)src_pitch, dst_tc,
+                       (long long)frames, (long long)channels);
+    return hd_launch_status("unpack_kernel");
+}
+
+int hipdsp_unpack_spectrum_f64(hipdsp_ctx *ctx, const float *src, double *dst_tcf, int64_t frames,
+                               int64_t channels, int64_t nfreq)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    HD_REQUIRE(frames >= 0 && channels >= 0 && nfreq >= 0, "negative size");
+    if (frames == 0 || channels == 0 || nfreq == 0) return HIPDSP_OK;
+    HD_REQUIRE(src != nullptr && dst_tcf != nullptr, "NULL data pointer");
+    HD_REQUIRE(channels <= 65535 && frames <= 0x7fffffffLL, "size out of range");
+    HD_CHECK_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(unpack_spectrum_kernel, dim3((unsigned)frames, (unsigned)channels), dim3(256), 0,
+                       ctx->stream, src, dst_tcf, (long long)frames, (long long)channels, (long long)nfreq);
+    return hd_launch_status("unpack_spectrum_kernel");
+}
+
+int hipdsp_synth(hipdsp_ctx *ctx, float *x, int64_t x_pitch, int64_t channels, int64_t frames, double rate,
+                 uint64_t seed, int64_t c0, int64_t c_total)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    HD_REQUIRE(frames >= 0 && channels >= 0 && c_total > 0 && rate > 0, "bad size");
+    if (frames == 0 || channels == 0) return HIPDSP_OK;
+    HD_REQUIRE(x != nullptr && x_pitch >= frames, "bad output");
+    HD_REQUIRE(channels <= 65535, "too many channels");
+    HD_CHECK_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(synth_kernel, dim3(grid1d(frames, 1024, 4096), (unsigned)channels), dim3(256), 0,
+                       ctx->stream, x, (long long)x_pitch, (long long)frames, rate,
+                       (unsigned long long)seed, (long long)c0, (long long)c_total);
+    return hd_launch_status("synth_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,258 @@
+"""Thin Python host layer over the libhip_dsp C ABI: context, device arrays, filter
+plans and the hot-path calls.  Device-native layout is planar float32
+(channels, frames); see ``include/hip_dsp.h``.
+"""
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+
+class Context:
+    """A device + HIP stream on which libhip_dsp enqueues its work."""
+
+    def __init__(self, device=0, stream=None):
+        h = ctypes.c_void_p()
+        check(lib.hipdsp_ctx_create(int(device), ctypes.c_void_p(stream or 0), ctypes.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_stream(self, stream):
+        check(lib.hipdsp_ctx_set_stream(self._h, ctypes.c_void_p(stream or 0)))
+
+    def synchronize(self):
+        check(lib.hipdsp_ctx_synchronize(self._h))
+
+    def set_max_segments(self, n):
+        check(lib.hipdsp_ctx_set_max_segments(self._h, int(n)))
+
+    def reserve(self, nbytes):
+        check(lib.hipdsp_ctx_reserve(self._h, int(nbytes)))
+
+    # events -------------------------------------------------------------
+    def event(self):
+        ev = ctypes.c_void_p()
+        check(lib.hipdsp_event_create(self._h, ctypes.byref(ev)))
+        return ev
+
+    def record(self, ev):
+        check(lib.hipdsp_event_record(self._h, ev))
+
+    def elapsed_ms(self, start, stop):
+        ms = ctypes.c_float()
+        check(lib.hipdsp_event_elapsed_ms(self._h, start, stop, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def destroy_event(self, ev):
+        check(lib.hipdsp_event_destroy(self._h, ev))
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            lib.hipdsp_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = None
+
+
+def default_context():
+    """The process-wide context on device 0 / LOCAL_RANK (created on first use)."""
+    global _default_ctx
+    if _default_ctx is None:
+        import os
+        _default_ctx = Context(int(os.environ.get('LOCAL_RANK', '0')))
+    return _default_ctx
+
+
+class DeviceArray:
+    """A caller-owned block of HBM with a NumPy-like shape/dtype (C-contiguous)."""
+
+    def __init__(self, ctx, shape, dtype=np.float32, ptr=None, owner=None):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in np.atleast_1d(shape))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64))*self.dtype.itemsize
+        self._own = ptr is None
+        self._owner = owner
+        if ptr is None:
+            p = ctypes.c_void_p()
+            check(lib.hipdsp_malloc(ctx.handle, self.nbytes, ctypes.byref(p)))
+            self.ptr = p.value or 0
+        else:
+            self.ptr = int(ptr)
+
+    @classmethod
+    def from_host(cls, ctx, array, dtype=None):
+        a = np.ascontiguousarray(array, dtype=dtype)
+        d = cls(ctx, a.shape, a.dtype)
+        d.copy_from_host(a)
+        return d
+
+    def copy_from_host(self, array):
+        a = np.ascontiguousarray(array, dtype=self.dtype)
+        if a.nbytes != self.nbytes:
+            raise ValueError('size mismatch in copy_from_host')
+        check(lib.hipdsp_memcpy_h2d(self.ctx.handle, ctypes.c_void_p(self.ptr),
+                                    ctypes.c_void_p(a.ctypes.data), self.nbytes))
+
+    def to_host(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        check(lib.hipdsp_memcpy_d2h(self.ctx.handle, ctypes.c_void_p(out.ctypes.data),
+                                    ctypes.c_void_p(self.ptr), self.nbytes))
+        return out
+
+    def zero_(self):
+        check(lib.hipdsp_memset(self.ctx.handle, ctypes.c_void_p(self.ptr), 0, self.nbytes))
+        return self
+
+    def view(self, offset_elems, shape):
+        """A non-owning sub-block starting `offset_elems` elements into this array."""
+        v = DeviceArray(self.ctx, shape, self.dtype,
+                        ptr=self.ptr + int(offset_elems)*self.dtype.itemsize, owner=self)
+        if v.ptr + v.nbytes > self.ptr + self.nbytes:
+            raise ValueError('view exceeds the parent array')
+        return v
+
+    def free(self):
+        if self._own and self.ptr:
+            lib.hipdsp_free(self.ctx.handle, ctypes.c_void_p(self.ptr))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _p(x):
+    """Device pointer of a DeviceArray, a torch tensor, an int, or None."""
+    if x is None:
+        return ctypes.c_void_p(0)
+    if isinstance(x, DeviceArray):
+        return ctypes.c_void_p(x.ptr)
+    if hasattr(x, 'data_ptr'):
+        return ctypes.c_void_p(x.data_ptr())
+    return ctypes.c_void_p(int(x))
+
+
+class SosPlan:
+    """Device-resident plan for one SOS table (see hipdsp_sosplan_* in hip_dsp.h)."""
+
+    def __init__(self, ctx, sos=None):
+        self.ctx = ctx
+        h = ctypes.c_void_p()
+        check(lib.hipdsp_sosplan_create(ctx.handle, ctypes.byref(h)))
+        self._h = h
+        self.n_sections = 0
+        if sos is not None:
+            self.set(sos)
+
+    @staticmethod
+    def _table(sos):
+        sos = np.ascontiguousarray(sos, dtype=np.float64)
+        if sos.ndim != 2 or sos.shape[1] != 6:
+            raise ValueError('sos must be shape (n_sections, 6)')
+        return sos
+
+    def set(self, sos):
+        sos = self._table(sos)
+        check(lib.hipdsp_sosplan_set(self.ctx.handle, self._h, ctypes.c_void_p(sos.ctypes.data),
+                                     len(sos)))
+        self.n_sections = len(sos)
+
+    def set_host(self, sos):
+        sos = self._table(sos)
+        check(lib.hipdsp_sosplan_set_host(self.ctx.handle, self._h,
+                                          ctypes.c_void_p(sos.ctypes.data), len(sos)))
+        self.n_sections = len(sos)
+
+    def upload(self):
+        check(lib.hipdsp_sosplan_upload(self.ctx.handle, self._h))
+
+    def info(self):
+        w = ctypes.c_int64()
+        e = ctypes.c_int()
+        check(lib.hipdsp_sosplan_info(self.ctx.handle, self._h, ctypes.byref(w), ctypes.byref(e)))
+        return int(w.value), int(e.value)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            lib.hipdsp_sosplan_destroy(self.ctx.handle, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _plan(plan):
+    return plan.handle if plan is not None else ctypes.c_void_p(0)
+
+
+def sosfilt(ctx, plan, x, x_pitch, y, y_pitch, channels, frames, skip=0):
+    check(lib.hipdsp_sosfilt(ctx.handle, _plan(plan), _p(x), int(x_pitch), _p(y), int(y_pitch),
+                             int(channels), int(frames), int(skip)))
+
+
+def envelope(ctx, plan, x, x_pitch, y, y_pitch, channels, frames, skip=0, rectify=True,
+             gain=np.pi/2, clamp=True):
+    check(lib.hipdsp_envelope(ctx.handle, _plan(plan), _p(x), int(x_pitch), _p(y), int(y_pitch),
+                              int(channels), int(frames), int(skip), int(bool(rectify)),
+                              float(gain), int(bool(clamp))))
+
+
+def spectrogram(ctx, x, x_pitch, channels, frames, nfft, hop, fs, out, frames_out, db_out=None):
+    check(lib.hipdsp_spectrogram(ctx.handle, _p(x), int(x_pitch), int(channels), int(frames),
+                                 int(nfft), int(hop), float(fs), _p(out), _p(db_out),
+                                 int(frames_out)))
+
+
+def decibel(ctx, p, out, n, ref_power=1.0, min_power=1e-20):
+    check(lib.hipdsp_decibel(ctx.handle, _p(p), _p(out), int(n), float(ref_power),
+                             float(min_power)))
+
+
+def decibel_image(ctx, spec_tf, image_ft, frames, nfreq, ref_power=1.0, min_power=1e-20):
+    check(lib.hipdsp_decibel_image(ctx.handle, _p(spec_tf), _p(image_ft), int(frames), int(nfreq),
+                                   float(ref_power), float(min_power)))
+
+
+def pack(ctx, src_tc, dst, dst_pitch, frames, channels, src_dtype=np.float64):
+    fn = lib.hipdsp_pack_f64 if np.dtype(src_dtype) == np.float64 else lib.hipdsp_pack_f32
+    check(fn(ctx.handle, _p(src_tc), _p(dst), int(dst_pitch), int(frames), int(channels)))
+
+
+def unpack(ctx, src, src_pitch, dst_tc, frames, channels):
+    check(lib.hipdsp_unpack_f64(ctx.handle, _p(src), int(src_pitch), _p(dst_tc), int(frames),
+                                int(channels)))
+
+
+def unpack_spectrum(ctx, src, dst_tcf, frames, channels, nfreq):
+    check(lib.hipdsp_unpack_spectrum_f64(ctx.handle, _p(src), _p(dst_tcf), int(frames),
+                                         int(channels), int(nfreq)))
+
+
+def synth(ctx, x, x_pitch, channels, frames, rate, seed, c0=0, c_total=None):
+    check(lib.hipdsp_synth(ctx.handle, _p(x), int(x_pitch), int(channels), int(frames),
+                           float(rate), int(seed), int(c0),
+                           int(c_total if c_total is not None else channels)))

@@ -1,0 +1,178 @@
+/*
+ * hip_dsp.h -- C ABI of libhip_dsp.so: MI355X (gfx950) kernels for audian's
+ * BufferedData DSP hot path.
+ *
+ * The reference (bendalab/audian) is pure Python and has no FFI of its own; each
+ * entry point below names the reference call (file:line under /root/reference)
+ * whose arithmetic it replaces.  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no exceptions across the boundary.
+ *   - Every call returns an int status (HIPDSP_OK == 0); hipdsp_last_error()
+ *     returns a thread-local message for the last failing call.
+ *   - All data pointers are DEVICE pointers unless the name says "host"; buffers
+ *     are caller-owned.  Work is enqueued on the context's HIP stream and is
+ *     asynchronous; hipdsp_ctx_synchronize() waits for it.
+ *   - Device-native layout is planar float32: a trace is (channels, frames) with
+ *     a row pitch in elements; a spectrogram is (channels, frames', F) compact.
+ *     The reference's layouts are time-major float64 (T, C) / (T', C, F)
+ *     (src/audian/buffereddata.py:46-48,70); the pack/unpack entry points convert
+ *     at the edge.
+ *   - IIR coefficients and state are float64 (mandatory); HBM I/O is
+ *     float32.
+ */
+#ifndef HIP_DSP_H
+#define HIP_DSP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPDSP_VERSION 100          /* 0.1.0 */
+
+#define HIPDSP_OK               0
+#define HIPDSP_ERR_INVALID      1   /* bad argument */
+#define HIPDSP_ERR_HIP          2   /* HIP runtime failure (message has detail) */
+#define HIPDSP_ERR_UNSUPPORTED  3   /* valid in the reference, not implemented here */
+#define HIPDSP_ERR_TOO_SHORT    4   /* sosfiltfilt: frames <= padlen (scipy: ValueError) */
+#define HIPDSP_ERR_NOMEM        5
+
+#define HIPDSP_MAX_SECTIONS     4   /* second-order sections per plan (cascade longer ones) */
+
+typedef struct hipdsp_ctx hipdsp_ctx;
+typedef struct hipdsp_sosplan hipdsp_sosplan;
+
+/* ---- library / context ------------------------------------------------- */
+
+int hipdsp_version(void);
+const char *hipdsp_last_error(void);
+int hipdsp_device_count(int *count);
+
+/* `stream` is a hipStream_t (NULL = the legacy default stream). */
+int hipdsp_ctx_create(int device, void *stream, hipdsp_ctx **out);
+int hipdsp_ctx_destroy(hipdsp_ctx *ctx);
+int hipdsp_ctx_set_stream(hipdsp_ctx *ctx, void *stream);
+int hipdsp_ctx_synchronize(hipdsp_ctx *ctx);
+/* Tuning knob: upper bound on time segments per channel of the block-parallel
+ * IIR (0 = automatic).  Results do not depend on it beyond fp64 rounding. */
+int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
+/* Pre-size the internal scratch (envelope forward pass) so that later calls do
+ * not allocate; required before stream capture into a hipGraph. */
+int hipdsp_ctx_reserve(hipdsp_ctx *ctx, size_t bytes);
+
+/* ---- device memory helpers (so a non-torch host can keep stages resident) */
+
+int hipdsp_malloc(hipdsp_ctx *ctx, size_t bytes, void **dptr);
+int hipdsp_free(hipdsp_ctx *ctx, void *dptr);
+int hipdsp_memset(hipdsp_ctx *ctx, void *dptr, int value, size_t bytes);
+int hipdsp_memcpy_h2d(hipdsp_ctx *ctx, void *dst, const void *host_src, size_t bytes);
+int hipdsp_memcpy_d2h(hipdsp_ctx *ctx, void *host_dst, const void *src, size_t bytes);
+int hipdsp_memcpy_d2d(hipdsp_ctx *ctx, void *dst, const void *src, size_t bytes);
+
+/* HIP events on the context's stream (bench.py times kernels with these). */
+int hipdsp_event_create(hipdsp_ctx *ctx, void **event);
+int hipdsp_event_destroy(hipdsp_ctx *ctx, void *event);
+int hipdsp_event_record(hipdsp_ctx *ctx, void *event);
+int hipdsp_event_elapsed_ms(hipdsp_ctx *ctx, void *start, void *stop, float *ms);
+
+/* ---- layout conversion at the edge -------------------------------------- */
+
+/* (T, C) interleaved float64 / float32 -> planar (C, dst_pitch) float32.
+ * Replaces the implicit layout of BufferedArray buffers (buffereddata.py:70). */
+int hipdsp_pack_f64(hipdsp_ctx *ctx, const double *src_tc, float *dst, int64_t dst_pitch,
+                    int64_t frames, int64_t channels);
+int hipdsp_pack_f32(hipdsp_ctx *ctx, const float *src_tc, float *dst, int64_t dst_pitch,
+                    int64_t frames, int64_t channels);
+/* planar (C, src_pitch) float32 -> (T, C) interleaved float64. */
+int hipdsp_unpack_f64(hipdsp_ctx *ctx, const float *src, int64_t src_pitch, double *dst_tc,
+                      int64_t frames, int64_t channels);
+/* (C, T', F) float32 -> (T', C, F) float64: the reference's
+ * Sxx.transpose((1, 2, 0)) (bufferedspectrogram.py:58). */
+int hipdsp_unpack_spectrum_f64(hipdsp_ctx *ctx, const float *src, double *dst_tcf,
+                               int64_t frames, int64_t channels, int64_t nfreq);
+
+/* ---- IIR filter plans ---------------------------------------------------- */
+
+/* A plan holds, in device memory, everything the block-parallel biquad cascade
+ * needs for one SOS table: coefficients, block transition matrices, steady-state
+ * initial conditions (scipy sosfilt_zi) and the warm-up length.  Updating a plan
+ * (hipdsp_sosplan_set) is an async copy on the stream, so a captured hipGraph
+ * replays under new cut-offs. */
+int hipdsp_sosplan_create(hipdsp_ctx *ctx, hipdsp_sosplan **out);
+int hipdsp_sosplan_destroy(hipdsp_ctx *ctx, hipdsp_sosplan *plan);
+/* host_sos: (n_sections, 6) float64 rows [b0 b1 b2 a0 a1 a2], a0 == 1, exactly
+ * what scipy.signal.butter(..., output='sos') returns
+ * (bufferedfilter.py:44-52, bufferedenvelope.py:47-52). */
+int hipdsp_sosplan_set(hipdsp_ctx *ctx, hipdsp_sosplan *plan, const double *host_sos,
+                       int n_sections);
+/* The two halves of hipdsp_sosplan_set, for hipGraph use: _set_host computes the
+ * plan into pinned host memory (no stream work); _upload enqueues the copy to the
+ * device block and may be captured, so each replay picks up the latest _set_host. */
+int hipdsp_sosplan_set_host(hipdsp_ctx *ctx, hipdsp_sosplan *plan, const double *host_sos,
+                            int n_sections);
+int hipdsp_sosplan_upload(hipdsp_ctx *ctx, hipdsp_sosplan *plan);
+/* Introspection (tests): warm-up length in samples, sosfiltfilt pad length. */
+int hipdsp_sosplan_info(hipdsp_ctx *ctx, hipdsp_sosplan *plan, int64_t *warmup, int *edge);
+
+/* ---- the hot path --------------------------------------------------------- */
+
+/* BufferedFilter.process (bufferedfilter.py:31-36):
+ *   y[c, :] = sosfilt(sos, x[c, :])[skip:]      zero initial state, per channel.
+ * x: (channels, x_pitch) with `frames` valid samples; y: (channels, y_pitch) with
+ * frames - skip valid samples.  plan == NULL copies x[skip:] (the sos-is-None
+ * pass-through branch, bufferedfilter.py:32-33). */
+int hipdsp_sosfilt(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const float *x,
+                   int64_t x_pitch, float *y, int64_t y_pitch, int64_t channels,
+                   int64_t frames, int64_t skip);
+
+/* BufferedEnvelope.process (bufferedenvelope.py:34-41):
+ *   y = sosfiltfilt(sos, gain*|x|, axis=0)[skip:]; if clamp: y[y < 0] = 0
+ * with scipy's default odd padding of 3*ntaps samples, sosfilt_zi-scaled initial
+ * conditions, forward then backward pass.  `rectify` != 0 applies gain*|x|
+ * (gain = pi/2 in the reference), rectify == 0 filters x itself (plain
+ * sosfiltfilt, e.g. the playback chain databrowser.py:1718-1729).
+ * Returns HIPDSP_ERR_TOO_SHORT when frames <= padlen (scipy raises ValueError).
+ * plan == NULL writes zeros (bufferedenvelope.py:35-36). */
+int hipdsp_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const float *x,
+                    int64_t x_pitch, float *y, int64_t y_pitch, int64_t channels,
+                    int64_t frames, int64_t skip, int rectify, double gain, int clamp);
+
+/* BufferedSpectrogram.process (bufferedspectrogram.py:45-59) ==
+ * scipy.signal.spectrogram(x, fs, 'hann', nperseg=nfft, noverlap=nfft-hop,
+ * detrend='constant', scaling='density', mode='psd'):
+ *   out[c, k, :] = one-sided PSD of x[c, k*hop : k*hop + nfft] for k < n_valid,
+ *   zeros for n_valid <= k < frames_out,
+ * where n_valid = (nsource - (nfft - hop)) / hop and
+ * nsource = min((frames_out - 1)*hop + nfft, frames)  (0 valid frames when
+ * nsource < nfft).  out is (channels, frames_out, nfft/2 + 1) compact float32.
+ * If db_out != NULL it additionally receives decibel(out) (fused epilogue,
+ * specitem.py:36) in the same layout.  nfft must be a power of two in [8, 8192]. */
+int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, int64_t channels,
+                       int64_t frames, int nfft, int hop, double fs, float *out,
+                       float *db_out, int64_t frames_out);
+
+/* thunderlab.powerspectrum.decibel (specitem.py:28,36; spectrogramplot.py:159;
+ * bufferedspectrogram.py:116-117): out = 10*log10(p/ref_power), -inf where
+ * p <= min_power. */
+int hipdsp_decibel(hipdsp_ctx *ctx, const float *p, float *out, int64_t n, double ref_power,
+                   double min_power);
+/* SpecItem.update_plot (specitem.py:36): decibel(buffer[:, ch, :].T) -- one
+ * channel's (frames, nfreq) slab to a (nfreq, frames) dB image. */
+int hipdsp_decibel_image(hipdsp_ctx *ctx, const float *spec_tf, float *image_ft,
+                         int64_t frames, int64_t nfreq, double ref_power, double min_power);
+
+/* ---- synthetic input (bench / tests) --------------------------- */
+
+/* x[c, t] = 0.5*u(seed, c, t) + 0.5*sin(2*pi*1000*(1 + (c0 + c)/c_total)*t/rate),
+ * u uniform in [-1, 1) from a counter-based hash; generated on device. */
+int hipdsp_synth(hipdsp_ctx *ctx, float *x, int64_t x_pitch, int64_t channels,
+                 int64_t frames, double rate, uint64_t seed, int64_t c0, int64_t c_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIP_DSP_H */

@@ -1,0 +1,226 @@
+"""HIP path vs the CPU oracle and the scipy golden fixtures, through the C ABI.
+
+Tolerance (BASELINE.json north_star): 1e-4 relative float32, measured as
+max|a-b| / max|b| per channel (per frame for PSDs) -- see conftest.rel_err.
+"""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+import gpu_helpers as gh
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def synth(rng, n, channels, rate):
+    t = np.arange(n)/rate
+    x = rng.uniform(-1.0, 1.0, size=(n, channels))
+    for c in range(channels):
+        x[:, c] = 0.5*x[:, c] + 0.5*np.sin(2*np.pi*1000.0*(1 + c/channels)*t)
+    return x.astype(np.float32)
+
+
+def test_library_and_device():
+    from audian_amd import _lib, hipdsp
+    assert _lib.lib.hipdsp_version() == 100
+    c = gh.ctx()
+    a = hipdsp.DeviceArray.from_host(c, np.arange(10, dtype=np.float32))
+    assert np.array_equal(a.to_host(), np.arange(10, dtype=np.float32))
+
+
+def test_pack_unpack_roundtrip():
+    rng = np.random.default_rng(1)
+    for T, C in [(1, 1), (33, 3), (1000, 64), (4097, 5)]:
+        x = rng.standard_normal((T, C))
+        c = gh.ctx()
+        y = gh.from_planar(c, gh.to_planar(c, x), T, C)
+        assert np.array_equal(y, x.astype(np.float32).astype(np.float64))
+        x32 = x.astype(np.float32)
+        y = gh.from_planar(c, gh.to_planar(c, x32), T, C)
+        assert np.array_equal(y, x32.astype(np.float64))
+
+
+def test_sosfilt_golden():
+    g = load_golden('sosfilt')
+    for k in range(int(g['count'])):
+        sos, x, y = g[f'sos_{k}'], g[f'x_{k}'], g[f'y_{k}']
+        got = gh.gpu_sosfilt(sos, x)
+        assert got.shape == y.shape
+        for c in range(y.shape[1]):
+            assert rel_err(got[:, c], y[:, c]) < TOL, (k, c)
+
+
+@pytest.mark.parametrize('btype,order,wn,rate,T', [
+    ('bandpass', 2, (300.0, 3000.0), 96000.0, 300001),
+    ('bandpass', 4, (300.0, 3000.0), 48000.0, 200000),
+    ('lowpass', 2, (20.0,), 96000.0, 1500000),
+    ('bandpass', 2, (5.0, 3000.0), 96000.0, 700003),
+    ('highpass', 3, (100.0,), 192000.0, 150000),
+    ('lowpass', 1, (4000.0,), 48000.0, 70000),
+])
+def test_sosfilt_long_vs_oracle(oracle, btype, order, wn, rate, T):
+    """Many tiles and several time segments (warm-up path) against the C oracle."""
+    from audian_amd.design import butter_sos
+    rng = np.random.default_rng(7)
+    sos = butter_sos(order, wn if len(wn) > 1 else wn[0], btype, rate)
+    x = synth(rng, T, 3, rate)
+    want = oracle.sosfilt(sos, x.astype(np.float64))
+    got = gh.gpu_sosfilt(sos, x)
+    for c in range(3):
+        assert rel_err(got[:, c], want[:, c]) < TOL
+    # the result must not depend on the segmentation
+    one = gh.gpu_sosfilt(sos, x, max_segments=1)
+    for c in range(3):
+        assert rel_err(one[:, c], want[:, c]) < TOL
+        assert rel_err(got[:, c], one[:, c]) < 1e-6
+
+
+def test_sosfilt_skip_and_passthrough(oracle):
+    g = load_golden('sosfilt')
+    sos, x, y = g['sos_2'], g['x_2'], g['y_2']
+    for skip in (1, 5, 1024, len(x) - 1, len(x)):
+        got = gh.gpu_sosfilt(sos, x, skip=skip)
+        assert got.shape == (len(x) - skip, x.shape[1])
+        if skip < len(x):
+            assert rel_err(got, y[skip:]) < TOL
+    got = gh.gpu_sosfilt(None, x, skip=3)           # sos is None: pass-through
+    assert np.array_equal(got, x[3:].astype(np.float64))
+
+
+def test_envelope_golden():
+    g = load_golden('envelope')
+    for k in range(int(g['count'])):
+        sos, x, y = g[f'sos_{k}'], g[f'x_{k}'], g[f'y_{k}']
+        got = gh.gpu_envelope(sos, x, clamp=float(g[f'hp_{k}']) == 0)
+        for c in range(y.shape[1]):
+            assert rel_err(got[:, c], y[:, c]) < TOL, (k, c)
+
+
+def test_envelope_too_short_raises():
+    g = load_golden('envelope')
+    sos = g['sos_0']
+    with pytest.raises(ValueError):
+        gh.gpu_envelope(sos, np.ones((9, 1), dtype=np.float32))
+    gh.gpu_envelope(sos, np.ones((10, 1), dtype=np.float32))
+    got = gh.gpu_envelope(None, np.ones((100, 2), dtype=np.float32))    # sos None -> zeros
+    assert np.all(got == 0)
+
+
+@pytest.mark.parametrize('env,order,hp,rate,T', [
+    (20.0, 2, 0.0, 96000.0, 1500000),
+    (500.0, 2, 0.0, 48000.0, 400000),
+    (500.0, 2, 10.0, 48000.0, 400000),
+    (200.0, 3, 0.0, 44100.0, 250000),
+])
+def test_envelope_long_vs_oracle(oracle, env, order, hp, rate, T):
+    from audian_amd.design import butter_sos
+    rng = np.random.default_rng(8)
+    sos = butter_sos(order, (hp, env), 'bandpass', rate) if hp > 0 else \
+        butter_sos(order, env, 'lowpass', rate)
+    x = synth(rng, T, 2, rate)
+    want = np.zeros((T, 2))
+    oracle.envelope_process(sos, x.astype(np.float64), want, 0, highpass_cutoff=hp)
+    got = gh.gpu_envelope(sos, x, clamp=hp == 0)
+    for c in range(2):
+        assert rel_err(got[:, c], want[:, c]) < TOL
+    got = gh.gpu_envelope(sos, x, skip=7, clamp=hp == 0)
+    assert rel_err(got, want[7:]) < TOL
+
+
+def test_spectrogram_golden():
+    g = load_golden('spectrogram')
+    for k in range(int(g['count'])):
+        rate, nfft, hop = g[f'par_{k}']
+        nfft, hop = int(nfft), int(hop)
+        x, S = g[f'x_{k}'], g[f'S_{k}']              # S: (F, T', C)
+        if nfft & (nfft - 1):
+            with pytest.raises(NotImplementedError):
+                gh.gpu_spectrogram(x, rate, nfft, hop, S.shape[1])
+            continue
+        nd = S.shape[1] + 2                          # two zero tail frames
+        got = gh.gpu_spectrogram(x, rate, nfft, hop, nd)
+        assert got.shape == (nd, x.shape[1], nfft//2 + 1)
+        assert np.all(got[S.shape[1]:] == 0)
+        for c in range(S.shape[2]):
+            for j in range(S.shape[1]):
+                assert rel_err(got[j, c, :], S[:, j, c]) < TOL, (k, j, c)
+
+
+def test_spectrogram_short_source_and_db(oracle):
+    x = np.ones((100, 2), dtype=np.float32)
+    got = gh.gpu_spectrogram(x, 48000.0, 256, 128, 3)
+    assert np.all(got == 0)
+    g = load_golden('spectrogram')
+    x, S = g['x_1'], g['S_1']
+    got, db = gh.gpu_spectrogram(x, 48000.0, 1024, 256, S.shape[1] + 1, want_db=True)
+    want = oracle.decibel(got)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(db), fin)
+    assert np.all(db[~fin] == -np.inf)
+    assert np.max(np.abs(db[fin] - want[fin])) < 1e-3
+
+
+def test_decibel_golden():
+    from audian_amd import hipdsp
+    g = load_golden('decibel')
+    c = gh.ctx()
+    p = g['p'].astype(np.float32)
+    want = np.full(p.shape, -np.inf)
+    m = p > np.float32(1e-20)
+    want[m] = 10*np.log10(p[m].astype(np.float64))
+    dp = hipdsp.DeviceArray.from_host(c, p)
+    out = hipdsp.DeviceArray(c, p.shape, np.float32)
+    hipdsp.decibel(c, dp, out, p.size)
+    got = out.to_host()
+    assert np.array_equal(np.isinf(got), ~m)
+    assert np.max(np.abs(got[m] - want[m])) < 1e-4
+    # SpecItem image: decibel(buffer[:, ch, :].T)
+    rng = np.random.default_rng(3)
+    spec = (10.0**rng.uniform(-12, 2, size=(70, 129))).astype(np.float32)
+    ds = hipdsp.DeviceArray.from_host(c, spec)
+    img = hipdsp.DeviceArray(c, (129, 70), np.float32)
+    hipdsp.decibel_image(c, ds, img, 70, 129)
+    assert np.max(np.abs(img.to_host() - 10*np.log10(spec.astype(np.float64)).T)) < 1e-4
+
+
+def test_chain_golden():
+    """data -> filter -> {spectrogram, envelope}, stages resident on the device."""
+    from audian_amd import hipdsp
+    g = load_golden('chain')
+    c = gh.ctx()
+    x = g['x']
+    T, C = x.shape
+    dx = gh.to_planar(c, x)
+    df = hipdsp.DeviceArray(c, (C, T), np.float32)
+    hipdsp.sosfilt(c, hipdsp.SosPlan(c, g['sos']), dx, T, df, T, C, T, 0)
+    nd = g['spec'].shape[0] + 1
+    ds = hipdsp.DeviceArray(c, (C, nd, 129), np.float32)
+    hipdsp.spectrogram(c, df, T, C, T, 256, 128, float(g['rate']), ds, nd)
+    de = hipdsp.DeviceArray(c, (C, T), np.float32)
+    hipdsp.envelope(c, hipdsp.SosPlan(c, g['esos']), df, T, de, T, C, T, 0)
+    filt = gh.from_planar(c, df, T, C)
+    env = gh.from_planar(c, de, T, C)
+    spec = ds.to_host().transpose(1, 0, 2)
+    for ch in range(C):
+        assert rel_err(filt[:, ch], g['filt'][:, ch]) < TOL
+        assert rel_err(env[:, ch], g['env'][:, ch]) < TOL
+        for j in range(nd - 1):
+            assert rel_err(spec[j, ch], g['spec'][j, ch]) < TOL
+    assert np.all(spec[-1] == 0)
+
+
+def test_synth_is_deterministic_and_bounded():
+    from audian_amd import hipdsp
+    c = gh.ctx()
+    a = hipdsp.DeviceArray(c, (4, 96000), np.float32)
+    b = hipdsp.DeviceArray(c, (2, 96000), np.float32)
+    hipdsp.synth(c, a, 96000, 4, 96000, 96000.0, 1234)
+    hipdsp.synth(c, b, 96000, 2, 96000, 96000.0, 1234, c0=2, c_total=4)
+    ha, hb = a.to_host(), b.to_host()
+    assert np.array_equal(ha[2:], hb)                 # channel shards agree with the whole
+    assert np.all(np.abs(ha) <= 1.0)
+    spec = np.abs(np.fft.rfft(ha[1]))                 # tone at 1000*(1 + 1/4) Hz
+    assert np.argmax(spec[1:]) + 1 == 1250
