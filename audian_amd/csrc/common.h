@@ -16,6 +16,7 @@ struct hipdsp_ctx {
     int n_cus;
     void *scratch;         // envelope forward-pass intermediate
     size_t scratch_bytes;
+    hipEvent_t mid_event;  // optional: recorded between envelope fwd and bwd
 };
 
 #define HD_CHECK_HIP(expr)                                                        \

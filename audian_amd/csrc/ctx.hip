@@ -46,6 +46,7 @@ int hipdsp_ctx_create(int device, void *stream, hipdsp_ctx **out)
     ctx->n_cus = prop.multiProcessorCount;
     ctx->scratch = nullptr;
     ctx->scratch_bytes = 0;
+    ctx->mid_event = nullptr;
     *out = ctx;
     return HIPDSP_OK;
 }
@@ -77,6 +78,13 @@ int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments)
     HD_REQUIRE(ctx != nullptr, "ctx is NULL");
     HD_REQUIRE(max_segments >= 0, "max_segments must be >= 0");
     ctx->max_segments = max_segments;
+    return HIPDSP_OK;
+}
+
+int hipdsp_ctx_set_mid_event(hipdsp_ctx *ctx, void *event)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    ctx->mid_event = (hipEvent_t)event;
     return HIPDSP_OK;
 }
 

@@ -664,6 +664,7 @@ int hipdsp_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const float *x,
     rc = launch_scan<MODE_ENV_FWD>(ctx, plan, plan->dev, plan->host->n_sections, a, channels,
                                    plan->host->warm);
     if (rc != HIPDSP_OK) return rc;
+    if (ctx->mid_event) HD_CHECK_HIP(hipEventRecord(ctx->mid_event, ctx->stream));
     if (frames - skip == 0) return HIPDSP_OK;
     // backward pass over the reversed scratch -> y (trim edge, skip, clamp)
     a.in = (const float *)work; a.in_pitch = wpitch; a.out = y; a.out_pitch = y_pitch;

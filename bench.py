@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Benchmark of the BufferedData DSP hot path on MI355X.
+
+One "step" = one pass of the chain  data -> BufferedFilter (Butterworth band-pass)
+-> {BufferedSpectrogram (Hann STFT PSD), BufferedEnvelope (rectify + sosfiltfilt)}
+over one batch of synthetic multichannel float32 audio that is already resident in
+HBM (BASELINE.json configs[2]: 64 ch x 600 s x 96 kHz per GPU, nfft 2048 / hop 1024,
+band-pass 300-3000 Hz order 2, envelope low-pass 20 Hz).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line: whole-job Msamples/s, the HBM roofline of the dominant
+kernel (HIP-event timed inside the timed region) and, at N=1, the reference's scipy
+CPU path timed on this box's host cores on a bounded sample.
+"""
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--channels', type=int, default=64, help='channels per GPU')
+    ap.add_argument('--seconds', type=float, default=600.0)
+    ap.add_argument('--rate', type=float, default=96000.0)
+    ap.add_argument('--nfft', type=int, default=2048)
+    ap.add_argument('--hop', type=int, default=1024)
+    ap.add_argument('--hp', type=float, default=300.0)
+    ap.add_argument('--lp', type=float, default=3000.0)
+    ap.add_argument('--order', type=int, default=2)
+    ap.add_argument('--env', type=float, default=20.0)
+    ap.add_argument('--tile-seconds', type=float, default=80.0,
+                    help='N>1: length of the spectrogram tile that is all-gathered')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-seconds', type=float, default=60.0)
+    ap.add_argument('--max-segments', type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, sos, esos):
+    """The reference's own CPU path (scipy call pattern, float64, one thread) on a
+    bounded sample of the same workload; falls back to the C/NumPy oracle port."""
+    C, T = args.channels, int(args.cpu_sample_seconds*args.rate)
+    rng = np.random.default_rng(1234 + 2)
+    t = np.arange(T)/args.rate
+    x = rng.uniform(-1.0, 1.0, size=(T, C))
+    for c in range(C):
+        x[:, c] = 0.5*x[:, c] + 0.5*np.sin(2*np.pi*1000.0*(1 + c/C)*t)
+    try:
+        from oracle import scipy_path as path
+        impl = 'scipy %s call pattern of the reference (oracle/scipy_path.py)' % \
+            __import__('scipy').__version__
+        run = lambda: path.chain(x, args.rate, sos, esos, args.nfft, args.hop)
+    except ImportError:
+        from oracle import oracle as path
+        impl = 'C/NumPy oracle port (oracle/oracle.py); scipy not installed'
+
+        def run():
+            filt = np.zeros_like(x)
+            path.filter_process(sos, x, filt, 0)
+            spec = np.zeros(((T + args.hop - 1)//args.hop, C, args.nfft//2 + 1))
+            path.spectrogram_process(filt, spec, args.rate, args.nfft, args.hop)
+            env = np.zeros_like(x)
+            path.envelope_process(esos, filt, env, 0)
+    t0 = time.perf_counter()
+    run()
+    dt = time.perf_counter() - t0
+    return {'value': C*T/dt/1e6, 'unit': 'Msamples/s', 'cores': 1, 'kind': 'port',
+            'host_cores': os.cpu_count(),
+            'sample': f'{C} ch x {args.cpu_sample_seconds:g} s x {args.rate/1000:g} kHz float64, '
+                      f'same chain, {dt:.1f} s wall; {impl}'}
+
+
+def parity_subset(args, hipdsp, ctx, dx, df, ds, de, T, nd, sos, esos):
+    """First 2 s of channels {0, C/2, C-1}: HIP outputs vs the CPU oracle
+    (max|a-b|/max|b| per channel, per frame for the PSD)."""
+    from oracle import oracle
+    C, F = args.channels, args.nfft//2 + 1
+    n_cmp = min(T, int(2*args.rate))
+    n_in = min(T, int(3*args.rate))          # the backward pass needs a look-ahead
+    worst = 0.0
+    for c in sorted({0, C//2, C - 1}):
+        x = dx.view(c*T, (n_in,)).to_host().astype(np.float64)[:, None]
+        filt = np.zeros_like(x)
+        oracle.filter_process(sos, x, filt, 0)
+        g = df.view(c*T, (n_cmp,)).to_host()
+        worst = max(worst, np.max(np.abs(g - filt[:n_cmp, 0]))/np.max(np.abs(filt[:n_cmp, 0])))
+        env = np.zeros_like(x)
+        oracle.envelope_process(esos, filt, env, 0)
+        g = de.view(c*T, (n_cmp,)).to_host()
+        worst = max(worst, np.max(np.abs(g - env[:n_cmp, 0]))/np.max(np.abs(env[:n_cmp, 0])))
+        nfr = min(nd, (n_cmp - args.nfft)//args.hop)
+        if nfr > 0:
+            spec = np.zeros((nfr, 1, F))
+            oracle.spectrogram_process(filt[:(nfr - 1)*args.hop + args.nfft], spec, args.rate,
+                                       args.nfft, args.hop)
+            g = ds.view(c*nd*F, (nfr, F)).to_host()
+            for k in range(nfr):
+                worst = max(worst, np.max(np.abs(g[k] - spec[k, 0]))/np.max(np.abs(spec[k, 0])))
+    return float(worst)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus N > 1 must be launched with torch.distributed.run '
+                     '(one rank per GPU)')
+        args.gpus = world
+
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        stream = torch.cuda.current_stream().cuda_stream
+    else:
+        stream = None
+    ctx = hipdsp.Context(local_rank, stream)
+    if args.max_segments:
+        ctx.set_max_segments(args.max_segments)
+
+    C, T = args.channels, int(round(args.seconds*args.rate))
+    F = args.nfft//2 + 1
+    nd = (T + args.hop - 1)//args.hop                 # BufferedData.update_step frames
+    sos = butter_sos(args.order, (args.hp, args.lp), 'bandpass', args.rate)
+    esos = butter_sos(2, args.env, 'lowpass', args.rate)
+    plan, eplan = hipdsp.SosPlan(ctx, sos), hipdsp.SosPlan(ctx, esos)
+    warm_f, _ = plan.info()
+    warm_e, edge = eplan.info()
+
+    dx = hipdsp.DeviceArray(ctx, (C, T), np.float32)
+    df = hipdsp.DeviceArray(ctx, (C, T), np.float32)
+    de = hipdsp.DeviceArray(ctx, (C, T), np.float32)
+    if world > 1:
+        tspec = torch.empty((C, nd, F), dtype=torch.float32, device='cuda')
+        ds = hipdsp.DeviceArray(ctx, (C, nd, F), np.float32, ptr=tspec.data_ptr(), owner=tspec)
+        tile_frames = min(nd, int(math.ceil(args.tile_seconds*args.rate/args.hop)))
+        gathered = torch.empty((world*C, tile_frames, F), dtype=torch.float32, device='cuda')
+    else:
+        ds = hipdsp.DeviceArray(ctx, (C, nd, F), np.float32)
+    ctx.reserve(4*C*((T + 2*edge + 3)//4*4))
+    hipdsp.synth(ctx, dx, T, C, T, args.rate, 1234 + 2, c0=rank*C, c_total=world*C)
+    ctx.synchronize()
+
+    n_ev = 5
+    total = args.warmup + args.steps
+    events = [[ctx.event() for _ in range(n_ev)] for _ in range(args.steps)]
+    mids = [ctx.event() for _ in range(args.steps)]
+
+    def step(i):
+        ev = events[i] if i >= 0 else None
+        if ev:
+            ctx.record(ev[0])
+        hipdsp.sosfilt(ctx, plan, dx, T, df, T, C, T, 0)
+        if ev:
+            ctx.record(ev[1])
+        hipdsp.spectrogram(ctx, df, T, C, T, args.nfft, args.hop, args.rate, ds, nd)
+        if ev:
+            ctx.record(ev[2])
+            ctx.set_mid_event(mids[i])
+        hipdsp.envelope(ctx, eplan, df, T, de, T, C, T, 0, rectify=True, gain=np.pi/2, clamp=True)
+        if ev:
+            ctx.set_mid_event(None)
+            ctx.record(ev[3])
+        if world > 1:
+            # merged spectrogram tile of the visible window on every rank (RCCL over xGMI)
+            dist.all_gather_into_tensor(gathered, tspec[:, :tile_frames, :].contiguous())
+        if ev:
+            ctx.record(ev[4])
+
+    def fence():
+        ctx.synchronize()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(-1)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # per-kernel averages from the HIP events recorded inside the timed region
+    names = ['sos_scan<S=%d,filt>' % len(sos), 'spectrogram', 'sos_scan<S=%d,env_fwd>' % len(esos),
+             'sos_scan<S=%d,env_bwd>' % len(esos), 'allgather_tile']
+    ms = dict.fromkeys(names, 0.0)
+    for i in range(args.steps):
+        e = events[i]
+        ms[names[0]] += ctx.elapsed_ms(e[0], e[1])
+        ms[names[1]] += ctx.elapsed_ms(e[1], e[2])
+        ms[names[2]] += ctx.elapsed_ms(e[2], mids[i])
+        ms[names[3]] += ctx.elapsed_ms(mids[i], e[3])
+        ms[names[4]] += ctx.elapsed_ms(e[3], e[4])
+    for k in ms:
+        ms[k] /= args.steps
+    alg_bytes = {                       # algorithmic HBM bytes per launch
+        names[0]: 8.0*C*T,
+        names[1]: 4.0*C*T + 4.0*C*nd*F,
+        names[2]: 8.0*C*(T + 2*edge),
+        names[3]: 8.0*C*T + 4.0*C*2*edge,
+    }
+    dom = max(alg_bytes, key=lambda k: ms[k])
+    achieved = alg_bytes[dom]/(ms[dom]*1e-3)/1e9
+    kernels = {k: {'ms': round(ms[k], 4),
+                   'GBps': round(alg_bytes[k]/(ms[k]*1e-3)/1e9, 1) if k in alg_bytes and ms[k] > 0 else None}
+               for k in names if k != 'allgather_tile' or world > 1}
+
+    parity = None
+    cpu = None
+    if rank == 0:
+        parity = parity_subset(args, hipdsp, ctx, dx, df, ds, de, T, nd, sos, esos)
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args, sos, esos)
+
+    if rank == 0:
+        samples = float(C)*T*world
+        line = {
+            'metric': 'Msamples/s spectrogram+bandpass, 64ch x 96kHz',
+            'value': samples/(dt/args.steps)/1e6,
+            'unit': 'Msamples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt/args.steps*1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32 I/O, f64 IIR state',
+            'data': 'synthetic',
+            'config': {
+                'workload': f'BASELINE configs[2]: synthetic {C} ch/GPU x {args.seconds:g} s x '
+                            f'{args.rate/1000:g} kHz float32; bandpass {args.hp:g}-{args.lp:g} Hz '
+                            f'order {args.order} -> spectrogram nfft {args.nfft} hop {args.hop} '
+                            f'+ envelope {args.env:g} Hz',
+                'channels_per_gpu': C, 'frames': T, 'spectrogram_frames': nd,
+                'parallelism': f'channel shard x{world}' +
+                               (f', all-gather of the {args.tile_seconds:g} s spectrogram tile'
+                                if world > 1 else ''),
+                'iir_warmup_samples': {'bandpass': warm_f, 'envelope': warm_e},
+            },
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 1),
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(achieved/HBM_PEAK_GBS, 4), 'traffic': None},
+            'kernels': kernels,
+            'chain_algorithmic_GBps': round(sum(alg_bytes.values())/(dt/args.steps)/1e9, 1),
+            'parity_max_rel_err': parity,
+            'cpu_baseline': cpu,
+        }
+        if parity is None or not parity < 1e-4:
+            line['invalid'] = 'parity gate failed'
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

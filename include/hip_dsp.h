@@ -79,6 +79,10 @@ int hipdsp_event_destroy(hipdsp_ctx *ctx, void *event);
 int hipdsp_event_record(hipdsp_ctx *ctx, void *event);
 int hipdsp_event_elapsed_ms(hipdsp_ctx *ctx, void *start, void *stop, float *ms);
 
+/* Profiling hook: when set (non-NULL), hipdsp_envelope records this event between
+ * its forward and backward kernels, so a bench can time the two separately. */
+int hipdsp_ctx_set_mid_event(hipdsp_ctx *ctx, void *event);
+
 /* ---- layout conversion at the edge -------------------------------------- */
 
 /* (T, C) interleaved float64 / float32 -> planar (C, dst_pitch) float32.
