@@ -46,6 +46,7 @@ _SIGNATURES = {
     'hipdsp_ctx_set_stream': ([_vp, _vp], _int),
     'hipdsp_ctx_synchronize': ([_vp], _int),
     'hipdsp_ctx_set_max_segments': ([_vp, _int], _int),
+    'hipdsp_ctx_set_option': ([_vp, ctypes.c_char_p, ctypes.c_longlong], _int),
     'hipdsp_ctx_reserve': ([_vp, _sz], _int),
     'hipdsp_ctx_set_mid_event': ([_vp, _vp], _int),
     'hipdsp_malloc': ([_vp, _sz, _pp], _int),

@@ -17,6 +17,8 @@ struct hipdsp_ctx {
     void *scratch;         // envelope forward-pass intermediate
     size_t scratch_bytes;
     hipEvent_t mid_event;  // optional: recorded between envelope fwd and bwd
+    void *fft_tables[20];  // per log2(nfft): window | TWM | TWN (device), built on first use
+    int force_generic_fft; // tests: use the generic radix-2 kernel for every nfft
 };
 
 #define HD_CHECK_HIP(expr)                                                        \

@@ -47,6 +47,8 @@ int hipdsp_ctx_create(int device, void *stream, hipdsp_ctx **out)
     ctx->scratch = nullptr;
     ctx->scratch_bytes = 0;
     ctx->mid_event = nullptr;
+    for (int i = 0; i < 20; i++) ctx->fft_tables[i] = nullptr;
+    ctx->force_generic_fft = 0;
     *out = ctx;
     return HIPDSP_OK;
 }
@@ -55,6 +57,8 @@ int hipdsp_ctx_destroy(hipdsp_ctx *ctx)
 {
     if (!ctx) return HIPDSP_OK;
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    for (int i = 0; i < 20; i++)
+        if (ctx->fft_tables[i]) (void)hipFree(ctx->fft_tables[i]);
     delete ctx;
     return HIPDSP_OK;
 }
@@ -79,6 +83,15 @@ int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments)
     HD_REQUIRE(max_segments >= 0, "max_segments must be >= 0");
     ctx->max_segments = max_segments;
     return HIPDSP_OK;
+}
+
+int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value)
+{
+    HD_REQUIRE(ctx != nullptr && name != nullptr, "NULL argument");
+    if (strcmp(name, "max_segments") == 0) return hipdsp_ctx_set_max_segments(ctx, (int)value);
+    if (strcmp(name, "force_generic_fft") == 0) { ctx->force_generic_fft = value != 0; return HIPDSP_OK; }
+    hipdsp_set_error("unknown option '%s'", name);
+    return HIPDSP_ERR_INVALID;
 }
 
 int hipdsp_ctx_set_mid_event(hipdsp_ctx *ctx, void *event)

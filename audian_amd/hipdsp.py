@@ -33,6 +33,9 @@ class Context:
     def set_max_segments(self, n):
         check(lib.hipdsp_ctx_set_max_segments(self._h, int(n)))
 
+    def set_option(self, name, value):
+        check(lib.hipdsp_ctx_set_option(self._h, name.encode(), int(value)))
+
     def set_mid_event(self, ev):
         check(lib.hipdsp_ctx_set_mid_event(self._h, ev if ev is not None else ctypes.c_void_p(0)))
 

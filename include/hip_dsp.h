@@ -60,6 +60,9 @@ int hipdsp_ctx_synchronize(hipdsp_ctx *ctx);
 /* Tuning knob: upper bound on time segments per channel of the block-parallel
  * IIR (0 = automatic).  Results do not depend on it beyond fp64 rounding. */
 int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
+/* Named tuning/testing options: "max_segments" (as above), "force_generic_fft"
+ * (non-zero: every nfft takes the generic radix-2 spectrogram kernel). */
+int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value);
 /* Pre-size the internal scratch (envelope forward pass) so that later calls do
  * not allocate; required before stream capture into a hipGraph. */
 int hipdsp_ctx_reserve(hipdsp_ctx *ctx, size_t bytes);

@@ -149,6 +149,34 @@ def test_spectrogram_golden():
                 assert rel_err(got[j, c, :], S[:, j, c]) < TOL, (k, j, c)
 
 
+@pytest.mark.parametrize('nfft,hop', [(256, 128), (256, 37), (512, 256), (512, 128), (1024, 256),
+                                      (2048, 1024), (2048, 512), (4096, 2048), (128, 64), (8192, 4096)])
+def test_spectrogram_fast_and_generic_vs_oracle(oracle, nfft, hop):
+    """Every supported size through its own kernel and through the generic radix-2 kernel."""
+    rng = np.random.default_rng(nfft + hop)
+    rate = 96000.0
+    nframes = 70
+    T = (nframes - 1)*hop + nfft + 5
+    x = (synth(rng, T, 3, rate) + np.float32(0.1)).astype(np.float32)
+    nd = (T + hop - 1)//hop
+    want = np.zeros((nd, 3, nfft//2 + 1))
+    oracle.spectrogram_process(x.astype(np.float64), want, rate, nfft, hop)
+    got = gh.gpu_spectrogram(x, rate, nfft, hop, nd)
+    c = gh.ctx()
+    c.set_option('force_generic_fft', 1)
+    try:
+        gen = gh.gpu_spectrogram(x, rate, nfft, hop, nd)
+    finally:
+        c.set_option('force_generic_fft', 0)
+    for res in (got, gen):
+        for ch in range(3):
+            for j in range(nd):
+                if np.max(np.abs(want[j, ch])) == 0:
+                    assert np.all(res[j, ch] == 0)
+                else:
+                    assert rel_err(res[j, ch], want[j, ch]) < TOL, (nfft, hop, j, ch)
+
+
 def test_spectrogram_short_source_and_db(oracle):
     x = np.ones((100, 2), dtype=np.float32)
     got = gh.gpu_spectrogram(x, 48000.0, 256, 128, 3)
