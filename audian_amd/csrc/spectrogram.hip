@@ -153,25 +153,33 @@ __device__ __forceinline__ void stockham_stage(float2 *v, float2 *fb, const floa
 {
     constexpr int PPL = M / LPF;
     constexpr int NB = PPL / R;          // butterflies per lane
+    // all loads of the stage come before any store: the exchange is in place and one
+    // butterfly's outputs land on another butterfly's inputs
+    if (LOAD) {
+#pragma unroll
+        for (int u = 0; u < NB; u++)
+#pragma unroll
+            for (int t = 0; t < R; t++) v[u * R + t] = fb[pad16(l + LPF * u + t * (M / R))];
+    }
 #pragma unroll
     for (int u = 0; u < NB; u++) {
         const int j = l + LPF * u;
         float2 *b = v + u * R;
-        if (LOAD) {
-#pragma unroll
-            for (int t = 0; t < R; t++) b[t] = fb[pad16(j + t * (M / R))];
-        }
         if (NS > 1) {
             const int k = j % NS;
 #pragma unroll
             for (int t = 1; t < R; t++) b[t] = cmul(b[t], twm[k * t * (M / (NS * R))]);
         }
         dft<R>(b);
-        if (STORE) {
+    }
+    if (STORE) {
+#pragma unroll
+        for (int u = 0; u < NB; u++) {
+            const int j = l + LPF * u;
             const int k = j % NS;
             const int base = (j / NS) * NS * R + k;
 #pragma unroll
-            for (int t = 0; t < R; t++) fb[pad16(base + t * NS)] = b[t];
+            for (int t = 0; t < R; t++) fb[pad16(base + t * NS)] = v[u * R + t];
         }
     }
 }
