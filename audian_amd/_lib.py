@@ -55,6 +55,7 @@ _SIGNATURES = {
     'hipdsp_memcpy_h2d': ([_vp, _vp, _vp, _sz], _int),
     'hipdsp_memcpy_d2h': ([_vp, _vp, _vp, _sz], _int),
     'hipdsp_memcpy_d2d': ([_vp, _vp, _vp, _sz], _int),
+    'hipdsp_memcpy2d_d2d': ([_vp, _vp, _sz, _vp, _sz, _sz, _sz], _int),
     'hipdsp_event_create': ([_vp, _pp], _int),
     'hipdsp_event_destroy': ([_vp, _vp], _int),
     'hipdsp_event_record': ([_vp, _vp], _int),
@@ -62,7 +63,7 @@ _SIGNATURES = {
     'hipdsp_pack_f64': ([_vp, _vp, _vp, _i64, _i64, _i64], _int),
     'hipdsp_pack_f32': ([_vp, _vp, _vp, _i64, _i64, _i64], _int),
     'hipdsp_unpack_f64': ([_vp, _vp, _i64, _vp, _i64, _i64], _int),
-    'hipdsp_unpack_spectrum_f64': ([_vp, _vp, _vp, _i64, _i64, _i64], _int),
+    'hipdsp_unpack_spectrum_f64': ([_vp, _vp, _i64, _vp, _i64, _i64, _i64], _int),
     'hipdsp_sosplan_create': ([_vp, _pp], _int),
     'hipdsp_sosplan_destroy': ([_vp, _vp], _int),
     'hipdsp_sosplan_set': ([_vp, _vp, _vp, _int], _int),
@@ -71,7 +72,7 @@ _SIGNATURES = {
     'hipdsp_sosplan_info': ([_vp, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_int)], _int),
     'hipdsp_sosfilt': ([_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64], _int),
     'hipdsp_envelope': ([_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _dbl, _int], _int),
-    'hipdsp_spectrogram': ([_vp, _vp, _i64, _i64, _i64, _int, _int, _dbl, _vp, _vp, _i64], _int),
+    'hipdsp_spectrogram': ([_vp, _vp, _i64, _i64, _i64, _int, _int, _dbl, _vp, _vp, _i64, _i64], _int),
     'hipdsp_decibel': ([_vp, _vp, _vp, _i64, _dbl, _dbl], _int),
     'hipdsp_decibel_image': ([_vp, _vp, _vp, _i64, _i64, _dbl, _dbl], _int),
     'hipdsp_synth': ([_vp, _vp, _i64, _i64, _i64, _dbl, ctypes.c_uint64, _i64, _i64], _int),

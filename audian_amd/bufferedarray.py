@@ -1,0 +1,178 @@
+"""Minimal ring-buffer base class standing in for ``audioio.BufferedArray``.
+
+audioio is not part of the reference tree (``src/audian/buffereddata.py:7`` imports
+it), so this module supplies the contract the ``BufferedData`` surface relies on,
+derived from the reference's call sites:
+
+  attributes  rate, channels, frames, shape, ndim, size, offset, buffer, bufferframes,
+              backframes, follow, ampl_min, ampl_max, unit, buffer_changed, verbose
+  methods     __len__ (frames), __getitem__ (moves the buffer on demand,
+              data.py:112), update_time(t0, t1) (data.py:227), update_buffer,
+              move_buffer(offset, nframes) (buffereddata.py:87: keeps the overlapping
+              part, calls load_buffer for what is missing, sets buffer_changed),
+              allocate_buffer() (buffereddata.py:114), reload_buffer() (:115),
+              load_buffer(offset, nframes, view) -- the subclass hook.
+
+It is written from that contract, not from audioio's source.
+"""
+
+import numpy as np
+
+
+class BufferedArray(object):
+
+    def __init__(self, verbose=0):
+        self.rate = 0.0
+        self.channels = 0
+        self.frames = 0
+        self.shape = (0, 0)
+        self.ndim = 2
+        self.size = 0
+        self.offset = 0
+        self.bufferframes = 0
+        self.backframes = 0
+        self.follow = 0
+        self.ampl_min = -1.0
+        self.ampl_max = 1.0
+        self.unit = ''
+        self.verbose = verbose
+        self.buffer_changed = np.zeros(0, dtype=bool)
+        self.buffer = np.zeros((0, 0))
+
+    def __len__(self):
+        return self.frames
+
+    # -- subclass hook ---------------------------------------------------------
+    def load_buffer(self, offset, nframes, buffer):
+        raise NotImplementedError
+
+    # -- buffer management -----------------------------------------------------
+    def _blank(self, nframes):
+        return np.zeros((int(nframes),) + tuple(self.shape[1:]))
+
+    def allocate_buffer(self, nframes=None, force=False):
+        """Size ``buffer`` to ``bufferframes`` frames (clipped to the data)."""
+        if nframes is None:
+            nframes = self.bufferframes
+        if self.offset + nframes > self.frames:
+            nframes = max(0, self.frames - self.offset)
+        if force or nframes != len(self.buffer) or \
+           tuple(self.buffer.shape[1:]) != tuple(self.shape[1:]):
+            self.buffer = self._blank(nframes)
+
+    def reload_buffer(self):
+        """Recompute the whole current buffer in place."""
+        if len(self.buffer) > 0:
+            self.load_buffer(self.offset, len(self.buffer), self.buffer)
+            self.buffer_changed[:] = True
+
+    def move_buffer(self, offset, nframes):
+        """Make the buffer cover frames [offset, offset + nframes): the part that
+        overlaps the current buffer is kept, the rest comes from ``load_buffer``."""
+        offset = int(max(0, offset))
+        nframes = int(max(0, min(nframes, self.frames - offset)))
+        old, old_off = self.buffer, self.offset
+        if offset == old_off and nframes == len(old):
+            return
+        new = self._blank(nframes)
+        keep0 = max(offset, old_off)
+        keep1 = min(offset + nframes, old_off + len(old))
+        if tuple(old.shape[1:]) != tuple(new.shape[1:]):
+            keep0 = keep1 = 0
+        todo = []
+        if keep1 > keep0:
+            new[keep0 - offset:keep1 - offset] = old[keep0 - old_off:keep1 - old_off]
+            if keep0 > offset:
+                todo.append((offset, keep0 - offset))
+            if keep1 < offset + nframes:
+                todo.append((keep1, offset + nframes - keep1))
+        elif nframes > 0:
+            todo.append((offset, nframes))
+        self._adopt_buffer(new, offset, old_off, len(old), keep0, keep1)
+        for r_offset, r_nframes in todo:
+            self.load_buffer(r_offset, r_nframes,
+                             self.buffer[r_offset - offset:r_offset - offset + r_nframes])
+        self.buffer_changed[:] = True
+
+    def _adopt_buffer(self, new, offset, old_offset, old_nframes, keep0, keep1):
+        """Install the recycled buffer (hook for subclasses that mirror it elsewhere)."""
+        self.buffer = new
+        self.offset = offset
+
+    def _buffer_position(self, start, stop):
+        """Where to put the buffer so that frames [start, stop) are inside it."""
+        nframes = max(self.bufferframes, stop - start)
+        offset = start - self.backframes
+        if offset + nframes > self.frames:
+            offset = self.frames - nframes
+        if offset < 0:
+            offset = 0
+        if offset + nframes > self.frames:
+            nframes = self.frames - offset
+        return offset, nframes
+
+    def update_buffer(self, start, stop):
+        start = int(max(0, start))
+        stop = int(min(self.frames, stop))
+        if stop <= start:
+            return
+        if start < self.offset or stop > self.offset + len(self.buffer):
+            offset, nframes = self._buffer_position(start, stop)
+            self.move_buffer(offset, nframes)
+
+    def update_time(self, start, stop):
+        self.update_buffer(int(start*self.rate), int(stop*self.rate) + 1)
+
+    def __getitem__(self, key):
+        if not isinstance(key, tuple):
+            key = (key,)
+        first, rest = key[0], key[1:]
+        if isinstance(first, slice):
+            start, stop, step = first.indices(self.frames)
+            if step < 1:
+                raise IndexError('negative steps are not supported')
+            if stop <= start:
+                return self.buffer[(slice(0, 0),) + rest]
+            self.update_buffer(start, stop)
+            return self.buffer[(slice(start - self.offset, stop - self.offset, step),) + rest]
+        index = int(first)
+        if index < 0:
+            index += self.frames
+        if index < 0 or index >= self.frames:
+            raise IndexError('frame index out of range')
+        self.update_buffer(index, index + 1)
+        return self.buffer[(index - self.offset,) + rest]
+
+
+class ArrayLoader(BufferedArray):
+    """An in-memory (frames, channels) recording behind the BufferedArray interface:
+    stands in for ``thunderlab.dataloader.DataLoader`` (``src/audian/data.py:172``)
+    with its ``buffer_time`` / ``back_time`` arguments."""
+
+    def __init__(self, data, rate, buffer_time=60.0, back_time=20.0, unit='a.u.',
+                 ampl_max=1.0, verbose=0):
+        super().__init__(verbose)
+        data = np.asarray(data)
+        if data.ndim == 1:
+            data = data[:, None]
+        self.data = data
+        self.rate = float(rate)
+        self.frames, self.channels = data.shape
+        self.shape = (self.frames, self.channels)
+        self.ndim = 2
+        self.size = self.frames*self.channels
+        self.unit = unit
+        self.ampl_min = -ampl_max
+        self.ampl_max = ampl_max
+        self.bufferframes = min(self.frames, int(buffer_time*self.rate))
+        self.backframes = int(back_time*self.rate)
+        self.buffer_changed = np.zeros(self.channels, dtype=bool)
+        self.buffer = np.zeros((0, self.channels))
+        self.name = 'data'
+        self.dests = []
+        self.need_update = False
+        self.plot_items = [None]*self.channels
+        self.move_buffer(0, self.bufferframes)
+
+    def load_buffer(self, offset, nframes, buffer):
+        buffer[:, :] = self.data[offset:offset + nframes, :]

@@ -1,0 +1,365 @@
+"""Base class for computed traces: the ``BufferedData`` plugin surface of audian
+(``src/audian/buffereddata.py:10-153`` in /root/reference), re-stated on top of a
+device-resident mirror.
+
+What the PyQt browser sees is unchanged: ``open(source, step, more_shape)``,
+``process(source, dest, nbefore)`` (the subclass hook), ``load_buffer``,
+``align_buffer``, ``recompute``, ``recompute_all``, ``set_need_update``,
+``expand_times``, ``update_step`` and the attributes ``rate, channels, frames, shape,
+offset, buffer, buffer_changed, ampl_min, ampl_max, unit, source, dests, need_update,
+plot_items``.  The bookkeeping follows the reference line by line in meaning --
+including its seconds-divided-by-rate quirk in ``load_buffer``
+(buffereddata.py:96,99), because that defines which samples reach the kernels.
+
+What is new: every trace keeps its current buffer in HBM as planar float32
+(channels, frames[, F]).  ``process()`` implementations write there and only mark the
+host copy stale; reading ``trace.buffer`` (or ``trace[i0:i1, ch]``) copies back what
+is stale, lazily.  A derived trace whose source is another ``BufferedData`` reads the
+source's device mirror, so filter -> spectrogram -> envelope never leaves HBM
+(SURVEY 7-4).
+"""
+
+import os
+from math import floor, ceil
+
+import numpy as np
+
+from .bufferedarray import BufferedArray
+
+_TRACE = bool(os.environ.get('AUDIAN_AMD_TRACE'))
+
+
+class _Call(object):
+    """Where the slab handed to process() sits: set by load_buffer for one call."""
+
+    def __init__(self, soffset, snframes, doffset, dnframes):
+        self.soffset, self.snframes = soffset, snframes
+        self.doffset, self.dnframes = doffset, dnframes
+
+
+def _merge(ranges):
+    out = []
+    for a, b in sorted(r for r in ranges if r[1] > r[0]):
+        if out and a <= out[-1][1]:
+            out[-1][1] = max(out[-1][1], b)
+        else:
+            out.append([a, b])
+    return out
+
+
+def _covers(ranges, a, b):
+    return any(r[0] <= a and b <= r[1] for r in ranges) or b <= a
+
+
+def _subtract(ranges, a, b):
+    out = []
+    for r0, r1 in ranges:
+        if r1 <= a or r0 >= b:
+            out.append([r0, r1])
+        else:
+            if r0 < a:
+                out.append([r0, a])
+            if r1 > b:
+                out.append([b, r1])
+    return out
+
+
+class BufferedData(BufferedArray):
+
+    _hostbuf = None
+    _dev = None
+    _dev_valid = ()
+    _stale = ()
+    _pending = None
+    _ctx = None
+
+    def __init__(self, name, source_name, tbefore=0, tafter=0,
+                 panel='none', panel_type='trace',
+                 color='#00ee00', lw_thin=1.1, lw_thick=2):
+        super().__init__(verbose=0)
+        self.name = name
+        self.source_name = source_name
+        # like the reference: own times start at 0 and only grow via expand_times()
+        self.tbefore = 0
+        self.tafter = 0
+        self.panel = panel
+        self.panel_type = panel_type
+        self.plot_items = []
+        self.color = color
+        self.lw_thin = lw_thin
+        self.lw_thick = lw_thick
+        self.source = None
+        self.source_tbefore = tbefore
+        self.source_tafter = tafter
+        self.dests = []
+        self.need_update = False
+
+    # ---- host buffer with lazy read-back ---------------------------------------
+    @property
+    def buffer(self):
+        if self._stale:
+            self._flush()
+        return self._hostbuf
+
+    @buffer.setter
+    def buffer(self, value):
+        # a new host buffer invalidates the mirror (allocate_buffer, open)
+        self._hostbuf = value
+        self._stale = []
+        self._dev = None
+        self._dev_valid = []
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            from . import hipdsp
+            self._ctx = hipdsp.default_context()
+        return self._ctx
+
+    def _inner(self):
+        """Elements per frame and channel (1 for traces, F for spectrograms)."""
+        n = 1
+        for s in self.shape[2:]:
+            n *= int(s)
+        return n
+
+    def _mirror(self):
+        """The device mirror of the current host buffer, allocated on demand."""
+        from . import hipdsp
+        if self._dev is None:
+            n = max(1, len(self._hostbuf)*self._inner())
+            self._dev = hipdsp.DeviceArray(self.ctx, (max(1, self.channels), n), np.float32)
+            self._dev_valid = []
+        return self._dev
+
+    def _flush(self):
+        """Copy the stale frame ranges from the mirror into the host buffer."""
+        from . import hipdsp
+        stale, self._stale = self._stale, []
+        inner = self._inner()
+        pitch = len(self._hostbuf)*inner
+        for a, b in stale:
+            n = b - a
+            tmp = hipdsp.DeviceArray(self.ctx, (n, self.channels, inner) if inner > 1
+                                     else (n, self.channels), np.float64)
+            src = self._dev.view(a*inner, (1,))
+            if inner > 1:
+                hipdsp.unpack_spectrum(self.ctx, src, tmp, n, self.channels, inner, src_pitch=pitch)
+                self._hostbuf[a:b] = tmp.to_host().reshape((n, self.channels) + tuple(self.shape[2:]))
+            else:
+                hipdsp.unpack(self.ctx, src, pitch, tmp, n, self.channels)
+                self._hostbuf[a:b] = tmp.to_host()
+            tmp.free()
+
+    def _adopt_buffer(self, new, offset, old_offset, old_nframes, keep0, keep1):
+        """move_buffer recycled the host buffer: recycle the mirror the same way."""
+        from . import hipdsp
+        old_dev, old_valid = self._dev, list(self._dev_valid)
+        self.buffer = new            # setter drops mirror and stale marks (host is current)
+        self.offset = offset
+        if old_dev is not None and keep1 > keep0 and \
+           _covers(old_valid, keep0 - old_offset, keep1 - old_offset) and len(new) > 0:
+            inner = self._inner()
+            dev = self._mirror()
+            hipdsp.memcpy2d(self.ctx, dev.view((keep0 - offset)*inner, (1,)), 4*len(new)*inner,
+                            old_dev.view((keep0 - old_offset)*inner, (1,)), 4*old_nframes*inner,
+                            4*(keep1 - keep0)*inner, self.channels)
+            self._dev_valid = [[keep0 - offset, keep1 - offset]]
+            self.ctx.synchronize()   # old mirror may be freed now
+        if old_dev is not None:
+            old_dev.free()
+
+    # ---- helpers for process() implementations -----------------------------------
+    def _take_call(self, source, dest):
+        call, self._pending = self._pending, None
+        if call is not None and (call.snframes != len(source) or call.dnframes != len(dest)):
+            call = None
+        return call
+
+    def _device_source(self, source, call):
+        """(device pointer holder, pitch in elements) of the source slab, planar float32.
+        Uses the source trace's mirror when it is valid there, else uploads `source`."""
+        from . import hipdsp
+        src = self.source
+        if call is not None and isinstance(src, BufferedData) and src._dev is not None and \
+           _covers(src._dev_valid, call.soffset, call.soffset + call.snframes):
+            inner = src._inner()
+            return src._dev.view(call.soffset*inner, (1,)), len(src._hostbuf)*inner, None
+        if call is not None and isinstance(src, BufferedData) and src._stale:
+            source = src.buffer[call.soffset:call.soffset + call.snframes]     # flushes
+        n = len(source)
+        dtype = np.float32 if source.dtype == np.float32 else np.float64
+        host = np.ascontiguousarray(source.reshape(n, -1), dtype=dtype)
+        up = hipdsp.DeviceArray.from_host(self.ctx, host)
+        planar = hipdsp.DeviceArray(self.ctx, (max(1, host.shape[1]), max(1, n)), np.float32)
+        if n > 0:
+            hipdsp.pack(self.ctx, up, planar, n, n, host.shape[1], src_dtype=dtype)
+        return planar, max(1, n), up
+
+    def _device_dest(self, dest, call):
+        """(device pointer holder, pitch in elements, is_mirror) for the output slab."""
+        from . import hipdsp
+        inner = self._inner()
+        if call is not None:
+            dev = self._mirror()
+            return dev.view(call.doffset*inner, (1,)), len(self._hostbuf)*inner, True
+        n = max(1, len(dest))
+        return hipdsp.DeviceArray(self.ctx, (max(1, self.channels), n*inner), np.float32), n*inner, False
+
+    def _finish_dest(self, dest, ddst, pitch, is_mirror, call):
+        """Mark the mirror range written (host stale), or copy a temporary result to dest."""
+        from . import hipdsp
+        if is_mirror:
+            a, b = call.doffset, call.doffset + call.dnframes
+            self._dev_valid = _merge(list(self._dev_valid) + [[a, b]])
+            self._stale = _merge(list(self._stale) + [[a, b]])
+            return
+        n, inner = len(dest), self._inner()
+        if n == 0:
+            return
+        if inner > 1:
+            tmp = hipdsp.DeviceArray(self.ctx, (n, self.channels, inner), np.float64)
+            hipdsp.unpack_spectrum(self.ctx, ddst, tmp, n, self.channels, inner, src_pitch=pitch)
+        else:
+            tmp = hipdsp.DeviceArray(self.ctx, (n, self.channels), np.float64)
+            hipdsp.unpack(self.ctx, ddst, pitch, tmp, n, self.channels)
+        dest[...] = tmp.to_host().reshape(dest.shape)
+
+    # ---- the reference's surface ----------------------------------------------------
+    def expand_times(self, tbefore, tafter):
+        self.tbefore += tbefore
+        self.tafter += tafter
+        return self.source_tbefore + tbefore, self.source_tafter + tafter
+
+    def update_step(self, step=1, more_shape=None):
+        tbuffer = self.bufferframes/self.rate
+        if step < 1:
+            step = 1
+        self.rate = self.source.rate/step
+        self.frames = (self.source.frames + step - 1)//step
+        if more_shape is None:
+            self.shape = (self.frames, self.channels)
+        else:
+            self.shape = (self.frames, self.channels) + more_shape
+        self.ndim = len(self.shape)
+        self.size = self.frames*self.channels
+        if self.source.bufferframes == self.source.frames:
+            self.bufferframes = self.frames
+        else:
+            self.bufferframes = int(tbuffer*self.rate)
+        self.offset = (self.source.offset + step - 1)//step
+        self.follow = 0
+
+    def open(self, source, step=1, more_shape=None):
+        self.source = source
+        self.source.dests.append(self)
+        self.ampl_min = source.ampl_min
+        self.ampl_max = source.ampl_max
+        self.unit = source.unit
+        self.bufferframes = 0
+        self.backframes = 0
+        self.channels = self.source.channels
+        self.rate = self.source.rate
+        self.buffer_changed = np.zeros(self.channels, dtype=bool)
+        self.buffer = np.zeros((0, self.channels))
+        self.plot_items = [None]*self.channels
+        self.update_step(step, more_shape)
+
+    def _source_len(self):
+        src = self.source
+        return len(src._hostbuf) if isinstance(src, BufferedData) else len(src.buffer)
+
+    def align_buffer(self):
+        soffset = self.source.offset
+        snframes = self._source_len()
+        if soffset > 0:
+            n = floor(self.source_tbefore*self.source.rate)
+            soffset += n
+            snframes -= n
+        if self.source.offset + self._source_len() < self.source.frames:
+            n = floor(self.source_tafter*self.source.rate)
+            snframes -= n
+        offset = ceil(soffset*self.rate/self.source.rate)
+        nframes = floor((soffset + snframes)*self.rate/self.source.rate) - offset
+        self.move_buffer(offset, nframes)
+        self.bufferframes = len(self._hostbuf)
+
+    def load_buffer(self, offset, nframes, buffer):
+        if _TRACE:
+            print(f'load {self.name} {offset/self.rate:.3f} - {(offset + nframes)/self.rate:.3f}')
+        # transform to rate of source buffer:
+        soffset = floor(offset*self.source.rate/self.rate)
+        snframes = ceil((offset + nframes)*self.source.rate/self.rate) - soffset
+        # the reference divides seconds by the rate here (buffereddata.py:96,99), so
+        # nbefore is 0 and nafter is 1 for any realistic rate; kept for parity.
+        nbefore = floor(self.source_tbefore/self.source.rate)
+        soffset -= nbefore
+        snframes += nbefore
+        nafter = ceil(self.source_tafter/self.source.rate)
+        snframes += nafter
+        soffset -= self.source.offset
+        if soffset < 0:
+            nbefore += soffset
+            snframes += soffset
+            soffset = 0
+        slen = self._source_len()
+        if soffset + snframes > slen:
+            snframes = slen - soffset
+        src = self.source
+        sbuf = src._hostbuf if isinstance(src, BufferedData) else src.buffer
+        source = sbuf[soffset:soffset + snframes]
+        self._pending = _Call(soffset, len(source), offset - self.offset, len(buffer))
+        try:
+            self.process(source, buffer, nbefore)
+        finally:
+            self._pending = None
+
+    def process(self, source, dest, nbefore):
+        raise NotImplementedError
+
+    def reload_buffer(self):
+        # everything is recomputed: nothing stale needs to be read back first
+        if len(self._hostbuf) > 0:
+            self._stale = []
+            self._dev_valid = []
+            self.load_buffer(self.offset, len(self._hostbuf), self._hostbuf)
+            self.buffer_changed[:] = True
+
+    def recompute(self):
+        if self._source_len() > 0:
+            self.allocate_buffer()
+        self.reload_buffer()
+
+    def is_visible(self):
+        for pi in self.plot_items:
+            if pi is not None and pi.isVisible():
+                return True
+        return False
+
+    def set_visible(self, show):
+        for pi in self.plot_items:
+            if pi is not None:
+                pi.setVisible(show)
+
+    def set_need_update(self):
+        self.need_update = False
+        for pi in self.plot_items:
+            if pi is not None and pi.isVisible():
+                self.need_update = True
+                break
+        for d in self.dests:
+            d.set_need_update()
+        # end of dependency chain:
+        if len(self.dests) == 0:
+            # go to sources and propagate needed update:
+            trace = self
+            while hasattr(trace, 'source'):
+                s = trace.source
+                s.need_update = trace.need_update or s.need_update
+                trace = s
+
+    def recompute_all(self):
+        if self.need_update:
+            self.recompute()
+            for d in self.dests:
+                d.recompute_all()

@@ -1,0 +1,80 @@
+"""Compute envelope on the fly: ``BufferedEnvelope`` of audian
+(``src/audian/bufferedenvelope.py`` in /root/reference).  The
+``sosfiltfilt(sos, (pi/2)*|x|, axis=0)`` call becomes one fused device call
+(``hipdsp_envelope``: rectify + odd padding + zi-scaled forward and backward biquad
+passes + clamp)."""
+
+import numpy as np
+
+from .buffereddata import BufferedData
+from .design import butter_sos
+
+
+class BufferedEnvelope(BufferedData):
+
+    def __init__(self, name='envelope', source='filtered',
+                 panel='trace', color='#ff8800',
+                 lw_thin=2.5, lw_thick=4, envelope_cutoff=500,
+                 filter_order=2, highpass_cutoff=0):
+        super().__init__(name, source, tbefore=1, panel=panel,
+                         panel_type='trace', color=color,
+                         lw_thin=lw_thin, lw_thick=lw_thick)
+        self.envelope_cutoff = envelope_cutoff
+        self.highpass_cutoff = highpass_cutoff
+        self.filter_order = filter_order
+        self.sos = None
+        self._plan = None
+
+    def open(self, source):
+        super().open(source)
+        self.sos = None
+        self.update()
+
+    def process(self, source, dest, nbefore):
+        """dest = sosfiltfilt(sos, (pi/2)|source|, axis=0)[nbefore:], negatives clamped to
+        0 unless a high-pass is set; zeros when the design failed
+        (bufferedenvelope.py:34-41).  Raises ValueError like scipy when the slab is not
+        longer than the pad length."""
+        from . import hipdsp
+        if self.sos is not None and len(dest) != len(source) - nbefore:
+            raise ValueError(f'could not broadcast input array from shape '
+                             f'({len(source) - nbefore},) into shape ({len(dest)},)')
+        call = self._take_call(source, dest)
+        if len(dest) == 0:
+            return
+        ddst, dpitch, is_mirror = self._device_dest(dest, call)
+        keep = None
+        if self.sos is None:
+            hipdsp.envelope(self.ctx, None, None, 0, ddst, dpitch, self.channels,
+                            len(dest), 0)
+        else:
+            dsrc, spitch, keep = self._device_source(source, call)
+            hipdsp.envelope(self.ctx, self._plan, dsrc, spitch, ddst, dpitch, self.channels,
+                            len(source), nbefore, rectify=True, gain=np.pi/2,
+                            clamp=self.highpass_cutoff == 0)
+        self._finish_dest(dest, ddst, dpitch, is_mirror, call)
+        if keep is not None or not is_mirror:
+            self.ctx.synchronize()
+
+    def update(self):
+        from . import hipdsp, _lib
+        try:
+            if self.highpass_cutoff > 0:
+                self.sos = butter_sos(self.filter_order,
+                                      (self.highpass_cutoff, self.envelope_cutoff),
+                                      'bandpass', self.rate)
+            else:
+                self.sos = butter_sos(self.filter_order, self.envelope_cutoff,
+                                      'lowpass', self.rate)
+        except ValueError:
+            self.sos = None
+        if self.sos is not None:
+            if len(self.sos) > _lib.MAX_SECTIONS:
+                raise NotImplementedError(
+                    f'envelope filters with more than {_lib.MAX_SECTIONS} second-order sections '
+                    '(the zi-scaled forward-backward pass is not split over plans)')
+            if self._plan is None:
+                self._plan = hipdsp.SosPlan(self.ctx, self.sos)
+            else:
+                self._plan.set(self.sos)
+        self.recompute_all()

@@ -1,0 +1,148 @@
+"""Spectrogram of source data on the fly: ``BufferedSpectrogram`` of audian
+(``src/audian/bufferedspectrogram.py`` in /root/reference).  thunderlab's
+``spectrogram`` / ``decibel`` (scipy.signal.spectrogram with a Hann window, constant
+detrend, density scaling) become ``hipdsp_spectrogram`` / ``hipdsp_decibel_image``."""
+
+import numpy as np
+
+from .buffereddata import BufferedData
+
+
+def decibel(power, ref_power=1.0, min_power=1e-20):
+    """thunderlab.powerspectrum.decibel for host arrays and scalars (used by the
+    once-per-trace colour-range estimate and by cursors; the image path is on the
+    device): 10*log10(power/ref_power), -inf at or below min_power."""
+    p = np.asarray(power, dtype=np.float64)
+    out = np.full(p.shape, -np.inf)
+    m = p > min_power
+    out[m] = 10.0*np.log10(p[m]/ref_power)
+    return out if out.ndim else float(out)
+
+
+class BufferedSpectrogram(BufferedData):
+
+    def __init__(self, name='spectrogram', source='filtered',
+                 panel='spectrogram', nfft=256,
+                 overlap_frac=0.5):
+        super().__init__(name, source, tafter=10, panel=panel,
+                         panel_type='spectrogram')
+        self.nfft = nfft
+        self.hop = 0
+        self.overlap_frac = overlap_frac
+        self.set_hop()
+        self.frequencies = np.zeros(0)
+        self.fresolution = 1
+        self.tresolution = 1
+        self.spec_rect = []
+        self.use_spec = True
+        self.init = True
+
+    def open(self, source):
+        self.hop = int(self.nfft*(1 - self.overlap_frac))
+        self.fresolution = source.rate/self.nfft
+        self.frequencies = np.arange(0, source.rate/2 + self.fresolution/2,
+                                     self.fresolution)
+        self.tresolution = self.hop/source.rate
+        self.spec_rect = []
+        self.use_spec = True
+        super().open(source, self.hop, more_shape=(self.nfft//2 + 1,))
+        self.unit = f'{self.unit}^2/Hz'
+        self.ampl_min = 0
+        self.ampl_max = self.source.rate/2
+
+    def process(self, source, dest, nbefore):
+        """dest[k, c, :] = one-sided PSD of source[k*hop : k*hop + nfft, c]; frames that do
+        not fit into the source are zero (bufferedspectrogram.py:45-66)."""
+        from . import hipdsp
+        call = self._take_call(source, dest)
+        nd = len(dest)
+        F = self.nfft//2 + 1
+        if nd > 0:
+            dsrc, spitch, keep = self._device_source(source, call)
+            ddst, dpitch, is_mirror = self._device_dest(dest, call)
+            hipdsp.spectrogram(self.ctx, dsrc, spitch, self.channels, len(source), self.nfft,
+                               self.hop, self.source.rate, ddst, nd, out_pitch=dpitch)
+            self._finish_dest(dest, ddst, dpitch, is_mirror, call)
+            if keep is not None or not is_mirror:
+                self.ctx.synchronize()
+            nsource = min((nd - 1)*self.hop + self.nfft, len(source))
+            if nsource >= self.nfft:
+                self.frequencies = np.arange(F)*self.source.rate/self.nfft
+        # extent of the full buffer:
+        self.spec_rect = [self.offset/self.rate, 0,
+                          len(self._hostbuf)/self.rate,
+                          self.source.rate/2 + self.fresolution]
+
+    def set_hop(self):
+        hop = int(np.round((1 - self.overlap_frac)*self.nfft))
+        if hop < 1:
+            hop = 1
+        if hop > self.nfft:
+            hop = self.nfft
+        if self.hop != hop:
+            self.hop = hop
+            self.overlap_frac = 1 - self.hop/self.nfft
+            return True
+        else:
+            return False
+
+    def update(self, nfft=None, overlap_frac=None):
+        spec_update = False
+        if nfft is not None:
+            if nfft < 8:
+                nfft = 8
+            max_nfft = min(len(self.source)//2, 2**30)
+            if nfft > max_nfft:
+                nfft = max_nfft
+            if self.nfft != nfft:
+                self.nfft = nfft
+                spec_update = True
+        if overlap_frac is not None:
+            if overlap_frac < 0.0:
+                overlap_frac = 0.0
+            elif overlap_frac > 0.99999:
+                overlap_frac = 0.99999
+            self.overlap_frac = overlap_frac
+        if self.set_hop():
+            spec_update = True
+        if spec_update:
+            self.tresolution = self.hop/self.source.rate
+            self.fresolution = self.source.rate/self.nfft
+            self.update_step(self.hop, more_shape=(self.nfft//2 + 1,))
+            self.recompute_all()
+
+    def decibel_image(self, channel, ref_power=1.0, min_power=1e-20):
+        """decibel(buffer[:, channel, :].T) as SpecItem.update_plot needs it
+        (src/audian/specitem.py:36), computed on the device from the mirror when it is
+        valid; returns a (F, frames) float32 host array."""
+        from . import hipdsp
+        from .buffereddata import _covers
+        n = len(self._hostbuf)
+        F = self.nfft//2 + 1
+        if n == 0:
+            return np.zeros((F, 0), dtype=np.float32)
+        if self._dev is not None and _covers(self._dev_valid, 0, n):
+            img = hipdsp.DeviceArray(self.ctx, (F, n), np.float32)
+            hipdsp.decibel_image(self.ctx, self._dev.view(channel*n*F, (1,)), img, n, F,
+                                 ref_power, min_power)
+            return img.to_host()
+        return decibel(self.buffer[:, channel, :].T, ref_power, min_power).astype(np.float32)
+
+    def estimate_noiselevels(self, channel):
+        if not self.init or len(self._hostbuf) == 0 or len(self._hostbuf.shape) < 3:
+            return None, None
+        nf = self._hostbuf.shape[2]//16
+        if nf < 1:
+            nf = 1
+        with np.errstate(all='ignore'):
+            zmin = np.percentile(decibel(self.buffer[:, channel, -nf:]), 95)
+        zmax = np.max(decibel(self.buffer[:, channel, :]))
+        if not np.isfinite(zmin) or not np.isfinite(zmax):
+            return None, None
+        self.init = False
+        zmax = zmin + 0.95*(zmax - zmin)
+        if zmax - zmin < 20:
+            zmax = zmin + 20
+        if zmax - zmin > 80:
+            zmin = zmax - 80
+        return zmin, zmax

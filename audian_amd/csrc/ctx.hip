@@ -164,6 +164,18 @@ int hipdsp_memcpy_d2d(hipdsp_ctx *ctx, void *dst, const void *src, size_t bytes)
     return HIPDSP_OK;
 }
 
+int hipdsp_memcpy2d_d2d(hipdsp_ctx *ctx, void *dst, size_t dst_pitch, const void *src, size_t src_pitch,
+                        size_t width, size_t height)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (width == 0 || height == 0) return HIPDSP_OK;
+    HD_REQUIRE(dst != nullptr && src != nullptr, "NULL data pointer");
+    HD_REQUIRE(dst_pitch >= width && src_pitch >= width, "pitch smaller than width");
+    HD_CHECK_HIP(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width, height, hipMemcpyDeviceToDevice,
+                                  ctx->stream));
+    return HIPDSP_OK;
+}
+
 int hipdsp_event_create(hipdsp_ctx *ctx, void **event)
 {
     HD_REQUIRE(ctx != nullptr && event != nullptr, "NULL argument");

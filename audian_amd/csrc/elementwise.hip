@@ -84,11 +84,12 @@ __global__ __launch_bounds__(256) void unpack_kernel(const float *__restrict__ s
 }
 
 // (C, T', F) float32 -> (T', C, F) float64; one block per (frame, channel) row
-__global__ void unpack_spectrum_kernel(const float *__restrict__ src, double *__restrict__ dst,
-                                       long long frames, long long channels, long long F)
+__global__ void unpack_spectrum_kernel(const float *__restrict__ src, long long src_pitch,
+                                       double *__restrict__ dst, long long frames, long long channels,
+                                       long long F)
 {
     const long long t = blockIdx.x, c = blockIdx.y;
-    const float *s = src + (c * frames + t) * F;
+    const float *s = src + c * src_pitch + t * F;
     double *d = dst + (t * channels + c) * F;
     for (long long f = threadIdx.x; f < F; f += blockDim.x) d[f] = (double)s[f];
 }
@@ -205,17 +206,20 @@ int hipdsp_unpack_f64(hipdsp_ctx *ctx, const float *src, int64_t src_pitch, doub
     return hd_launch_status("unpack_kernel");
 }
 
-int hipdsp_unpack_spectrum_f64(hipdsp_ctx *ctx, const float *src, double *dst_tcf, int64_t frames,
-                               int64_t channels, int64_t nfreq)
+int hipdsp_unpack_spectrum_f64(hipdsp_ctx *ctx, const float *src, int64_t src_pitch, double *dst_tcf,
+                               int64_t frames, int64_t channels, int64_t nfreq)
 {
     HD_REQUIRE(ctx != nullptr, "ctx is NULL");
     HD_REQUIRE(frames >= 0 && channels >= 0 && nfreq >= 0, "negative size");
     if (frames == 0 || channels == 0 || nfreq == 0) return HIPDSP_OK;
     HD_REQUIRE(src != nullptr && dst_tcf != nullptr, "NULL data pointer");
     HD_REQUIRE(channels <= 65535 && frames <= 0x7fffffffLL, "size out of range");
+    if (src_pitch == 0) src_pitch = frames * nfreq;
+    HD_REQUIRE(src_pitch >= frames * nfreq, "src_pitch smaller than one channel");
     HD_CHECK_HIP(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(unpack_spectrum_kernel, dim3((unsigned)frames, (unsigned)channels), dim3(256), 0,
-                       ctx->stream, src, dst_tcf, (long long)frames, (long long)channels, (long long)nfreq);
+                       ctx->stream, src, (long long)src_pitch, dst_tcf, (long long)frames,
+                       (long long)channels, (long long)nfreq);
     return hd_launch_status("unpack_spectrum_kernel");
 }
 

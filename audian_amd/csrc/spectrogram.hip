@@ -18,8 +18,9 @@ __device__ __forceinline__ float to_db(float p)
 // ---- generic path: any power-of-two nfft in [8, 8192] ---------------------------
 // One 256-thread workgroup per (frame, channel); radix-2 Stockham autosort in LDS.
 __global__ __launch_bounds__(256) void spec_generic_kernel(
-    const float *__restrict__ x, long long x_pitch, long long n_valid, long long frames_out, int nfft,
-    int hop, float scale, float *__restrict__ out, float *__restrict__ db_out)
+    const float *__restrict__ x, long long x_pitch, long long n_valid, long long frames_out,
+    long long out_pitch, int nfft, int hop, float scale, float *__restrict__ out,
+    float *__restrict__ db_out)
 {
     extern __shared__ float2 fftbuf[];        // 2 * nfft
     __shared__ float red[4];
@@ -27,7 +28,7 @@ __global__ __launch_bounds__(256) void spec_generic_kernel(
     const long long frame = blockIdx.x;
     const long long ch = blockIdx.y;
     const int F = nfft / 2 + 1;
-    const long long obase = (ch * frames_out + frame) * (long long)F;
+    const long long obase = ch * out_pitch + frame * (long long)F;
     if (frame >= n_valid) {                   // zero tail (bufferedspectrogram.py:59)
         for (int f = tid; f < F; f += 256) {
             out[obase + f] = 0.f;
@@ -186,9 +187,9 @@ __device__ __forceinline__ void stockham_stage(float2 *v, float2 *fb, const floa
 
 template <int NFFT, int LPF, int R1, int R2, int R3>
 __global__ __launch_bounds__(256) void spec_fast_kernel(
-    const float *__restrict__ x, long long x_pitch, long long n_valid, long long frames_out, int hop,
-    float scale, const float *__restrict__ tables, float *__restrict__ out, float *__restrict__ db_out,
-    int frames_per_wave)
+    const float *__restrict__ x, long long x_pitch, long long n_valid, long long frames_out,
+    long long out_pitch, int hop, float scale, const float *__restrict__ tables, float *__restrict__ out,
+    float *__restrict__ db_out, int frames_per_wave)
 {
     constexpr int M = NFFT / 2;
     constexpr int PPL = M / LPF;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void spec_fast_kernel(
     for (int it = 0; it < frames_per_wave; it++) {
         const long long frame = first + (long long)it * G + g;
         if (frame >= frames_out) continue;               // uniform per lane group
-        const long long obase = (ch * frames_out + frame) * (long long)F;
+        const long long obase = ch * out_pitch + frame * (long long)F;
         if (frame >= n_valid) {                          // zero tail
             for (int f = l; f < F; f += LPF) {
                 out[obase + f] = 0.f;
@@ -292,15 +293,16 @@ __global__ __launch_bounds__(256) void spec_fast_kernel(
 
 template <int NFFT, int LPF, int R1, int R2, int R3>
 int launch_fast(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long channels, long long n_valid,
-                long long frames_out, int hop, float scale, const float *tables, float *out, float *db_out)
+                long long frames_out, long long out_pitch, int hop, float scale, const float *tables,
+                float *out, float *db_out)
 {
     constexpr int G = 64 / LPF;
     const int fpw = 16;                                  // frames per wave (x G side by side)
     long long per_block = 4LL * fpw * G;
     long long bx = (frames_out + per_block - 1) / per_block;
     hipLaunchKernelGGL((spec_fast_kernel<NFFT, LPF, R1, R2, R3>), dim3((unsigned)bx, (unsigned)channels),
-                       dim3(256), 0, ctx->stream, x, x_pitch, n_valid, frames_out, hop, scale, tables, out,
-                       db_out, fpw);
+                       dim3(256), 0, ctx->stream, x, x_pitch, n_valid, frames_out, out_pitch, hop, scale,
+                       tables, out, db_out, fpw);
     return hd_launch_status("spec_fast_kernel");
 }
 
@@ -348,7 +350,7 @@ int fft_tables(hipdsp_ctx *ctx, int nfft, const float **dev)
 
 extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, int64_t channels,
                                   int64_t frames, int nfft, int hop, double fs, float *out,
-                                  float *db_out, int64_t frames_out)
+                                  float *db_out, int64_t frames_out, int64_t out_pitch)
 {
     HD_REQUIRE(ctx != nullptr, "ctx is NULL");
     HD_REQUIRE(channels >= 0 && frames >= 0 && frames_out >= 0, "negative size");
@@ -361,6 +363,8 @@ extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pit
     }
     if (channels == 0 || frames_out == 0) return HIPDSP_OK;
     HD_REQUIRE(out != nullptr, "out is NULL");
+    if (out_pitch == 0) out_pitch = frames_out * (long long)(nfft / 2 + 1);
+    HD_REQUIRE(out_pitch >= frames_out * (long long)(nfft / 2 + 1), "out_pitch smaller than one channel");
     HD_REQUIRE(channels <= 65535, "more than 65535 channels");
     HD_REQUIRE(frames_out <= 0x7fffffffLL, "too many frames");
     HD_CHECK_HIP(hipSetDevice(ctx->device));
@@ -382,11 +386,11 @@ extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pit
         int rc = fft_tables(ctx, nfft, &tables);
         if (rc != HIPDSP_OK) return rc;
         switch (nfft) {
-        case 256:  return launch_fast<256, 16, 8, 4, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, hop, scale, tables, out, db_out);
-        case 512:  return launch_fast<512, 32, 8, 8, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, hop, scale, tables, out, db_out);
-        case 1024: return launch_fast<1024, 64, 8, 8, 8>(ctx, x, x_pitch, channels, n_valid, frames_out, hop, scale, tables, out, db_out);
-        case 2048: return launch_fast<2048, 64, 16, 16, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, hop, scale, tables, out, db_out);
-        case 4096: return launch_fast<4096, 64, 16, 16, 8>(ctx, x, x_pitch, channels, n_valid, frames_out, hop, scale, tables, out, db_out);
+        case 256:  return launch_fast<256, 16, 8, 4, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, tables, out, db_out);
+        case 512:  return launch_fast<512, 32, 8, 8, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, tables, out, db_out);
+        case 1024: return launch_fast<1024, 64, 8, 8, 8>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, tables, out, db_out);
+        case 2048: return launch_fast<2048, 64, 16, 16, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, tables, out, db_out);
+        case 4096: return launch_fast<4096, 64, 16, 16, 8>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, tables, out, db_out);
         }
     }
     size_t lds = sizeof(float2) * 2 * (size_t)nfft;
@@ -394,7 +398,7 @@ extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pit
         HD_CHECK_HIP(hipFuncSetAttribute((const void *)spec_generic_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(spec_generic_kernel, dim3((unsigned)frames_out, (unsigned)channels), dim3(256), lds,
-                       ctx->stream, x, (long long)x_pitch, n_valid, (long long)frames_out, nfft, hop, scale,
-                       out, db_out);
+                       ctx->stream, x, (long long)x_pitch, n_valid, (long long)frames_out, (long long)out_pitch,
+                       nfft, hop, scale, out, db_out);
     return hd_launch_status("spec_generic_kernel");
 }

@@ -227,10 +227,11 @@ def envelope(ctx, plan, x, x_pitch, y, y_pitch, channels, frames, skip=0, rectif
                               float(gain), int(bool(clamp))))
 
 
-def spectrogram(ctx, x, x_pitch, channels, frames, nfft, hop, fs, out, frames_out, db_out=None):
+def spectrogram(ctx, x, x_pitch, channels, frames, nfft, hop, fs, out, frames_out, db_out=None,
+                out_pitch=0):
     check(lib.hipdsp_spectrogram(ctx.handle, _p(x), int(x_pitch), int(channels), int(frames),
                                  int(nfft), int(hop), float(fs), _p(out), _p(db_out),
-                                 int(frames_out)))
+                                 int(frames_out), int(out_pitch)))
 
 
 def decibel(ctx, p, out, n, ref_power=1.0, min_power=1e-20):
@@ -253,9 +254,14 @@ def unpack(ctx, src, src_pitch, dst_tc, frames, channels):
                                 int(channels)))
 
 
-def unpack_spectrum(ctx, src, dst_tcf, frames, channels, nfreq):
-    check(lib.hipdsp_unpack_spectrum_f64(ctx.handle, _p(src), _p(dst_tcf), int(frames),
-                                         int(channels), int(nfreq)))
+def unpack_spectrum(ctx, src, dst_tcf, frames, channels, nfreq, src_pitch=0):
+    check(lib.hipdsp_unpack_spectrum_f64(ctx.handle, _p(src), int(src_pitch), _p(dst_tcf),
+                                         int(frames), int(channels), int(nfreq)))
+
+
+def memcpy2d(ctx, dst, dst_pitch_bytes, src, src_pitch_bytes, width_bytes, height):
+    check(lib.hipdsp_memcpy2d_d2d(ctx.handle, _p(dst), int(dst_pitch_bytes), _p(src),
+                                  int(src_pitch_bytes), int(width_bytes), int(height)))
 
 
 def synth(ctx, x, x_pitch, channels, frames, rate, seed, c0=0, c_total=None):

@@ -75,6 +75,10 @@ int hipdsp_memset(hipdsp_ctx *ctx, void *dptr, int value, size_t bytes);
 int hipdsp_memcpy_h2d(hipdsp_ctx *ctx, void *dst, const void *host_src, size_t bytes);
 int hipdsp_memcpy_d2h(hipdsp_ctx *ctx, void *host_dst, const void *src, size_t bytes);
 int hipdsp_memcpy_d2d(hipdsp_ctx *ctx, void *dst, const void *src, size_t bytes);
+/* `height` rows of `width` bytes between pitched device blocks (ring-buffer recycling
+ * of the device mirror, buffereddata.py:87). */
+int hipdsp_memcpy2d_d2d(hipdsp_ctx *ctx, void *dst, size_t dst_pitch, const void *src,
+                        size_t src_pitch, size_t width, size_t height);
 
 /* HIP events on the context's stream (bench.py times kernels with these). */
 int hipdsp_event_create(hipdsp_ctx *ctx, void **event);
@@ -98,9 +102,11 @@ int hipdsp_pack_f32(hipdsp_ctx *ctx, const float *src_tc, float *dst, int64_t ds
 int hipdsp_unpack_f64(hipdsp_ctx *ctx, const float *src, int64_t src_pitch, double *dst_tc,
                       int64_t frames, int64_t channels);
 /* (C, T', F) float32 -> (T', C, F) float64: the reference's
- * Sxx.transpose((1, 2, 0)) (bufferedspectrogram.py:58). */
-int hipdsp_unpack_spectrum_f64(hipdsp_ctx *ctx, const float *src, double *dst_tcf,
-                               int64_t frames, int64_t channels, int64_t nfreq);
+ * Sxx.transpose((1, 2, 0)) (bufferedspectrogram.py:58).  src_pitch = elements
+ * between consecutive channels of src (>= frames*nfreq). */
+int hipdsp_unpack_spectrum_f64(hipdsp_ctx *ctx, const float *src, int64_t src_pitch,
+                               double *dst_tcf, int64_t frames, int64_t channels,
+                               int64_t nfreq);
 
 /* ---- IIR filter plans ---------------------------------------------------- */
 
@@ -155,12 +161,13 @@ int hipdsp_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const float *x,
  *   zeros for n_valid <= k < frames_out,
  * where n_valid = (nsource - (nfft - hop)) / hop and
  * nsource = min((frames_out - 1)*hop + nfft, frames)  (0 valid frames when
- * nsource < nfft).  out is (channels, frames_out, nfft/2 + 1) compact float32.
+ * nsource < nfft).  out is (channels, frames_out, nfft/2 + 1) float32 with out_pitch
+ * elements between consecutive channels (0 = compact, frames_out*(nfft/2 + 1)).
  * If db_out != NULL it additionally receives decibel(out) (fused epilogue,
  * specitem.py:36) in the same layout.  nfft must be a power of two in [8, 8192]. */
 int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, int64_t channels,
                        int64_t frames, int nfft, int hop, double fs, float *out,
-                       float *db_out, int64_t frames_out);
+                       float *db_out, int64_t frames_out, int64_t out_pitch);
 
 /* thunderlab.powerspectrum.decibel (specitem.py:28,36; spectrogramplot.py:159;
  * bufferedspectrogram.py:116-117): out = 10*log10(p/ref_power), -inf where

@@ -1,0 +1,237 @@
+"""Host logic of the BufferedData facade (no GPU): bookkeeping, index transforms
+incl. the reference's seconds/rate quirk, ring-buffer recycling, dirty propagation.
+Expected values are derived by hand from src/audian/buffereddata.py:33-153 and
+src/audian/data.py:150-231 of the reference."""
+
+from math import ceil, floor
+
+import numpy as np
+import pytest
+
+from audian_amd.bufferedarray import ArrayLoader
+from audian_amd.buffereddata import BufferedData, _merge, _covers
+from audian_amd.bufferedspectrogram import BufferedSpectrogram, decibel
+from audian_amd.tracegraph import TraceGraph
+
+
+class Item:
+    def __init__(self, visible=True):
+        self.visible = visible
+
+    def isVisible(self):
+        return self.visible
+
+    def setVisible(self, show):
+        self.visible = show
+
+
+class Doubler(BufferedData):
+    """Stateless stand-in for a derived trace: dest = 2*source[nbefore:]."""
+
+    def __init__(self, name='double', source='data', tbefore=0, tafter=0, step=1):
+        super().__init__(name, source, tbefore=tbefore, tafter=tafter)
+        self.step = step
+        self.calls = []
+
+    def open(self, source):
+        super().open(source, self.step)
+
+    def process(self, source, dest, nbefore):
+        self.calls.append((len(source), len(dest), nbefore, self._pending.soffset,
+                           self._pending.doffset))
+        n = len(dest)
+        dest[:] = 2*source[nbefore:nbefore + n*self.step:self.step][:n]
+
+
+def ramp(frames, channels=2):
+    return np.arange(frames, dtype=np.float64)[:, None] + 0.25*np.arange(channels)[None, :]
+
+
+def make_graph(trace, frames=4000, rate=100.0, buffer_time=10.0, back_time=2.0):
+    g = TraceGraph(buffer_time, back_time)
+    g.add_trace(trace)
+    g.setup_traces()
+    g.open(ramp(frames), rate)
+    return g
+
+
+def test_interval_helpers():
+    assert _merge([[5, 7], [0, 2], [2, 4], [6, 9]]) == [[0, 4], [5, 9]]
+    assert _covers([[0, 4], [5, 9]], 1, 3) and not _covers([[0, 4], [5, 9]], 3, 6)
+
+
+def test_array_loader_and_getitem():
+    a = ArrayLoader(ramp(1000), 100.0, buffer_time=2.0, back_time=0.5)
+    assert len(a) == 1000 and a.bufferframes == 200 and a.backframes == 50
+    assert a.offset == 0 and len(a.buffer) == 200
+    assert np.array_equal(a[10:20, 1], ramp(1000)[10:20, 1])
+    assert a.offset == 0
+    assert np.array_equal(a[500:520, 0], ramp(1000)[500:520, 0])     # moves the buffer
+    assert a.offset == 450 and len(a.buffer) == 200
+    assert a[999, 0] == 999.0
+    assert a.offset + len(a.buffer) == 1000
+    with pytest.raises(IndexError):
+        a[1000]
+
+
+def test_open_and_update_step():
+    t = Doubler(tbefore=10)
+    g = make_graph(t)
+    assert (t.rate, t.frames, t.shape, t.channels) == (100.0, 4000, (4000, 2), 2)
+    assert t.source is g.data and g.data.dests == [t]
+    assert t.unit == g.data.unit and t.ampl_max == g.data.ampl_max
+    # data buffer: buffer_time + tbefore (10) -> 20 s, back_time 2 + 10
+    assert (g.tbefore, g.tafter) == (10, 0)
+    assert g.data.bufferframes == 2000 and g.data.backframes == 1200
+    s = Doubler(step=8)
+    g = make_graph(s)
+    assert s.rate == 100.0/8 and s.frames == 500 and s.shape == (500, 2)
+    assert s.bufferframes == int((0/100.0)*s.rate)           # bufferframes was 0 before open
+
+
+def test_load_buffer_quirk_and_align():
+    """tbefore/tafter are divided by the rate in load_buffer (buffereddata.py:96,99):
+    nbefore = floor(10/100) = 0, nafter = ceil(10/100) = 1."""
+    t = Doubler(tbefore=10, tafter=10)
+    g = make_graph(t)
+    t.plot_items = [Item(), None]
+    g.set_need_update()
+    assert t.need_update and g.data.need_update      # propagated up from the visible leaf
+    g.update_times(0.0, 5.0)
+    # data buffer starts at 0 -> no front trim; it ends before EOF -> back trim floor(10*100)
+    assert g.data.offset == 0 and len(g.data.buffer) == 3000   # 10 + 10 + 10 s
+    assert t.offset == 0 and len(t.buffer) == 3000 - 1000
+    ns, nd, nbefore, soff, doff = t.calls[-1]
+    assert (nd, nbefore, soff, doff) == (2000, 0, 0, 0)
+    assert ns == 2000 + 1                                       # nafter = 1 sample
+    assert np.array_equal(t.buffer, 2*ramp(4000)[:2000])
+    # scroll forward: data offset > 0 -> front trim floor(10*100) as well
+    g.update_times(25.0, 30.0)
+    d0 = g.data.offset
+    assert d0 == int(15.0*100) - g.data.backframes + 0 or d0 >= 0
+    assert t.offset == d0 + 1000
+    assert np.array_equal(t.buffer, 2*ramp(4000)[t.offset:t.offset + len(t.buffer)])
+    assert np.all(t.buffer_changed)
+
+
+def test_move_buffer_recycles_overlap():
+    t = Doubler()
+    g = make_graph(t, buffer_time=10.0, back_time=0.0)
+    t.plot_items = [Item(), Item()]
+    g.set_need_update()
+    g.update_times(0.0, 5.0)
+    assert len(t.calls) == 1 and t.calls[0][1] == 1000
+    g.update_times(6.0, 12.0)            # data moves to [600, 1600): 400 frames overlap
+    assert g.data.offset == 600
+    assert len(t.calls) == 2
+    ns, nd, nbefore, soff, doff = t.calls[1]
+    assert (nd, doff) == (600, 400)      # only the missing tail is computed
+    assert soff == 400
+    assert np.array_equal(t.buffer, 2*ramp(4000)[600:1600])
+    g.update_times(3.0, 9.0)             # backwards: head is missing
+    assert np.array_equal(t.buffer, 2*ramp(4000)[t.offset:t.offset + len(t.buffer)])
+    assert t.calls[-1][4] == 0
+
+
+def test_strided_trace_index_transform():
+    """A trace at rate/step (the spectrogram's case): offsets via ceil/floor as in
+    align_buffer (buffereddata.py:85-86) and load_buffer (:94-95)."""
+    s = Doubler(step=8, tafter=10)
+    g = make_graph(s, frames=4001)
+    s.plot_items = [Item(), None]
+    g.set_need_update()
+    g.update_times(0.0, 5.0)
+    n_data = len(g.data.buffer)
+    trimmed = n_data - floor(10*100.0)
+    assert s.offset == 0 and len(s.buffer) == floor(trimmed*s.rate/100.0)
+    ns, nd, nbefore, soff, doff = s.calls[-1]
+    assert ns == min(ceil(nd*8) + 1, n_data) and nbefore == 0
+
+
+def test_need_update_propagation_and_recompute_all():
+    g = TraceGraph(10.0, 2.0)
+    a, b, c = Doubler('a', 'data'), Doubler('b', 'a'), Doubler('c', 'a')
+    for t in (c, b, a):
+        g.add_trace(t)
+    g.setup_traces()
+    assert [t.name for t in g.traces] == ['a', 'b', 'c'] or [t.name for t in g.traces] == ['a', 'c', 'b']
+    g.open(ramp(3000), 100.0)
+    assert a.dests == [g['b'], g['c']] or a.dests == [g['c'], g['b']]
+    b.plot_items = [Item(True), None]
+    c.plot_items = [Item(False), None]
+    a.plot_items = [Item(False), None]
+    g.set_need_update()
+    assert b.need_update and not c.need_update
+    assert a.need_update and g.data.need_update       # propagated up from the visible leaf
+    g.update_times(0.0, 5.0)
+    n0 = len(a.calls)
+    a.recompute_all()
+    assert len(a.calls) == n0 + 1 and len(b.calls) >= 2 and len(c.calls) == 0
+    assert np.array_equal(b.buffer, 4*ramp(3000)[b.offset:b.offset + len(b.buffer)])
+    b.set_visible(False)
+    g.set_need_update()
+    assert not b.need_update
+
+
+def test_missing_source_is_reported():
+    g = TraceGraph()
+    g.add_trace(Doubler('x', 'nowhere'))
+    with pytest.raises(ValueError):
+        g.setup_traces()
+
+
+def test_expand_times_accumulation():
+    from audian_amd.bufferedfilter import BufferedFilter
+    from audian_amd.bufferedenvelope import BufferedEnvelope
+    g = TraceGraph()
+    f, s, e = BufferedFilter.__new__(BufferedFilter), None, None
+    # constructors only (no device needed before open)
+    f = BufferedFilter()
+    s = BufferedSpectrogram()
+    e = BufferedEnvelope()
+    for t in (f, s, e):
+        g.add_trace(t)
+    g.setup_traces()
+    tb = [0]*3
+    ta = [0]*3
+    tbefore = tafter = 0
+    for k in reversed(range(3)):
+        b, a = g.traces[k].expand_times(tb[k], ta[k])
+        i = g.sources[k]
+        if i < 0:
+            tbefore, tafter = max(tbefore, b), max(tafter, a)
+        else:
+            tb[i], ta[i] = max(tb[i], b), max(ta[i], a)
+    assert (tbefore, tafter) == (11, 10)            # data.py:154-168 with the default traces
+    assert (f.tbefore, f.tafter) == (1, 10) and (f.source_tbefore, f.source_tafter) == (10, 0)
+
+
+def test_spectrogram_parameters():
+    s = BufferedSpectrogram()
+    assert (s.nfft, s.hop, s.overlap_frac) == (256, 128, 0.5)
+    src = ArrayLoader(ramp(100000), 48000.0, buffer_time=1.0, back_time=0.0)
+    s.open(src)
+    assert s.hop == 128 and s.rate == 48000.0/128 and s.frames == ceil(100000/128)
+    assert s.shape == (s.frames, 2, 129) and s.unit.endswith('^2/Hz')
+    assert (s.ampl_min, s.ampl_max) == (0, 24000.0)
+    assert s.fresolution == 48000.0/256 and s.tresolution == 128/48000.0
+    assert len(s.frequencies) == 129
+    s.update(nfft=4)                        # clamped to 8
+    assert s.nfft == 8 and s.hop == 4 and s.shape[2] == 5
+    s.update(nfft=2**31)                    # clamped to len(source)//2
+    assert s.nfft == 50000
+    s.update(nfft=1024, overlap_frac=2.0)   # overlap clamped to 0.99999 -> hop >= 1
+    assert s.nfft == 1024 and s.hop == 1 and abs(s.overlap_frac - (1 - 1/1024)) < 1e-12
+    s.update(overlap_frac=-1.0)
+    assert s.hop == 1024 and s.overlap_frac == 0.0
+    s.update(overlap_frac=0.75)
+    assert s.hop == 256 and s.rate == 48000.0/256
+    assert s.estimate_noiselevels(0) == (None, None)          # empty buffer
+
+
+def test_host_decibel():
+    p = np.array([0.0, 1e-20, 1e-19, 1.0, 100.0])
+    d = decibel(p)
+    assert d[0] == -np.inf and d[1] == -np.inf
+    assert np.allclose(d[2:], [-190.0, 0.0, 20.0])
+    assert decibel(10.0) == 10.0

@@ -1,0 +1,253 @@
+"""The drop-in surface end to end on the GPU: BufferedFilter -> {BufferedSpectrogram,
+BufferedEnvelope} driven like audian's Data model drives them, compared with twin
+traces whose process() bodies are the CPU oracle's restatement of the reference."""
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+class Item:
+    def __init__(self, visible=True):
+        self.visible = visible
+
+    def isVisible(self):
+        return self.visible
+
+    def setVisible(self, show):
+        self.visible = show
+
+
+def recording(rate, seconds, channels, seed=11):
+    rng = np.random.default_rng(seed)
+    n = int(rate*seconds)
+    t = np.arange(n)/rate
+    x = rng.uniform(-1, 1, size=(n, channels))
+    for c in range(channels):
+        x[:, c] = 0.5*x[:, c] + 0.5*np.sin(2*np.pi*(700.0 + 300*c)*t)*(1 + np.sin(2*np.pi*3*t))/2
+    return x.astype(np.float32).astype(np.float64)
+
+
+def oracle_twins(oracle):
+    """Subclasses that keep the facade's bookkeeping but compute with the oracle."""
+    from audian_amd.bufferedfilter import BufferedFilter
+    from audian_amd.bufferedenvelope import BufferedEnvelope
+    from audian_amd.bufferedspectrogram import BufferedSpectrogram
+
+    class OFilter(BufferedFilter):
+        def process(self, source, dest, nbefore):
+            self._pending = None
+            oracle.filter_process(self.sos, source, dest, nbefore)
+
+        def update(self):
+            plans, self.ctx_calls = None, 0
+            from audian_amd.design import butter_sos
+            hp, lp, r = self.highpass_cutoff, self.lowpass_cutoff, self.rate
+            if hp < 0.001*r/2 and lp >= r/2 - 1e-8:
+                self.sos = None
+            elif hp < 0.001*r/2:
+                self.sos = butter_sos(self.filter_order, lp, 'lowpass', r)
+            elif lp >= r/2 - 1e-8:
+                self.sos = butter_sos(self.filter_order, hp, 'highpass', r)
+            else:
+                self.sos = butter_sos(self.filter_order, (hp, lp), 'bandpass', r)
+            self.recompute_all()
+
+    class OEnvelope(BufferedEnvelope):
+        def process(self, source, dest, nbefore):
+            self._pending = None
+            oracle.envelope_process(self.sos, source, dest, nbefore, self.highpass_cutoff)
+
+        def update(self):
+            from audian_amd.design import butter_sos
+            try:
+                if self.highpass_cutoff > 0:
+                    self.sos = butter_sos(self.filter_order, (self.highpass_cutoff, self.envelope_cutoff),
+                                          'bandpass', self.rate)
+                else:
+                    self.sos = butter_sos(self.filter_order, self.envelope_cutoff, 'lowpass', self.rate)
+            except ValueError:
+                self.sos = None
+            self.recompute_all()
+
+    class OSpectrogram(BufferedSpectrogram):
+        def process(self, source, dest, nbefore):
+            self._pending = None
+            oracle.spectrogram_process(source, dest, self.source.rate, self.nfft, self.hop)
+
+    return OFilter, OEnvelope, OSpectrogram
+
+
+def build(classes, x, rate, buffer_time, back_time, **spec_kw):
+    from audian_amd.tracegraph import TraceGraph
+    F, E, S = classes
+    g = TraceGraph(buffer_time, back_time)
+    for t in (F(), S(**spec_kw), E(envelope_cutoff=200.0)):
+        g.add_trace(t)
+    g.setup_traces()
+    g.open(x, rate)
+    for t in g.traces:
+        t.plot_items = [Item() for _ in range(t.channels)]
+    g.set_need_update()
+    return g
+
+
+def compare(g, o):
+    for name in ('filtered', 'envelope', 'spectrogram'):
+        a, b = g[name], o[name]
+        assert a.offset == b.offset and a.buffer.shape == b.buffer.shape, name
+        assert (a.rate, a.frames, a.shape) == (b.rate, b.frames, b.shape)
+        if name == 'spectrogram':
+            for ch in range(a.channels):
+                for k in range(len(a.buffer)):
+                    want = b.buffer[k, ch]
+                    if np.max(np.abs(want)) == 0:
+                        assert np.all(a.buffer[k, ch] == 0)
+                    else:
+                        assert rel_err(a.buffer[k, ch], want) < TOL, (name, k, ch)
+        else:
+            for ch in range(a.channels):
+                assert rel_err(a.buffer[:, ch], b.buffer[:, ch]) < TOL, (name, ch)
+
+
+def test_scroll_update_and_recompute_match_oracle_twins(oracle):
+    from audian_amd.bufferedfilter import BufferedFilter
+    from audian_amd.bufferedenvelope import BufferedEnvelope
+    from audian_amd.bufferedspectrogram import BufferedSpectrogram
+    rate = 16000.0
+    x = recording(rate, 40.0, 2)
+    g = build((BufferedFilter, BufferedEnvelope, BufferedSpectrogram), x, rate, 4.0, 1.0, nfft=256)
+    o = build(oracle_twins(oracle), x, rate, 4.0, 1.0, nfft=256)
+    assert (g.tbefore, g.tafter) == (11, 10)
+    for twin in (g, o):
+        twin['filtered'].highpass_cutoff = 300.0
+        twin['filtered'].lowpass_cutoff = 3000.0
+        twin['filtered'].update()
+    for t0, t1 in [(0.0, 2.0), (1.0, 3.0), (12.0, 15.0), (14.0, 17.0), (5.0, 6.0), (38.0, 40.0)]:
+        g.update_times(t0, t1)
+        o.update_times(t0, t1)
+        compare(g, o)
+    # interactive cut-off change: filter -> spectrogram -> envelope recomputed depth-first
+    for hp, lp in [(1000.0, 5000.0), (0.0, 2000.0), (500.0, rate/2), (0.0, rate/2)]:
+        for twin in (g, o):
+            twin['filtered'].highpass_cutoff = hp
+            twin['filtered'].lowpass_cutoff = lp
+            twin['filtered'].update()
+        compare(g, o)
+    # resolution change
+    for twin in (g, o):
+        twin['spectrogram'].update(nfft=1024, overlap_frac=0.75)
+    compare(g, o)
+    assert g['spectrogram'].shape[2] == 513 and g['spectrogram'].hop == 256
+    # envelope: band-pass variant (no clamp) and failed design -> zeros
+    for twin in (g, o):
+        twin['envelope'].highpass_cutoff = 5.0
+        twin['envelope'].update()
+    compare(g, o)
+    for twin in (g, o):
+        twin['envelope'].envelope_cutoff = rate       # above Nyquist: butter raises, sos = None
+        twin['envelope'].update()
+    assert g['envelope'].sos is None and np.all(g['envelope'].buffer == 0)
+    # slicing through __getitem__ and the spectrogram helpers
+    s = g['spectrogram']
+    i0 = s.offset
+    assert np.array_equal(s[i0:i0 + 3, 1], s.buffer[:3, 1])
+    img = s.decibel_image(1)
+    want = oracle.decibel(s.buffer[:, 1, :].T)
+    fin = np.isfinite(want)
+    assert img.shape == want.shape and np.array_equal(np.isfinite(img), fin)
+    assert np.max(np.abs(img[fin] - want[fin])) < 1e-3
+    zmin, zmax = s.estimate_noiselevels(0)
+    assert zmin is not None and 20 <= zmax - zmin <= 80
+    assert s.spec_rect == [s.offset/s.rate, 0, len(s.buffer)/s.rate, rate/2 + s.fresolution]
+
+
+def test_chain_stays_on_the_device(oracle, monkeypatch):
+    """Only the raw data is uploaded; spectrogram and envelope read the filter's mirror,
+    and nothing is copied back until a buffer is read."""
+    from audian_amd import hipdsp
+    from audian_amd.bufferedfilter import BufferedFilter
+    from audian_amd.bufferedenvelope import BufferedEnvelope
+    from audian_amd.bufferedspectrogram import BufferedSpectrogram
+    rate = 16000.0
+    x = recording(rate, 20.0, 3, seed=5)
+    g = build((BufferedFilter, BufferedEnvelope, BufferedSpectrogram), x, rate, 4.0, 1.0, nfft=512)
+    g.update_times(2.0, 4.0)
+    counts = {'pack': 0, 'unpack': 0, 'unpack_spectrum': 0}
+    for name in counts:
+        real = getattr(hipdsp, name)
+
+        def wrapped(*a, _real=real, _name=name, **k):
+            counts[_name] += 1
+            return _real(*a, **k)
+        monkeypatch.setattr(hipdsp, name, wrapped)
+    f = g['filtered']
+    f.highpass_cutoff, f.lowpass_cutoff = 400.0, 4000.0
+    f.update()                                  # recompute_all through the whole graph
+    assert counts == {'pack': 1, 'unpack': 0, 'unpack_spectrum': 0}
+    _ = g['spectrogram'].buffer                 # the display reads one trace
+    assert counts == {'pack': 1, 'unpack': 0, 'unpack_spectrum': 1}
+    _ = g['envelope'][g['envelope'].offset:g['envelope'].offset + 10, 0]
+    assert counts['unpack'] == 1
+    o = build(oracle_twins(oracle), x, rate, 4.0, 1.0, nfft=512)
+    o.update_times(2.0, 4.0)
+    of = o['filtered']
+    of.highpass_cutoff, of.lowpass_cutoff = 400.0, 4000.0
+    of.update()
+    compare(g, o)
+
+
+def test_process_as_plain_function_on_host_arrays(oracle):
+    """process(source, dest, nbefore) called directly with NumPy arrays (the plugin hook)."""
+    from audian_amd.bufferedarray import ArrayLoader
+    from audian_amd.bufferedfilter import BufferedFilter
+    from audian_amd.bufferedenvelope import BufferedEnvelope
+    from audian_amd.bufferedspectrogram import BufferedSpectrogram
+    rate = 48000.0
+    x = recording(rate, 1.0, 2, seed=3)
+    src = ArrayLoader(x, rate, buffer_time=1.0, back_time=0.0)
+    f = BufferedFilter()
+    f.open(src)
+    f.highpass_cutoff, f.lowpass_cutoff, f.filter_order = 300.0, 3000.0, 4
+    f.update()
+    assert f.sos.shape == (4, 6)
+    dest = np.zeros((len(x) - 7, 2))
+    f.process(x, dest, 7)
+    want = np.zeros_like(dest)
+    oracle.filter_process(f.sos, x, want, 7)
+    assert rel_err(dest, want) < TOL
+    with pytest.raises(ValueError):
+        f.process(x, np.zeros((len(x), 2)), 7)
+    f.filter_order = 6                                   # 6 sections: two chained plans
+    f.update()
+    assert f.sos.shape == (6, 6) and len(f._plans) == 2
+    f.process(x, dest, 7)
+    oracle.filter_process(f.sos, x, want, 7)
+    assert rel_err(dest, want) < TOL
+    e = BufferedEnvelope(envelope_cutoff=100.0)
+    e.open(src)
+    dest = np.zeros_like(x)
+    e.process(x, dest, 0)
+    want = np.zeros_like(x)
+    oracle.envelope_process(e.sos, x, want, 0)
+    assert rel_err(dest, want) < TOL
+    with pytest.raises(ValueError):
+        e.process(x[:9], np.zeros((9, 2)), 0)            # not longer than padlen
+    s = BufferedSpectrogram(nfft=512)
+    s.open(src)
+    nd = 40
+    dest = np.full((nd, 2, 257), np.nan)
+    s.process(x[:nd*256 + 1], dest, 0)
+    want = np.zeros_like(dest)
+    oracle.spectrogram_process(x[:nd*256 + 1], want, rate, 512, 256)
+    assert np.all(dest[-1] == 0)
+    for k in range(nd - 1):
+        assert rel_err(dest[k], want[k]) < TOL
+    s.nfft, s.hop = 100, 50
+    with pytest.raises(NotImplementedError):
+        s.process(x, np.zeros((10, 2, 51)), 0)
