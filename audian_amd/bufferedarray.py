@@ -47,6 +47,13 @@ class BufferedArray(object):
         raise NotImplementedError
 
     # -- buffer management -----------------------------------------------------
+    def _buf(self):
+        """The buffer as stored (subclasses with a lazy host copy return it unsynced)."""
+        return self.buffer
+
+    def _prepare_keep(self, a, b):
+        """Hook: frames [a, b) of the current buffer are about to be copied."""
+
     def _blank(self, nframes):
         return np.zeros((int(nframes),) + tuple(self.shape[1:]))
 
@@ -56,14 +63,15 @@ class BufferedArray(object):
             nframes = self.bufferframes
         if self.offset + nframes > self.frames:
             nframes = max(0, self.frames - self.offset)
-        if force or nframes != len(self.buffer) or \
-           tuple(self.buffer.shape[1:]) != tuple(self.shape[1:]):
+        cur = self._buf()
+        if force or nframes != len(cur) or tuple(cur.shape[1:]) != tuple(self.shape[1:]):
             self.buffer = self._blank(nframes)
 
     def reload_buffer(self):
         """Recompute the whole current buffer in place."""
-        if len(self.buffer) > 0:
-            self.load_buffer(self.offset, len(self.buffer), self.buffer)
+        cur = self._buf()
+        if len(cur) > 0:
+            self.load_buffer(self.offset, len(cur), cur)
             self.buffer_changed[:] = True
 
     def move_buffer(self, offset, nframes):
@@ -71,7 +79,7 @@ class BufferedArray(object):
         overlaps the current buffer is kept, the rest comes from ``load_buffer``."""
         offset = int(max(0, offset))
         nframes = int(max(0, min(nframes, self.frames - offset)))
-        old, old_off = self.buffer, self.offset
+        old, old_off = self._buf(), self.offset
         if offset == old_off and nframes == len(old):
             return
         new = self._blank(nframes)
@@ -81,6 +89,7 @@ class BufferedArray(object):
             keep0 = keep1 = 0
         todo = []
         if keep1 > keep0:
+            self._prepare_keep(keep0 - old_off, keep1 - old_off)
             new[keep0 - offset:keep1 - offset] = old[keep0 - old_off:keep1 - old_off]
             if keep0 > offset:
                 todo.append((offset, keep0 - offset))

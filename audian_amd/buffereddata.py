@@ -109,6 +109,21 @@ class BufferedData(BufferedArray):
         self._dev = None
         self._dev_valid = []
 
+    def _buf(self):
+        return self._hostbuf
+
+    def _prepare_keep(self, a, b):
+        """Only the part of the host copy that survives a buffer move is read back."""
+        if self._stale:
+            keep = []
+            for r0, r1 in self._stale:
+                lo, hi = max(r0, a), min(r1, b)
+                if hi > lo:
+                    keep.append([lo, hi])
+            self._stale = keep
+            if keep:
+                self._flush()
+
     @property
     def ctx(self):
         if self._ctx is None:
