@@ -59,6 +59,13 @@ struct SeqArgs {
     int clamp;
 };
 
+__device__ __forceinline__ long long opaque_zero()
+{
+    int z;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    return (long long)z;
+}
+
 __device__ __forceinline__ int lds_slot(int row, int q) { return row * 8 + (q ^ ((row >> 1) & 7)); }
 
 // One logical sample (slow path: sequence borders, odd extension).
@@ -148,12 +155,15 @@ __device__ __forceinline__ void store_four(const SeqArgs &a, float *out, long lo
 }
 
 template <int S, int MODE>
-__global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *P, SeqArgs a)
+__global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *__restrict__ P0, SeqArgs a)
 {
-    // The plan tables (coefficients, G, M: up to ~3 KB) are wave-uniform and read
-    // with scalar loads.  RELOAD() stops the compiler from hoisting them out of the
-    // tile loop, which would need ~500 SGPRs and spill them through v_writelane.
-#define RELOAD() asm volatile("" ::: "memory")
+    // The plan tables (coefficients, G, M: up to ~3 KB) are wave-uniform and must come
+    // through scalar loads (s_load -> SGPR operands of v_fma_f64).  Hoisting them out of
+    // the tile loop would need ~500 SGPRs and spill through v_writelane; a "memory"
+    // clobber would demote them to per-lane vector loads.  So every use goes through
+    // PLAN(): the same pointer plus an opaque, always-zero scalar that the compiler must
+    // assume changes each time, which pins the s_load next to its use.
+#define PLAN() (reinterpret_cast<const SosPlanDev *>(reinterpret_cast<const char *>(P0) + opaque_zero()))
     constexpr int D = 2 * S;
     __shared__ float4 lds[64 * 8];
     const int lane = threadIdx.x;
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *P, SeqAr
     const long long lo = (long long)seg * a.seg_len;
     long long hi = lo + a.seg_len;
     if (hi > a.N) hi = a.N;
-    long long start = lo - P->warm;
+    long long start = lo - P0->warm;
     const bool true_init = start <= 0;
     if (start < 0) start = 0;
 
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *P, SeqAr
         // scipy sosfiltfilt: zi * x_ext[0] (forward) / zi * y_fwd[-1] (backward)
         double v0 = (double)load_one<MODE>(a, in, 0);
 #pragma unroll
-        for (int r = 0; r < D; r++) carry[r] = P->zi[r] * v0;
+        for (int r = 0; r < D; r++) carry[r] = P0->zi[r] * v0;
     }
 
     for (long long tile = start; tile < hi; tile += TILE) {
@@ -194,7 +204,7 @@ __global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *P, SeqAr
         for (int r = 0; r < D; r++) f[r] = 0.0;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            RELOAD();
+            const SosPlanDev *P = PLAN();
             const float4 v = lds[lds_slot(lane, q)];
             const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -204,9 +214,9 @@ __global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *P, SeqAr
                 for (int r = 0; r < D; r++) f[r] = fma(P->G[4 * q + k][r], xd, f[r]);
             }
         }
-        RELOAD();
         // fold the tile's incoming state into lane 0: P_0 = A^L carry + f_0
         {
+            const SosPlanDev *P = PLAN();
             double t[D];
 #pragma unroll
             for (int r = 0; r < D; r++) {
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *P, SeqAr
         // ---- inclusive scan over lanes: P_i += A^(L*d) P_(i-d)
 #pragma unroll
         for (int k = 0; k < 6; k++) {
-            RELOAD();
+            const SosPlanDev *P = PLAN();
             const int d = 1 << k;
             double q[D];
 #pragma unroll
@@ -249,8 +259,8 @@ __global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *P, SeqAr
 
         // ---- phase 3: the cascade itself (scipy _sosfilt order: samples outer, sections
         // inner); the lane re-reads its row from LDS and overwrites it with the outputs
-        RELOAD();
         {
+            const SosPlanDev *P = PLAN();
             double cf[S][5];
 #pragma unroll
             for (int s = 0; s < S; s++)
@@ -275,7 +285,6 @@ __global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *P, SeqAr
                 lds[lds_slot(lane, q)] = make_float4(e[0], e[1], e[2], e[3]);
             }
         }
-        RELOAD();
         __syncthreads();
         if (tile + TILE > lo) {      // warm-up tiles produce no output
 #pragma unroll
