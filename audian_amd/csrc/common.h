@@ -19,6 +19,8 @@ struct hipdsp_ctx {
     hipEvent_t mid_event;  // optional: recorded between envelope fwd and bwd
     void *fft_tables[20];  // per log2(nfft): window | TWM | TWN (device), built on first use
     int force_generic_fft; // tests: use the generic radix-2 kernel for every nfft
+    void *fft_tables2[20]; // same for the two-stage kernel: tw2 | twn | window
+    int spec_fpw, spec_flags, spec_waves, spec_kernel;   // experiments (tools/), 0 = defaults
 };
 
 #define HD_CHECK_HIP(expr)                                                        \

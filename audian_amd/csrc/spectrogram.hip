@@ -5,6 +5,7 @@
 // (thunderlab decibel, src/audian/specitem.py:36).
 #include "common.h"
 #include <cmath>
+#include <type_traits>
 
 namespace {
 
@@ -146,11 +147,23 @@ template <> __device__ __forceinline__ void dft<16>(float2 *v)
 
 __device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// 8-byte global load the compiler does not track (the caller counts vmcnt by hand)
+__device__ __forceinline__ v2f asm_load8(const float *p, int imm)
+{
+    v2f r;
+    asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(r) : "v"(p), "n"(imm) : "memory");
+    return r;
+}
+
 // One Stockham stage on the PPL register values of this lane.
 //   butterfly j = l + LPF*u reads in[j + t*M/R], twiddles by W^(k t), k = j % NS,
 //   and writes out[(j/NS)*NS*R + k + t*NS].
-template <int R, int NS, int M, int LPF, bool LOAD, bool STORE>
-__device__ __forceinline__ void stockham_stage(float2 *v, float2 *fb, const float2 *twm, int l)
+// `tw` is this stage's own table, tw[(t-1)*NS + k] = exp(-2 pi i k t / (NS R)): lanes
+// with consecutive k read consecutive entries (no LDS bank conflicts).
+template <int R, int NS, int M, int LPF, bool LOAD, bool STORE, bool POWERS = false>
+__device__ __forceinline__ void stockham_stage(float2 *v, float2 *fb, const float2 *tw, int l)
 {
     constexpr int PPL = M / LPF;
     constexpr int NB = PPL / R;          // butterflies per lane
@@ -168,8 +181,18 @@ __device__ __forceinline__ void stockham_stage(float2 *v, float2 *fb, const floa
         float2 *b = v + u * R;
         if (NS > 1) {
             const int k = j % NS;
+            if (POWERS) {            // table holds W^k only; W^(k t) by repeated multiplication
+                const float2 w1 = tw[k];
+                float2 w = w1;
 #pragma unroll
-            for (int t = 1; t < R; t++) b[t] = cmul(b[t], twm[k * t * (M / (NS * R))]);
+                for (int t = 1; t < R; t++) {
+                    b[t] = cmul(b[t], w);
+                    if (t + 1 < R) w = cmul(w, w1);
+                }
+            } else {
+#pragma unroll
+                for (int t = 1; t < R; t++) b[t] = cmul(b[t], tw[(t - 1) * NS + k]);
+            }
         }
         dft<R>(b);
     }
@@ -185,11 +208,11 @@ __device__ __forceinline__ void stockham_stage(float2 *v, float2 *fb, const floa
     }
 }
 
-template <int NFFT, int LPF, int R1, int R2, int R3>
-__global__ __launch_bounds__(256) void spec_fast_kernel(
+template <int NFFT, int LPF, int R1, int R2, int R3, int WAVES, bool DB>
+__global__ __launch_bounds__(64 * WAVES) void spec_fast_kernel(
     const float *__restrict__ x, long long x_pitch, long long n_valid, long long frames_out,
     long long out_pitch, int hop, float scale, const float *__restrict__ tables, float *__restrict__ out,
-    float *__restrict__ db_out, int frames_per_wave)
+    float *__restrict__ db_out, int frames_per_wave, int flags)
 {
     constexpr int M = NFFT / 2;
     constexpr int PPL = M / LPF;
@@ -198,53 +221,261 @@ __global__ __launch_bounds__(256) void spec_fast_kernel(
     constexpr int MP = M + M / 16;           // padded frame buffer
     static_assert(R1 * R2 * R3 == M, "radices must multiply to M");
     static_assert(PPL % R1 == 0 && PPL % R2 == 0 && PPL % R3 == 0, "radix must divide points per lane");
-    __shared__ float2 smem[M + (M / 2 + 1) + 4 * G * MP];
-    float2 *twm = smem;                      // exp(-2 pi i m / M)
-    float2 *twn = smem + M;                  // exp(-2 pi i k / NFFT), k <= M/2
+    constexpr int NW = WAVES;                // waves per workgroup
+    constexpr int TW2 = (R2 - 1) * R1;       // stage-2 twiddles [t-1][k], k < R1
+    constexpr int TW3 = R1 * R2;             // stage-3 twiddles W_M^k, k < R1*R2 (powers on the fly)
+    constexpr int TWN = M / 2 + 1;           // split step: exp(-2 pi i k / NFFT)
+    constexpr int NTAB = TW2 + TW3 + TWN + M;   // + window as M float2
+    __shared__ float2 smem[NTAB + NW * G * MP];
+    const float2 *tw2 = smem;
+    const float2 *tw3 = smem + TW2;
+    const float2 *twn = smem + TW2 + TW3;
+    const float2 *win = smem + TW2 + TW3 + TWN;      // (w[2n], w[2n+1])
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
     const int g = lane / LPF, l = lane % LPF;
-    float2 *fb = smem + M + (M / 2 + 1) + (wave * G + g) * MP;
+    float2 *fb = smem + NTAB + (wave * G + g) * MP;
 
-    {   // tables: [window NFFT floats][twm M float2][twn M/2+1 float2]
-        const float2 *src = reinterpret_cast<const float2 *>(tables + NFFT);
-        for (int i = tid; i < M + M / 2 + 1; i += 256) smem[i] = src[i];
-    }
-    // Hann window for this lane's samples: n = j + t*M/R1, j = l + LPF*u
-    float2 win[PPL];
-    {
-        const float2 *w2 = reinterpret_cast<const float2 *>(tables);
-#pragma unroll
-        for (int u = 0; u < PPL / R1; u++)
-#pragma unroll
-            for (int t = 0; t < R1; t++) win[u * R1 + t] = w2[l + LPF * u + t * (M / R1)];
+    {   // device tables are stored in exactly this order
+        const float2 *src = reinterpret_cast<const float2 *>(tables);
+        for (int i = tid; i < NTAB; i += 64 * NW) smem[i] = src[i];
     }
     __syncthreads();
 
     const long long ch = blockIdx.y;
     const float *xc = x + ch * x_pitch;
-    const long long first = ((long long)blockIdx.x * 4 + wave) * (long long)frames_per_wave * G;
+    float *oc = out + ch * out_pitch;
+    float *dc = DB ? db_out + ch * out_pitch : nullptr;
+    // first frame of this wave; wave-uniform (scalar) when a frame takes the whole wave
+    const long long first = ((long long)blockIdx.x * NW + wave) * (long long)frames_per_wave * G;
 
-    for (int it = 0; it < frames_per_wave; it++) {
-        const long long frame = first + (long long)it * G + g;
-        if (frame >= frames_out) continue;               // uniform per lane group
-        const long long obase = ch * out_pitch + frame * (long long)F;
-        if (frame >= n_valid) {                          // zero tail
-            for (int f = l; f < F; f += LPF) {
-                out[obase + f] = 0.f;
-                if (db_out) db_out[obase + f] = -INFINITY;
-            }
-            continue;
-        }
-        const float *seg = xc + frame * (long long)hop;
-        float2 v[PPL];
-        float s = 0.f;
+    // Raw samples of one frame: the lane keeps z[n], n = l + LPF*u + t*M/R1, at [u*R1 + t].
+    // The loads are inline asm so that the wait for them can be counted by hand: the
+    // next frame is fetched right after stage 3 (its registers are free until the next
+    // stage 1), i.e. BEFORE this frame's stores, and `s_waitcnt vmcnt(NST)` at the top
+    // of the next frame then retires the loads while the NST younger stores stay in
+    // flight.  (hipcc would wait vmcnt(0) here, i.e. for every store acknowledgement.)
+    v2f raw[PPL];
+    auto fetch = [&](long long frame) {
+        const float *seg = xc + frame * (long long)hop + 2 * l;
 #pragma unroll
         for (int u = 0; u < PPL / R1; u++)
 #pragma unroll
             for (int t = 0; t < R1; t++) {
+                constexpr int CH = 512;                        // float2 per 4096-byte window
+                const int n = LPF * u + t * (M / R1);          // compile-time after unrolling
+                raw[u * R1 + t] = asm_load8(seg + 2 * (n / CH) * CH, (n % CH) * 8);
+            }
+    };
+    // stores behind a prefetch in the steady-state loop; one less than issued, so the wait
+    // stays sufficient even if the compiler ever merged two of them
+    constexpr int NST0 = (DB ? 2 : 1) * (PPL + 1) - 1;
+    constexpr int NST = NST0 > 63 ? 63 : NST0;        // vmcnt is a 6-bit field
+
+    const long long last_valid = n_valid > 0 ? n_valid - 1 : 0;
+
+    // One frame per lane group.  `keep` masks the stores of lane groups whose frame is not
+    // valid (only in the one mixed iteration of a wave).  With PF the next frame is
+    // prefetched; the steady-state body has no divergent branch around its stores.
+    auto body = [&](long long frame, bool keep, auto full, auto pf) {
+        constexpr bool FULL = decltype(full)::value;
+        constexpr bool PF = decltype(pf)::value;
+        float *o = oc + frame * (long long)F;
+        float *od = DB ? dc + frame * (long long)F : nullptr;
+        float2 v[PPL];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < PPL; i++) {
+            asm volatile("" : "+v"(raw[i]));              // not before the counted wait
+            v[i] = make_float2(raw[i].x, raw[i].y);
+            s += v[i].x + v[i].y;
+        }
+#pragma unroll
+        for (int d = LPF / 2; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        const float mean = s * (1.0f / (float)NFFT);
+#pragma unroll
+        for (int u = 0; u < PPL / R1; u++)
+#pragma unroll
+            for (int t = 0; t < R1; t++) {
+                const float2 w = win[l + LPF * u + t * (M / R1)];
+                float2 &e = v[u * R1 + t];
+                e = make_float2((e.x - mean) * w.x, (e.y - mean) * w.y);
+            }
+        stockham_stage<R1, 1, M, LPF, false, true>(v, fb, tw2, l);
+        stockham_stage<R2, R1, M, LPF, true, true>(v, fb, tw2, l);
+        stockham_stage<R3, R1 * R2, M, LPF, true, true, true>(v, fb, tw3, l);
+        if (PF) {
+            const long long nf = frame + G;
+            fetch(nf < last_valid ? nf : last_valid);
+        }
+        // split step: X[k] = E + W^k O, X[M-k] = conj(E - W^k O)
+        float pk_last = 0.f;
+#pragma unroll
+        for (int q = 0; q < PPL / 2; q++) {
+            const int k = l + LPF * q;
+            const float2 zk = fb[pad16(k)];
+            const float2 zm = fb[pad16((M - k) & (M - 1))];
+            const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+            const float2 od2 = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
+            const float2 t = cmul(od2, twn[k]);
+            const float2 a = cadd(e, t), b = csub(e, t);
+            float pk = 2.f * scale * (a.x * a.x + a.y * a.y);
+            float pm = 2.f * scale * (b.x * b.x + b.y * b.y);
+            if (q == 0) {
+                // bin 0 pairs with itself: DC = re + im, Nyquist = re - im, not doubled
+                const float dc0 = zk.x + zk.y, ny = zk.x - zk.y;
+                pk = (l == 0) ? dc0 * dc0 * scale : pk;
+                pm = (l == 0) ? ny * ny * scale : pm;
+            }
+            if (FULL || keep) {
+                o[k] = pk;
+                o[M - k] = pm;
+                if (DB) { od[k] = to_db(pk); od[M - k] = to_db(pm); }
+            }
+            pk_last = pk;
+        }
+        {   // bin M/2 pairs with itself (lane 0); the other lanes repeat their last store so
+            // that the instruction is unconditional
+            const float2 z = fb[pad16(M / 2)];
+            const float ph = 2.f * scale * (z.x * z.x + z.y * z.y);
+            const int kk = (l == 0) ? M / 2 : l + LPF * (PPL / 2 - 1);
+            const float pv = (l == 0) ? ph : pk_last;
+            if (FULL || keep) {
+                o[kk] = pv;
+                if (DB) od[kk] = to_db(pv);
+            }
+        }
+    };
+
+    // iterations in which every lane group of the wave has a valid frame
+    long long n_main = (n_valid - first) / G;
+    if (n_main < 0) n_main = 0;
+    if (n_main > frames_per_wave) n_main = frames_per_wave;
+    {
+        const long long f0 = first + g;
+        fetch(f0 < last_valid ? f0 : last_valid);
+    }
+    if (n_main > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        body(first + g, true, std::true_type(), std::true_type());
+    }
+    for (int it = 1; it < (int)n_main; it++) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+        body(first + (long long)it * G + g, true, std::true_type(), std::true_type());
+    }
+    // retire the last prefetch before anything else may reuse its registers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < PPL; i++) asm volatile("" : "+v"(raw[i]));
+    // at most one mixed iteration, then the zero tail (bufferedspectrogram.py:59)
+    for (int it = (int)n_main; it < frames_per_wave; it++) {
+        const long long frame = first + (long long)it * G + g;
+        if (first + (long long)it * G >= frames_out) break;
+        if (G > 1 && it == (int)n_main && first + (long long)it * G < n_valid)
+            body(frame < last_valid ? frame : last_valid, frame < n_valid, std::false_type(),
+                 std::false_type());
+        if (frame >= n_valid && frame < frames_out) {
+            float *o = oc + frame * (long long)F;
+            for (int f = l; f < F; f += LPF) {
+                o[f] = 0.f;
+                if (DB) dc[frame * (long long)F + f] = -INFINITY;
+            }
+        }
+    }
+}
+
+template <> __device__ __forceinline__ void dft<32>(float2 *v)
+{
+    // radix-2 decimation in time over two 16-point transforms; W32^k = exp(-i pi k / 16)
+    const float c[16] = {1.f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                         0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f,
+                         0.19509032201612826785f, 0.f, -0.19509032201612826785f, -0.38268343236508977173f,
+                         -0.55557023301960222474f, -0.70710678118654752440f, -0.83146961230254523708f,
+                         -0.92387953251128675613f, -0.98078528040323044913f};
+    const float sn[16] = {0.f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
+                          0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f,
+                          0.98078528040323044913f, 1.f, 0.98078528040323044913f, 0.92387953251128675613f,
+                          0.83146961230254523708f, 0.70710678118654752440f, 0.55557023301960222474f,
+                          0.38268343236508977173f, 0.19509032201612826785f};
+    float2 e[16], o[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { e[k] = v[2 * k]; o[k] = v[2 * k + 1]; }
+    dft<16>(e); dft<16>(o);
+#pragma unroll
+    for (int k = 1; k < 16; k++) {
+        if (k == 8) o[k] = mul_negi(o[k]);
+        else o[k] = cmul(o[k], make_float2(c[k], -sn[k]));
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { v[k] = cadd(e[k], o[k]); v[k + 16] = csub(e[k], o[k]); }
+}
+
+// ---- two-stage fast path (M = R1 x R2): one LDS exchange per frame -------------------
+// LPF lanes own a frame, PPL = M/LPF = max(R1, R2) points per lane.  Stage 1 (radix R1)
+// takes its inputs straight from HBM, stage 2 (radix R2) leaves lane l with the bins
+// k = l + LPF*m in natural order, and the split step fetches the partner bin M-k from
+// lane LPF-l with ds_bpermute (no third trip through LDS memory).
+template <int NFFT, int LPF, int R1, int R2, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void spec2_kernel(
+    const float *__restrict__ x, long long x_pitch, long long n_valid, long long frames_out,
+    long long out_pitch, int hop, float scale, const float *__restrict__ tables, float *__restrict__ out,
+    float *__restrict__ db_out, int frames_per_wave, int flags)
+{
+    constexpr int M = NFFT / 2;
+    constexpr int PPL = M / LPF;
+    constexpr int G = 64 / LPF;
+    constexpr int F = M + 1;
+    constexpr int MP = M + M / 16;
+    constexpr int NB1 = PPL / R1, NB2 = PPL / R2;
+    static_assert(R1 * R2 == M, "radices must multiply to M");
+    static_assert(PPL % R1 == 0 && PPL % R2 == 0, "radix must divide points per lane");
+    constexpr int TW2 = (R2 - 1) * R1;       // stage-2 twiddles [t-1][k], k < R1
+    constexpr int TWN = M / 2 + 1;
+    constexpr int NTAB = TW2 + TWN + M;      // + window as M float2
+    __shared__ float2 smem[NTAB + WAVES * G * MP];
+    const float2 *tw2 = smem;
+    const float2 *twn = smem + TW2;
+    const float2 *win = smem + TW2 + TWN;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int g = lane / LPF, l = lane % LPF;
+    float2 *fb = smem + NTAB + (wave * G + g) * MP;
+    {
+        const float2 *src = reinterpret_cast<const float2 *>(tables);
+        for (int i = tid; i < NTAB; i += 64 * WAVES) smem[i] = src[i];
+    }
+    __syncthreads();
+
+    const long long ch = blockIdx.y;
+    const float *xc = x + ch * x_pitch;
+    // each lane group walks its own run of consecutive frames
+    const long long first = (((long long)blockIdx.x * WAVES + wave) * G + g) * (long long)frames_per_wave;
+    const int partner = g * LPF + ((LPF - l) & (LPF - 1));
+
+    for (int it = 0; it < frames_per_wave; it++) {
+        const long long frame = first + it;
+        const bool active = frame < frames_out;
+        const bool valid = frame < n_valid;
+        const long long obase = ch * out_pitch + frame * (long long)F;
+        if (active && !valid) {                              // zero tail
+            for (int f = l; f < F; f += LPF) {
+                out[obase + f] = 0.f;
+                if (db_out) db_out[obase + f] = -INFINITY;
+            }
+        }
+        // lanes without a frame still take part in the cross-lane steps below
+        const float *seg = xc + (valid ? frame : 0) * (long long)hop;
+        float2 v[PPL];
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < NB1; u++)
+#pragma unroll
+            for (int t = 0; t < R1; t++) {
                 const int n = l + LPF * u + t * (M / R1);
-                f2u r = *reinterpret_cast<const f2u *>(seg + 2 * n);
+                f2u r;
+                if (!valid) { r.x = 0.f; r.y = 0.f; }
+                else r = *reinterpret_cast<const f2u *>(seg + 2 * n);
                 v[u * R1 + t] = make_float2(r.x, r.y);
                 s += r.x + r.y;
             }
@@ -252,21 +483,34 @@ __global__ __launch_bounds__(256) void spec_fast_kernel(
         for (int d = LPF / 2; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
         const float mean = s * (1.0f / (float)NFFT);
 #pragma unroll
-        for (int i = 0; i < PPL; i++)
-            v[i] = make_float2((v[i].x - mean) * win[i].x, (v[i].y - mean) * win[i].y);
-
-        stockham_stage<R1, 1, M, LPF, false, true>(v, fb, twm, l);
-        stockham_stage<R2, R1, M, LPF, true, true>(v, fb, twm, l);
-        stockham_stage<R3, R1 * R2, M, LPF, true, true>(v, fb, twm, l);
-
-        // split step: X[k] = E + W^k O, X[M-k] = conj(E - W^k O)
+        for (int u = 0; u < NB1; u++)
 #pragma unroll
-        for (int q = 0; q < PPL / 2; q++) {
-            const int k = l + LPF * q;
-            const float2 zk = fb[pad16(k)];
-            const float2 zm = fb[pad16((M - k) & (M - 1))];
+            for (int t = 0; t < R1; t++) {
+                const float2 w = win[l + LPF * u + t * (M / R1)];
+                float2 &e = v[u * R1 + t];
+                e = make_float2((e.x - mean) * w.x, (e.y - mean) * w.y);
+            }
+        stockham_stage<R1, 1, M, LPF, false, true>(v, fb, tw2, l);
+        stockham_stage<R2, R1, M, LPF, true, false>(v, fb, tw2, l);
+        // now v[u*R2 + t] = Z[k], k = (l + LPF*u) + t*R1 = l + LPF*m with m = u + NB2*t
+        // split step for m < PPL/2 (k < M/2): partner bin M-k sits in lane LPF-l at
+        // m' = PPL-1-m (lane 0: in itself at m' = PPL-m)
+#pragma unroll
+        for (int m = 0; m < PPL / 2; m++) {
+            const int k = l + LPF * m;
+            const float2 zk = v[(m % NB2) * R2 + m / NB2];
+            const int mp = PPL - 1 - m;
+            const float2 zsrc = v[(mp % NB2) * R2 + mp / NB2];
+            float2 zm;
+            zm.x = __shfl(zsrc.x, partner, 64);
+            zm.y = __shfl(zsrc.y, partner, 64);
+            if (m > 0) {
+                const int m0 = PPL - m;                      // lane 0 pairs inside itself
+                const float2 z0 = v[(m0 % NB2) * R2 + m0 / NB2];
+                if (l == 0) zm = z0;
+            }
             float pk, pm;
-            if (k == 0) {
+            if (m == 0 && l == 0) {
                 const float a = zk.x + zk.y, b = zk.x - zk.y;    // DC and Nyquist, not doubled
                 pk = a * a * scale;
                 pm = b * b * scale;
@@ -278,12 +522,15 @@ __global__ __launch_bounds__(256) void spec_fast_kernel(
                 pk = 2.f * scale * (a.x * a.x + a.y * a.y);
                 pm = 2.f * scale * (b.x * b.x + b.y * b.y);
             }
-            out[obase + k] = pk;
-            out[obase + M - k] = pm;
-            if (db_out) { db_out[obase + k] = to_db(pk); db_out[obase + M - k] = to_db(pm); }
+            if (valid) {
+                out[obase + k] = pk;
+                out[obase + M - k] = pm;
+                if (db_out) { db_out[obase + k] = to_db(pk); db_out[obase + M - k] = to_db(pm); }
+            }
         }
-        if (l == 0) {                                      // k = M/2 pairs with itself
-            const float2 z = fb[pad16(M / 2)];
+        if (l == 0 && valid) {                               // k = M/2 pairs with itself
+            constexpr int mh = PPL / 2;
+            const float2 z = v[(mh % NB2) * R2 + mh / NB2];
             const float p = 2.f * scale * (z.x * z.x + z.y * z.y);
             out[obase + M / 2] = p;
             if (db_out) db_out[obase + M / 2] = to_db(p);
@@ -291,40 +538,65 @@ __global__ __launch_bounds__(256) void spec_fast_kernel(
     }
 }
 
-template <int NFFT, int LPF, int R1, int R2, int R3>
+// Consecutive frames one wave (lane group) walks: long runs amortise the table load
+// and keep the 50 % overlap in cache, short runs keep small inputs spread over the chip.
+int frames_per_wave(const hipdsp_ctx *ctx, long long channels, long long frames_out, int G)
+{
+    if (ctx->spec_fpw > 0) return ctx->spec_fpw;
+    long long groups = (long long)ctx->n_cus * 32 * G;        // lane groups we want busy
+    long long f = channels * frames_out / groups;
+    if (f < 4) f = 4;
+    if (f > 64) f = 64;
+    return (int)f;
+}
+
+template <int NFFT, int LPF, int R1, int R2, int R3, int WAVES>
 int launch_fast(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long channels, long long n_valid,
                 long long frames_out, long long out_pitch, int hop, float scale, const float *tables,
                 float *out, float *db_out)
 {
     constexpr int G = 64 / LPF;
-    const int fpw = 16;                                  // frames per wave (x G side by side)
-    long long per_block = 4LL * fpw * G;
+    const int fpw = frames_per_wave(ctx, channels, frames_out, G);
+    long long per_block = (long long)WAVES * fpw * G;
     long long bx = (frames_out + per_block - 1) / per_block;
-    hipLaunchKernelGGL((spec_fast_kernel<NFFT, LPF, R1, R2, R3>), dim3((unsigned)bx, (unsigned)channels),
-                       dim3(256), 0, ctx->stream, x, x_pitch, n_valid, frames_out, out_pitch, hop, scale,
-                       tables, out, db_out, fpw);
+    if (db_out)
+        hipLaunchKernelGGL((spec_fast_kernel<NFFT, LPF, R1, R2, R3, WAVES, true>),
+                           dim3((unsigned)bx, (unsigned)channels), dim3(64 * WAVES), 0, ctx->stream, x, x_pitch,
+                           n_valid, frames_out, out_pitch, hop, scale, tables, out, db_out, fpw, ctx->spec_flags);
+    else
+        hipLaunchKernelGGL((spec_fast_kernel<NFFT, LPF, R1, R2, R3, WAVES, false>),
+                           dim3((unsigned)bx, (unsigned)channels), dim3(64 * WAVES), 0, ctx->stream, x, x_pitch,
+                           n_valid, frames_out, out_pitch, hop, scale, tables, out, db_out, fpw, ctx->spec_flags);
     return hd_launch_status("spec_fast_kernel");
 }
 
-// window | twm | twn for one nfft, computed in float64 on the host
-int fft_tables(hipdsp_ctx *ctx, int nfft, const float **dev)
+// tw2 | tw3 | twn | window for one nfft, computed in float64 on the host in the order the
+// kernel keeps them in LDS
+int fft_tables(hipdsp_ctx *ctx, int nfft, int R1, int R2, int R3, const float **dev)
 {
     int lg = 0;
     while ((1 << lg) < nfft) lg++;
     if (!ctx->fft_tables[lg]) {
         const int M = nfft / 2;
-        size_t n = (size_t)nfft + 2 * (size_t)M + 2 * (size_t)(M / 2 + 1);
+        const int TW2 = (R2 - 1) * R1, TW3 = R1 * R2, TWN = M / 2 + 1;
+        size_t n = 2 * (size_t)(TW2 + TW3 + TWN + M);
         float *h = new float[n];
-        for (int i = 0; i < nfft; i++) h[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)i / (double)nfft));
-        float *p = h + nfft;
-        for (int m = 0; m < M; m++) {
-            double a = -2.0 * M_PI * (double)m / (double)M;
+        float *p = h;
+        for (int t = 1; t < R2; t++)
+            for (int k = 0; k < R1; k++) {
+                double a = -2.0 * M_PI * (double)(k * t) / (double)(R1 * R2);
+                *p++ = (float)cos(a); *p++ = (float)sin(a);
+            }
+        for (int k = 0; k < R1 * R2; k++) {
+            double a = -2.0 * M_PI * (double)k / (double)M;
             *p++ = (float)cos(a); *p++ = (float)sin(a);
         }
+        (void)R3;
         for (int k = 0; k <= M / 2; k++) {
             double a = -2.0 * M_PI * (double)k / (double)nfft;
             *p++ = (float)cos(a); *p++ = (float)sin(a);
         }
+        for (int i = 0; i < nfft; i++) *p++ = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)i / (double)nfft));
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
         if (ctx->stream) (void)hipStreamIsCapturing(ctx->stream, &st);
         if (st != hipStreamCaptureStatusNone) {
@@ -344,6 +616,76 @@ int fft_tables(hipdsp_ctx *ctx, int nfft, const float **dev)
     }
     *dev = (const float *)ctx->fft_tables[lg];
     return HIPDSP_OK;
+}
+
+// tw2 | twn | window for the two-stage kernel
+int fft_tables2(hipdsp_ctx *ctx, int nfft, int R1, int R2, const float **dev)
+{
+    int lg = 0;
+    while ((1 << lg) < nfft) lg++;
+    if (!ctx->fft_tables2[lg]) {
+        const int M = nfft / 2;
+        const int TW2 = (R2 - 1) * R1, TWN = M / 2 + 1;
+        size_t n = 2 * (size_t)(TW2 + TWN + M);
+        float *h = new float[n];
+        float *p = h;
+        for (int t = 1; t < R2; t++)
+            for (int k = 0; k < R1; k++) {
+                double a = -2.0 * M_PI * (double)(k * t) / (double)M;
+                *p++ = (float)cos(a); *p++ = (float)sin(a);
+            }
+        for (int k = 0; k <= M / 2; k++) {
+            double a = -2.0 * M_PI * (double)k / (double)nfft;
+            *p++ = (float)cos(a); *p++ = (float)sin(a);
+        }
+        for (int i = 0; i < nfft; i++) *p++ = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)i / (double)nfft));
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (ctx->stream) (void)hipStreamIsCapturing(ctx->stream, &st);
+        if (st != hipStreamCaptureStatusNone) {
+            delete[] h;
+            hipdsp_set_error("first spectrogram call for nfft %d during stream capture; run it once before", nfft);
+            return HIPDSP_ERR_INVALID;
+        }
+        void *d = nullptr;
+        hipError_t e = hipMalloc(&d, n * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(d, h, n * sizeof(float), hipMemcpyHostToDevice);
+        delete[] h;
+        if (e != hipSuccess) {
+            if (d) (void)hipFree(d);
+            HD_CHECK_HIP(e);
+        }
+        ctx->fft_tables2[lg] = d;
+    }
+    *dev = (const float *)ctx->fft_tables2[lg];
+    return HIPDSP_OK;
+}
+
+template <int NFFT, int LPF, int R1, int R2, int WAVES>
+int run_fast2(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long channels, long long n_valid,
+              long long frames_out, long long out_pitch, int hop, float scale, float *out, float *db_out)
+{
+    const float *tables = nullptr;
+    int rc = fft_tables2(ctx, NFFT, R1, R2, &tables);
+    if (rc != HIPDSP_OK) return rc;
+    constexpr int G = 64 / LPF;
+    const int fpw = frames_per_wave(ctx, channels, frames_out, G);
+    long long per_block = (long long)WAVES * G * fpw;
+    long long bx = (frames_out + per_block - 1) / per_block;
+    hipLaunchKernelGGL((spec2_kernel<NFFT, LPF, R1, R2, WAVES>), dim3((unsigned)bx, (unsigned)channels),
+                       dim3(64 * WAVES), 0, ctx->stream, x, x_pitch, n_valid, frames_out, out_pitch, hop, scale,
+                       tables, out, db_out, fpw, ctx->spec_flags);
+    return hd_launch_status("spec2_kernel");
+}
+
+template <int NFFT, int LPF, int R1, int R2, int R3, int WAVES>
+int run_fast(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long channels, long long n_valid,
+             long long frames_out, long long out_pitch, int hop, float scale, float *out, float *db_out)
+{
+    const float *tables = nullptr;
+    int rc = fft_tables(ctx, NFFT, R1, R2, R3, &tables);
+    if (rc != HIPDSP_OK) return rc;
+    return launch_fast<NFFT, LPF, R1, R2, R3, WAVES>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch,
+                                                     hop, scale, tables, out, db_out);
 }
 
 }  // namespace
@@ -382,15 +724,23 @@ extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pit
     }
     float scale = (float)(1.0 / (fs * wss));
     if (!ctx->force_generic_fft && nfft >= 256 && nfft <= 4096) {
-        const float *tables = nullptr;
-        int rc = fft_tables(ctx, nfft, &tables);
-        if (rc != HIPDSP_OK) return rc;
+        // spec_kernel: 0 = default choice per size, 2 = two-stage kernel, 3 = three-stage kernel
+        const int want = ctx->spec_kernel;
         switch (nfft) {
-        case 256:  return launch_fast<256, 16, 8, 4, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, tables, out, db_out);
-        case 512:  return launch_fast<512, 32, 8, 8, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, tables, out, db_out);
-        case 1024: return launch_fast<1024, 64, 8, 8, 8>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, tables, out, db_out);
-        case 2048: return launch_fast<2048, 64, 16, 16, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, tables, out, db_out);
-        case 4096: return launch_fast<4096, 64, 16, 16, 8>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, tables, out, db_out);
+        case 256:
+            if (want == 3) return run_fast<256, 16, 8, 4, 4, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+            return run_fast2<256, 8, 16, 8, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+        case 512:
+            if (want == 3) return run_fast<512, 32, 8, 8, 4, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+            return run_fast2<512, 16, 16, 16, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+        case 1024:
+            if (want == 2) return run_fast2<1024, 16, 32, 16, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+            return run_fast<1024, 64, 8, 8, 8, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+        case 2048:
+            if (want == 2) return run_fast2<2048, 32, 32, 32, 8>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+            return run_fast<2048, 64, 16, 16, 4, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+        case 4096:
+            return run_fast<4096, 64, 16, 16, 8, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
         }
     }
     size_t lds = sizeof(float2) * 2 * (size_t)nfft;

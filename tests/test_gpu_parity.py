@@ -161,14 +161,19 @@ def test_spectrogram_fast_and_generic_vs_oracle(oracle, nfft, hop):
     nd = (T + hop - 1)//hop
     want = np.zeros((nd, 3, nfft//2 + 1))
     oracle.spectrogram_process(x.astype(np.float64), want, rate, nfft, hop)
-    got = gh.gpu_spectrogram(x, rate, nfft, hop, nd)
+    results = [gh.gpu_spectrogram(x, rate, nfft, hop, nd)]
     c = gh.ctx()
-    c.set_option('force_generic_fft', 1)
     try:
-        gen = gh.gpu_spectrogram(x, rate, nfft, hop, nd)
+        for kern in (2, 3):               # two-stage and three-stage register/LDS kernels
+            c.set_option('spec_kernel', kern)
+            results.append(gh.gpu_spectrogram(x, rate, nfft, hop, nd))
+        c.set_option('spec_kernel', 0)
+        c.set_option('force_generic_fft', 1)
+        results.append(gh.gpu_spectrogram(x, rate, nfft, hop, nd))
     finally:
         c.set_option('force_generic_fft', 0)
-    for res in (got, gen):
+        c.set_option('spec_kernel', 0)
+    for res in results:
         for ch in range(3):
             for j in range(nd):
                 if np.max(np.abs(want[j, ch])) == 0:
