@@ -28,7 +28,22 @@ if not os.path.exists(LIB_PATH):
         '(`make -C audian_amd/csrc` or `python -c "import __graft_entry__ as g; g.build()"`). '
         'audian_amd has no CPU fallback.')
 
+# PyTorch wheels bundle their own libamdhip64/libhsa-runtime64 (same SONAME as ROCm's).
+# Two HIP runtimes in one process cannot both own the GPU, so when torch is going to be
+# used in this process (multi-GPU runs: torch.distributed/RCCL) it has to be loaded
+# FIRST; libhip_dsp.so then binds to the runtime that is already there.
+import sys as _sys
+if 'torch' not in _sys.modules and (int(os.environ.get('WORLD_SIZE', '1')) > 1 or
+                                    os.environ.get('AUDIAN_AMD_TORCH') == '1'):
+    import torch as _torch  # noqa: F401
+
 lib = ctypes.CDLL(LIB_PATH)
+
+
+def hip_runtime_path():
+    """Which libamdhip64 this process resolved (diagnostics for the note above)."""
+    with open('/proc/self/maps') as f:
+        return sorted({ln.split()[-1] for ln in f if 'libamdhip64' in ln})
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64

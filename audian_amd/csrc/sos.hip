@@ -469,23 +469,36 @@ int fill_plan(SosPlanDev *p, const double *sos, int S)
     return HIPDSP_OK;
 }
 
+// Choose the number of time segments per channel.  One wave per (channel, segment);
+// a segment costs its own length plus the warm-up it re-reads, and waves run in rounds
+// of `slots` resident waves: minimise rounds * (segment + warm-up).
 void plan_segments(const hipdsp_ctx *ctx, long long N, long long channels, long long warm,
                    long long *seg_len, int *n_seg)
 {
-    long long target = (long long)ctx->n_cus * 16;       // resident waves we aim for
-    long long want = (target + channels - 1) / channels;
-    if (ctx->max_segments > 0 && want > ctx->max_segments) want = ctx->max_segments;
-    if (want < 1) want = 1;
-    long long len = (N + want - 1) / want;
-    long long min_len = 4LL * TILE;
-    if (warm >= (1LL << 40)) min_len = N;                // non-decaying filter: one segment
-    else if (8 * warm > min_len) min_len = 8 * warm;     // warm-up re-reads <= 12.5 %
-    if (len < min_len) len = min_len;
-    len = (len + TILE - 1) / TILE * TILE;
-    long long n = (N + len - 1) / len;
-    if (n < 1) n = 1;
-    *seg_len = len;
-    *n_seg = (int)n;
+    const long long slots = (long long)ctx->n_cus * 16;
+    long long max_seg = (N + TILE - 1) / TILE;            // at least one tile per segment
+    if (warm >= (1LL << 40)) max_seg = 1;                 // non-decaying filter: never segment
+    if (ctx->max_segments > 0 && max_seg > ctx->max_segments) max_seg = ctx->max_segments;
+    if (max_seg > 65536) max_seg = 65536;
+    if (max_seg < 1) max_seg = 1;
+    long long best_n = 1, best_len = (N + TILE - 1) / TILE * TILE;
+    double best_cost = -1.0;
+    // candidates: segment counts that fill whole rounds, and powers of two below one round
+    for (long long rounds = 0; rounds <= 64; rounds++) {
+        for (int half = 0; half < (rounds == 0 ? 16 : 1); half++) {
+            long long n = rounds == 0 ? ((slots / channels) >> half) : rounds * slots / channels;
+            if (n < 1) n = 1;
+            if (n > max_seg) n = max_seg;
+            long long len = ((N + n - 1) / n + TILE - 1) / TILE * TILE;
+            if (len < TILE) len = TILE;
+            long long cnt = (N + len - 1) / len;
+            long long r = (channels * cnt + slots - 1) / slots;
+            double cost = (double)r * (double)(len + (cnt > 1 ? warm : 0));
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_n = cnt; best_len = len; }
+        }
+    }
+    *seg_len = best_len;
+    *n_seg = (int)best_n;
 }
 
 template <int MODE>

@@ -50,6 +50,11 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-seconds', type=float, default=60.0)
     ap.add_argument('--max-segments', type=int, default=0)
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="N>1 collective backend; 'gloo' (host staging) only to rehearse the "
+                         "multi-rank path on a one-GPU box")
+    ap.add_argument('--same-device', action='store_true',
+                    help='rehearsal: every rank uses GPU 0 (needs --backend gloo)')
     return ap.parse_args()
 
 
@@ -127,16 +132,23 @@ def main():
                      '(one rank per GPU)')
         args.gpus = world
 
-    from audian_amd import hipdsp
-    from audian_amd.design import butter_sos
-
     dist = None
     torch = None
     if world > 1:
-        import torch
+        import torch            # before libhip_dsp: one HIP runtime per process (_lib.py)
         import torch.distributed as dist
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+
+    if world > 1:
+        from audian_amd.dist import allgather_tiles, tile_frames as n_tile_frames
+        if args.same_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group('gloo')
         stream = torch.cuda.current_stream().cuda_stream
     else:
         stream = None
@@ -159,8 +171,7 @@ def main():
     if world > 1:
         tspec = torch.empty((C, nd, F), dtype=torch.float32, device='cuda')
         ds = hipdsp.DeviceArray(ctx, (C, nd, F), np.float32, ptr=tspec.data_ptr(), owner=tspec)
-        tile_frames = min(nd, int(math.ceil(args.tile_seconds*args.rate/args.hop)))
-        gathered = torch.empty((world*C, tile_frames, F), dtype=torch.float32, device='cuda')
+        tile_frames = n_tile_frames(nd, args.rate, args.hop, args.tile_seconds)
     else:
         ds = hipdsp.DeviceArray(ctx, (C, nd, F), np.float32)
     ctx.reserve(4*C*((T + 2*edge + 3)//4*4))
@@ -189,7 +200,11 @@ def main():
             ctx.record(ev[3])
         if world > 1:
             # merged spectrogram tile of the visible window on every rank (RCCL over xGMI)
-            dist.all_gather_into_tensor(gathered, tspec[:, :tile_frames, :].contiguous())
+            tile = tspec[:, :tile_frames, :]
+            if args.backend == 'gloo':
+                tile = tile.cpu()
+            merged = allgather_tiles(tile, world*C)
+            assert merged.shape[0] == world*C
         if ev:
             ctx.record(ev[4])
 
