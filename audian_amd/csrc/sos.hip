@@ -191,6 +191,8 @@ __global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *__restri
 
     for (long long tile = start; tile < hi; tile += TILE) {
         // ---- HBM -> LDS (coalesced 16 B per lane), LDS -> registers (row per lane)
+        // (A register prefetch of the next tile with a hand-counted vmcnt was measured and
+        // bought nothing: the kernel already runs at the device's read+write copy rate.)
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             long long p = tile + 256 * k + 4 * lane;
@@ -475,7 +477,7 @@ int fill_plan(SosPlanDev *p, const double *sos, int S)
 void plan_segments(const hipdsp_ctx *ctx, long long N, long long channels, long long warm,
                    long long *seg_len, int *n_seg)
 {
-    const long long slots = (long long)ctx->n_cus * 16;
+    const long long slots = (long long)ctx->n_cus * (ctx->sos_waves_per_cu > 0 ? ctx->sos_waves_per_cu : 16);
     long long max_seg = (N + TILE - 1) / TILE;            // at least one tile per segment
     if (warm >= (1LL << 40)) max_seg = 1;                 // non-decaying filter: never segment
     if (ctx->max_segments > 0 && max_seg > ctx->max_segments) max_seg = ctx->max_segments;

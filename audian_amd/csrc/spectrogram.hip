@@ -209,7 +209,7 @@ __device__ __forceinline__ void stockham_stage(float2 *v, float2 *fb, const floa
 }
 
 template <int NFFT, int LPF, int R1, int R2, int R3, int WAVES, bool DB>
-__global__ __launch_bounds__(64 * WAVES) void spec_fast_kernel(
+__global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? 3 : 1) * WAVES / 4) void spec_fast_kernel(
     const float *__restrict__ x, long long x_pitch, long long n_valid, long long frames_out,
     long long out_pitch, int hop, float scale, const float *__restrict__ tables, float *__restrict__ out,
     float *__restrict__ db_out, int frames_per_wave, int flags)
@@ -274,6 +274,7 @@ __global__ __launch_bounds__(64 * WAVES) void spec_fast_kernel(
     constexpr int NST = NST0 > 63 ? 63 : NST0;        // vmcnt is a 6-bit field
 
     const long long last_valid = n_valid > 0 ? n_valid - 1 : 0;
+    const int partner = g * LPF + ((LPF - l) & (LPF - 1));
 
     // One frame per lane group.  `keep` masks the stores of lane groups whose frame is not
     // valid (only in the one mixed iteration of a wave).  With PF the next frame is
@@ -304,25 +305,38 @@ __global__ __launch_bounds__(64 * WAVES) void spec_fast_kernel(
             }
         stockham_stage<R1, 1, M, LPF, false, true>(v, fb, tw2, l);
         stockham_stage<R2, R1, M, LPF, true, true>(v, fb, tw2, l);
-        stockham_stage<R3, R1 * R2, M, LPF, true, true, true>(v, fb, tw3, l);
+        stockham_stage<R3, R1 * R2, M, LPF, true, false, true>(v, fb, tw3, l);
         if (PF) {
             const long long nf = frame + G;
             fetch(nf < last_valid ? nf : last_valid);
         }
-        // split step: X[k] = E + W^k O, X[M-k] = conj(E - W^k O)
+        // Now v[u*R3 + t] = Z[k], k = l + LPF*m, m = u + NB3*t.  Split step for m < PPL/2
+        // (k < M/2): X[k] = E + W^k O, X[M-k] = conj(E - W^k O); the partner bin Z[M-k] sits
+        // in lane LPF-l at m' = PPL-1-m (lane 0: in itself at m' = PPL-m) and comes over
+        // with ds_bpermute instead of a third trip through LDS memory.
+        constexpr int NB3 = PPL / R3;
         float pk_last = 0.f;
 #pragma unroll
-        for (int q = 0; q < PPL / 2; q++) {
-            const int k = l + LPF * q;
-            const float2 zk = fb[pad16(k)];
-            const float2 zm = fb[pad16((M - k) & (M - 1))];
+        for (int m = 0; m < PPL / 2; m++) {
+            const int k = l + LPF * m;
+            const float2 zk = v[(m % NB3) * R3 + m / NB3];
+            const int mp = PPL - 1 - m;
+            const float2 zsrc = v[(mp % NB3) * R3 + mp / NB3];
+            float2 zm;
+            zm.x = __shfl(zsrc.x, partner, 64);
+            zm.y = __shfl(zsrc.y, partner, 64);
+            if (m > 0) {
+                const int m0 = PPL - m;
+                const float2 z0 = v[(m0 % NB3) * R3 + m0 / NB3];
+                zm = (l == 0) ? z0 : zm;
+            }
             const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
             const float2 od2 = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
             const float2 t = cmul(od2, twn[k]);
             const float2 a = cadd(e, t), b = csub(e, t);
             float pk = 2.f * scale * (a.x * a.x + a.y * a.y);
             float pm = 2.f * scale * (b.x * b.x + b.y * b.y);
-            if (q == 0) {
+            if (m == 0) {
                 // bin 0 pairs with itself: DC = re + im, Nyquist = re - im, not doubled
                 const float dc0 = zk.x + zk.y, ny = zk.x - zk.y;
                 pk = (l == 0) ? dc0 * dc0 * scale : pk;
@@ -335,9 +349,10 @@ __global__ __launch_bounds__(64 * WAVES) void spec_fast_kernel(
             }
             pk_last = pk;
         }
-        {   // bin M/2 pairs with itself (lane 0); the other lanes repeat their last store so
-            // that the instruction is unconditional
-            const float2 z = fb[pad16(M / 2)];
+        {   // bin M/2 pairs with itself (lane 0, m = PPL/2); the other lanes repeat their
+            // last store so that the instruction is unconditional
+            constexpr int mh = PPL / 2;
+            const float2 z = v[(mh % NB3) * R3 + mh / NB3];
             const float ph = 2.f * scale * (z.x * z.x + z.y * z.y);
             const int kk = (l == 0) ? M / 2 : l + LPF * (PPL / 2 - 1);
             const float pv = (l == 0) ? ph : pk_last;
@@ -728,8 +743,8 @@ extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pit
         const int want = ctx->spec_kernel;
         switch (nfft) {
         case 256:
-            if (want == 3) return run_fast<256, 16, 8, 4, 4, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
-            return run_fast2<256, 8, 16, 8, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+            if (want == 2) return run_fast2<256, 8, 16, 8, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+            return run_fast<256, 16, 8, 4, 4, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
         case 512:
             if (want == 3) return run_fast<512, 32, 8, 8, 4, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
             return run_fast2<512, 16, 16, 16, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);

@@ -26,12 +26,14 @@ def shard_channels(channels, rank, world):
     return c0, c1
 
 
-def allgather_tiles(local_tile, channels, group=None):
+def allgather_tiles(local_tile, channels, group=None, out=None, async_op=False):
     """All-gather per-rank tiles (channels_local, ...) along the channel axis.
 
     `local_tile` is this rank's contiguous torch tensor; `channels` the global channel
     count (so uneven shards can be un-padded).  Returns the merged (channels, ...)
-    tensor on every rank.  One collective; equal shards gather straight into the result.
+    tensor on every rank.  One collective; equal shards gather straight into the result
+    (`out` may be a preallocated result; with `async_op` the call returns
+    `(result, work)` and the caller overlaps compute until `work.wait()`).
     """
     import torch
     import torch.distributed as dist
@@ -43,9 +45,12 @@ def allgather_tiles(local_tile, channels, group=None):
     local_tile = local_tile.contiguous()
     rest = tuple(local_tile.shape[1:])
     if channels % world == 0:
-        out = torch.empty((channels,) + rest, dtype=local_tile.dtype, device=local_tile.device)
-        dist.all_gather_into_tensor(out, local_tile, group=group)
-        return out
+        if out is None:
+            out = torch.empty((channels,) + rest, dtype=local_tile.dtype, device=local_tile.device)
+        work = dist.all_gather_into_tensor(out, local_tile, group=group, async_op=async_op)
+        return (out, work) if async_op else out
+    if async_op or out is not None:
+        raise ValueError('async/preallocated gather needs equal channel shards')
     cmax = -(-channels//world)
     padded = torch.zeros((cmax,) + rest, dtype=local_tile.dtype, device=local_tile.device)
     padded[:c1 - c0] = local_tile

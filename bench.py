@@ -55,6 +55,8 @@ def parse():
                          "multi-rank path on a one-GPU box")
     ap.add_argument('--same-device', action='store_true',
                     help='rehearsal: every rank uses GPU 0 (needs --backend gloo)')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='rehearsal: take the multi-rank code path even with one rank')
     return ap.parse_args()
 
 
@@ -134,22 +136,29 @@ def main():
 
     dist = None
     torch = None
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         import torch            # before libhip_dsp: one HIP runtime per process (_lib.py)
         import torch.distributed as dist
     from audian_amd import hipdsp
     from audian_amd.design import butter_sos
 
-    if world > 1:
+    if multi:
         from audian_amd.dist import allgather_tiles, tile_frames as n_tile_frames
         if args.same_device:
             local_rank = 0
         torch.cuda.set_device(local_rank)
+        if world == 1 and 'MASTER_ADDR' not in os.environ:
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group('gloo')
-        stream = torch.cuda.current_stream().cuda_stream
+        # compute on a non-default stream so that the RCCL gather (its own stream) can
+        # overlap the envelope kernels; the legacy default stream would serialise them
+        cstream = torch.cuda.Stream()
+        torch.cuda.set_stream(cstream)
+        stream = cstream.cuda_stream
     else:
         stream = None
     ctx = hipdsp.Context(local_rank, stream)
@@ -168,18 +177,30 @@ def main():
     dx = hipdsp.DeviceArray(ctx, (C, T), np.float32)
     df = hipdsp.DeviceArray(ctx, (C, T), np.float32)
     de = hipdsp.DeviceArray(ctx, (C, T), np.float32)
-    if world > 1:
+    if multi:
         tspec = torch.empty((C, nd, F), dtype=torch.float32, device='cuda')
         ds = hipdsp.DeviceArray(ctx, (C, nd, F), np.float32, ptr=tspec.data_ptr(), owner=tspec)
         tile_frames = n_tile_frames(nd, args.rate, args.hop, args.tile_seconds)
+        tile_buf = torch.empty((C, tile_frames, F), dtype=torch.float32, device='cuda')
+        merged = torch.empty((world*C, tile_frames, F), dtype=torch.float32,
+                             device='cuda' if args.backend == 'nccl' else 'cpu')
     else:
         ds = hipdsp.DeviceArray(ctx, (C, nd, F), np.float32)
     ctx.reserve(4*C*((T + 2*edge + 3)//4*4))
     hipdsp.synth(ctx, dx, T, C, T, args.rate, 1234 + 2, c0=rank*C, c_total=world*C)
     ctx.synchronize()
 
+    # measured device-copy ceiling (read + write of one trace, hipMemcpy D2D), reported next
+    # to the 8 TB/s spec peak as SURVEY 8d asks; untimed, before the steps
+    ca, cb = ctx.event(), ctx.event()
+    hipdsp.lib.hipdsp_memcpy_d2d(ctx.handle, hipdsp._p(de), hipdsp._p(dx), 4*C*T)
+    ctx.record(ca)
+    for _ in range(3):
+        hipdsp.lib.hipdsp_memcpy_d2d(ctx.handle, hipdsp._p(de), hipdsp._p(dx), 4*C*T)
+    ctx.record(cb)
+    copy_gbps = 3*8.0*C*T/(ctx.elapsed_ms(ca, cb)*1e-3)/1e9
+
     n_ev = 5
-    total = args.warmup + args.steps
     events = [[ctx.event() for _ in range(n_ev)] for _ in range(args.steps)]
     mids = [ctx.event() for _ in range(args.steps)]
 
@@ -193,24 +214,29 @@ def main():
         hipdsp.spectrogram(ctx, df, T, C, T, args.nfft, args.hop, args.rate, ds, nd)
         if ev:
             ctx.record(ev[2])
+        work = None
+        if multi:
+            # merged spectrogram tile of the visible window on every rank: one RCCL
+            # all-gather over xGMI, issued now so that it overlaps the envelope kernels
+            tile_buf.copy_(tspec[:, :tile_frames, :])
+            if args.backend == 'nccl':
+                _, work = allgather_tiles(tile_buf, world*C, out=merged, async_op=True)
+            else:
+                allgather_tiles(tile_buf.cpu(), world*C, out=merged)
+        if ev:
             ctx.set_mid_event(mids[i])
         hipdsp.envelope(ctx, eplan, df, T, de, T, C, T, 0, rectify=True, gain=np.pi/2, clamp=True)
         if ev:
             ctx.set_mid_event(None)
             ctx.record(ev[3])
-        if world > 1:
-            # merged spectrogram tile of the visible window on every rank (RCCL over xGMI)
-            tile = tspec[:, :tile_frames, :]
-            if args.backend == 'gloo':
-                tile = tile.cpu()
-            merged = allgather_tiles(tile, world*C)
-            assert merged.shape[0] == world*C
+        if work is not None:
+            work.wait()                      # compute stream waits for the gather
         if ev:
             ctx.record(ev[4])
 
     def fence():
         ctx.synchronize()
-        if world > 1:
+        if multi:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -223,14 +249,14 @@ def main():
         step(i)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+    if multi:
+        tt = torch.tensor([dt], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     # per-kernel averages from the HIP events recorded inside the timed region
     names = ['sos_scan<S=%d,filt>' % len(sos), 'spectrogram', 'sos_scan<S=%d,env_fwd>' % len(esos),
-             'sos_scan<S=%d,env_bwd>' % len(esos), 'allgather_tile']
+             'sos_scan<S=%d,env_bwd>' % len(esos), 'allgather_tile_exposed']
     ms = dict.fromkeys(names, 0.0)
     for i in range(args.steps):
         e = events[i]
@@ -251,7 +277,7 @@ def main():
     achieved = alg_bytes[dom]/(ms[dom]*1e-3)/1e9
     kernels = {k: {'ms': round(ms[k], 4),
                    'GBps': round(alg_bytes[k]/(ms[k]*1e-3)/1e9, 1) if k in alg_bytes and ms[k] > 0 else None}
-               for k in names if k != 'allgather_tile' or world > 1}
+               for k in names if k != 'allgather_tile_exposed' or multi}
 
     parity = None
     cpu = None
@@ -286,7 +312,8 @@ def main():
             },
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved/HBM_PEAK_GBS, 4), 'traffic': None},
+                         'frac': round(achieved/HBM_PEAK_GBS, 4), 'traffic': None,
+                         'device_copy_GBps': round(copy_gbps, 1)},
             'kernels': kernels,
             'chain_algorithmic_GBps': round(sum(alg_bytes.values())/(dt/args.steps)/1e9, 1),
             'parity_max_rel_err': parity,
@@ -295,7 +322,7 @@ def main():
         if parity is None or not parity < 1e-4:
             line['invalid'] = 'parity gate failed'
         print(json.dumps(line))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

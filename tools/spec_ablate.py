@@ -4,15 +4,15 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audian_amd import hipdsp
 
-C, T, nfft, hop, rate = 64, int(120*96000), 2048, 1024, 96000.0
+C, T, rate = 64, int(120*96000), 96000.0
 ctx = hipdsp.Context(0)
 dx = hipdsp.DeviceArray(ctx, (C, T), np.float32)
 hipdsp.synth(ctx, dx, T, C, T, rate, 7)
-nd = (T + hop - 1)//hop
-ds = hipdsp.DeviceArray(ctx, (C, nd, nfft//2 + 1), np.float32)
 e0, e1 = ctx.event(), ctx.event()
 
-def run(**opts):
+def run(nfft, hop, **opts):
+    nd = (T + hop - 1)//hop
+    ds = hipdsp.DeviceArray(ctx, (C, nd, nfft//2 + 1), np.float32)
     for k, v in opts.items():
         ctx.set_option(k, v)
     for _ in range(2):
@@ -23,10 +23,12 @@ def run(**opts):
     ctx.record(e1)
     ms = ctx.elapsed_ms(e0, e1)/5
     gb = (4.0*C*T + 4.0*C*nd*(nfft//2 + 1))/1e9
-    print(f'{opts}: {ms:.3f} ms  {gb/ms*1e3:.0f} GB/s', flush=True)
+    print(f'nfft {nfft} hop {hop} {opts}: {ms:.3f} ms  {gb/ms*1e3:.0f} GB/s', flush=True)
+    ds.free()
 
-for kern, waves in ((3, 4), (3, 6), (3, 8), (0, 8)):
-    for fpw in (8, 16, 64):
-        run(spec_kernel=kern, spec_waves=waves, spec_fpw=fpw, spec_flags=0)
-for flags in (1, 2, 3):
-    run(spec_kernel=3, spec_waves=4, spec_fpw=16, spec_flags=flags)
+for fpw in (0, 16, 64):
+    run(2048, 1024, spec_kernel=0, spec_fpw=fpw)
+run(2048, 1024, spec_kernel=2, spec_fpw=0)
+for nfft, hop in ((256, 128), (512, 256), (1024, 512), (1024, 256), (4096, 2048)):
+    for kern in (0, 2, 3):
+        run(nfft, hop, spec_kernel=kern, spec_fpw=0)
