@@ -64,6 +64,12 @@ _SIGNATURES = {
     'hipdsp_ctx_set_option': ([_vp, ctypes.c_char_p, ctypes.c_longlong], _int),
     'hipdsp_ctx_reserve': ([_vp, _sz], _int),
     'hipdsp_ctx_set_mid_event': ([_vp, _vp], _int),
+    'hipdsp_stream_create': ([_vp, _pp], _int),
+    'hipdsp_stream_destroy': ([_vp, _vp], _int),
+    'hipdsp_graph_begin': ([_vp], _int),
+    'hipdsp_graph_end': ([_vp, _pp], _int),
+    'hipdsp_graph_launch': ([_vp, _vp], _int),
+    'hipdsp_graph_destroy': ([_vp, _vp], _int),
     'hipdsp_malloc': ([_vp, _sz, _pp], _int),
     'hipdsp_free': ([_vp, _vp], _int),
     'hipdsp_memset': ([_vp, _vp, _int, _sz], _int),

@@ -24,6 +24,11 @@ struct hipdsp_ctx {
     int spec_fpw, spec_flags, spec_waves, spec_kernel;   // experiments (tools/), 0 = defaults
 };
 
+struct hipdsp_graph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
 #define HD_CHECK_HIP(expr)                                                        \
     do {                                                                          \
         hipError_t _e = (expr);                                                   \

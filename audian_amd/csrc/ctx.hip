@@ -186,6 +186,73 @@ int hipdsp_memcpy2d_d2d(hipdsp_ctx *ctx, void *dst, size_t dst_pitch, const void
     return HIPDSP_OK;
 }
 
+int hipdsp_stream_create(hipdsp_ctx *ctx, void **stream)
+{
+    HD_REQUIRE(ctx != nullptr && stream != nullptr, "NULL argument");
+    HD_CHECK_HIP(hipSetDevice(ctx->device));
+    hipStream_t s;
+    HD_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return HIPDSP_OK;
+}
+
+int hipdsp_stream_destroy(hipdsp_ctx *ctx, void *stream)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (stream) {
+        if (ctx->stream == (hipStream_t)stream) ctx->stream = nullptr;
+        HD_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
+    }
+    return HIPDSP_OK;
+}
+
+int hipdsp_graph_begin(hipdsp_ctx *ctx)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    HD_REQUIRE(ctx->stream != nullptr, "stream capture needs a non-default stream "
+               "(hipdsp_stream_create + hipdsp_ctx_set_stream)");
+    HD_CHECK_HIP(hipSetDevice(ctx->device));
+    HD_CHECK_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    return HIPDSP_OK;
+}
+
+int hipdsp_graph_end(hipdsp_ctx *ctx, hipdsp_graph **out)
+{
+    HD_REQUIRE(ctx != nullptr && out != nullptr, "NULL argument");
+    *out = nullptr;
+    hipGraph_t g = nullptr;
+    HD_CHECK_HIP(hipStreamEndCapture(ctx->stream, &g));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        HD_CHECK_HIP(e);
+    }
+    hipdsp_graph *h = new hipdsp_graph();
+    h->graph = g;
+    h->exec = exec;
+    *out = h;
+    return HIPDSP_OK;
+}
+
+int hipdsp_graph_launch(hipdsp_ctx *ctx, hipdsp_graph *graph)
+{
+    HD_REQUIRE(ctx != nullptr && graph != nullptr, "NULL argument");
+    HD_CHECK_HIP(hipGraphLaunch(graph->exec, ctx->stream));
+    return HIPDSP_OK;
+}
+
+int hipdsp_graph_destroy(hipdsp_ctx *ctx, hipdsp_graph *graph)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (graph) {
+        (void)hipGraphExecDestroy(graph->exec);
+        (void)hipGraphDestroy(graph->graph);
+        delete graph;
+    }
+    return HIPDSP_OK;
+}
+
 int hipdsp_event_create(hipdsp_ctx *ctx, void **event)
 {
     HD_REQUIRE(ctx != nullptr && event != nullptr, "NULL argument");

@@ -42,6 +42,29 @@ class Context:
     def reserve(self, nbytes):
         check(lib.hipdsp_ctx_reserve(self._h, int(nbytes)))
 
+    # streams and graphs ---------------------------------------------------
+    def create_stream(self):
+        st = ctypes.c_void_p()
+        check(lib.hipdsp_stream_create(self._h, ctypes.byref(st)))
+        return st.value
+
+    def destroy_stream(self, stream):
+        check(lib.hipdsp_stream_destroy(self._h, ctypes.c_void_p(stream)))
+
+    def graph_begin(self):
+        check(lib.hipdsp_graph_begin(self._h))
+
+    def graph_end(self):
+        g = ctypes.c_void_p()
+        check(lib.hipdsp_graph_end(self._h, ctypes.byref(g)))
+        return g
+
+    def graph_launch(self, graph):
+        check(lib.hipdsp_graph_launch(self._h, graph))
+
+    def graph_destroy(self, graph):
+        check(lib.hipdsp_graph_destroy(self._h, graph))
+
     # events -------------------------------------------------------------
     def event(self):
         ev = ctypes.c_void_p()

@@ -67,6 +67,25 @@ int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value);
  * not allocate; required before stream capture into a hipGraph. */
 int hipdsp_ctx_reserve(hipdsp_ctx *ctx, size_t bytes);
 
+/* ---- streams and hipGraph capture (interactive recompute, BASELINE configs[4]) ---- */
+
+/* A non-blocking HIP stream owned by the library (stream capture cannot run on the
+ * legacy default stream).  Pass it to hipdsp_ctx_set_stream. */
+int hipdsp_stream_create(hipdsp_ctx *ctx, void **stream);
+int hipdsp_stream_destroy(hipdsp_ctx *ctx, void *stream);
+
+/* Capture everything enqueued on the context's stream between _begin and _end into an
+ * executable graph; hipdsp_graph_launch replays it on the context's stream.  Run each
+ * call once before capturing (FFT tables, scratch: hipdsp_ctx_reserve) -- nothing may
+ * allocate during capture.  Filter cut-offs change between replays through
+ * hipdsp_sosplan_set_host + a captured hipdsp_sosplan_upload (DataBrowser.update_filter
+ * -> BufferedFilter.update -> recompute_all, databrowser.py:1264-1288). */
+typedef struct hipdsp_graph hipdsp_graph;
+int hipdsp_graph_begin(hipdsp_ctx *ctx);
+int hipdsp_graph_end(hipdsp_ctx *ctx, hipdsp_graph **out);
+int hipdsp_graph_launch(hipdsp_ctx *ctx, hipdsp_graph *graph);
+int hipdsp_graph_destroy(hipdsp_ctx *ctx, hipdsp_graph *graph);
+
 /* ---- device memory helpers (so a non-torch host can keep stages resident) */
 
 int hipdsp_malloc(hipdsp_ctx *ctx, size_t bytes, void **dptr);

@@ -1,0 +1,70 @@
+"""BASELINE configs[4]: the interactive recompute (filter -> spectrogram -> envelope)
+captured once into a hipGraph and replayed under a live hp/lp cut-off sweep; the SOS
+coefficients live in a device plan that each replay re-uploads from pinned memory."""
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_graph_replay_under_cutoff_sweep(oracle):
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rate, C, T, nfft, hop = 192000.0, 4, 192000*2, 1024, 512
+    ctx = hipdsp.Context(0)
+    stream = ctx.create_stream()
+    ctx.set_stream(stream)
+    dx = hipdsp.DeviceArray(ctx, (C, T), np.float32)
+    hipdsp.synth(ctx, dx, T, C, T, rate, 99)
+    x = dx.to_host().T.astype(np.float64)
+    df = hipdsp.DeviceArray(ctx, (C, T), np.float32)
+    de = hipdsp.DeviceArray(ctx, (C, T), np.float32)
+    nd = (T + hop - 1)//hop
+    ds = hipdsp.DeviceArray(ctx, (C, nd, nfft//2 + 1), np.float32)
+    esos = butter_sos(2, 500.0, 'lowpass', rate)
+    plan = hipdsp.SosPlan(ctx, butter_sos(2, (100.0, 20000.0), 'bandpass', rate))
+    eplan = hipdsp.SosPlan(ctx, esos)
+
+    def chain():
+        plan.upload()
+        hipdsp.sosfilt(ctx, plan, dx, T, df, T, C, T, 0)
+        hipdsp.spectrogram(ctx, df, T, C, T, nfft, hop, rate, ds, nd)
+        hipdsp.envelope(ctx, eplan, df, T, de, T, C, T, 0)
+
+    chain()                       # warm: FFT tables, envelope scratch
+    ctx.synchronize()
+    ctx.graph_begin()
+    chain()
+    graph = ctx.graph_end()
+    for hp, lp in [(100.0, 20000.0), (700.0, 9000.0), (2000.0, 4000.0)]:
+        sos = butter_sos(2, (hp, lp), 'bandpass', rate)
+        plan.set_host(sos)        # host only: the captured upload node carries it over
+        ctx.graph_launch(graph)
+        ctx.synchronize()
+        filt = np.zeros_like(x)
+        oracle.filter_process(sos, x, filt, 0)
+        got = df.to_host()
+        for c in range(C):
+            assert rel_err(got[c], filt[:, c]) < 1e-4, (hp, lp, c)
+        env = np.zeros_like(x)
+        oracle.envelope_process(esos, filt, env, 0)
+        got = de.to_host()
+        for c in range(C):
+            assert rel_err(got[c], env[:, c]) < 1e-4
+        spec = np.zeros((nd, C, nfft//2 + 1))
+        oracle.spectrogram_process(filt, spec, rate, nfft, hop)
+        got = ds.to_host()
+        for c in range(C):
+            for k in range(0, nd - 1, 37):
+                assert rel_err(got[c, k], spec[k, c]) < 1e-4
+    # capture must not allocate: a spectrogram size seen for the first time is refused
+    ctx.graph_begin()
+    with pytest.raises(ValueError):
+        hipdsp.spectrogram(ctx, df, T, C, T, 4096, 2048, rate, ds, 8)
+    ctx.graph_destroy(ctx.graph_end())
+    ctx.graph_destroy(graph)
+    ctx.set_stream(None)
+    ctx.destroy_stream(stream)
