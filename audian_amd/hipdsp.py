@@ -234,6 +234,40 @@ class SosPlan:
             pass
 
 
+class Comm:
+    """RCCL communicator behind the C ABI (hipdsp_comm_*): rank 0 calls
+    `Comm.unique_id()` and ships the 128 bytes to the other ranks."""
+
+    def __init__(self, ctx, unique_id, rank, nranks):
+        self.ctx = ctx
+        self.rank, self.nranks = int(rank), int(nranks)
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        h = ctypes.c_void_p()
+        check(lib.hipdsp_comm_create(ctx.handle, buf, self.rank, self.nranks, ctypes.byref(h)))
+        self._h = h
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        check(lib.hipdsp_comm_unique_id(buf))
+        return buf.raw
+
+    def allgather(self, send, recv, count_per_rank):
+        check(lib.hipdsp_allgather_f32(self.ctx.handle, self._h, _p(send), _p(recv),
+                                       int(count_per_rank)))
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            lib.hipdsp_comm_destroy(self.ctx.handle, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def _plan(plan):
     return plan.handle if plan is not None else ctypes.c_void_p(0)
 

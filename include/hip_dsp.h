@@ -198,6 +198,23 @@ int hipdsp_decibel(hipdsp_ctx *ctx, const float *p, float *out, int64_t n, doubl
 int hipdsp_decibel_image(hipdsp_ctx *ctx, const float *spec_tf, float *image_ft,
                          int64_t frames, int64_t nfreq, double ref_power, double min_power);
 
+/* ---- multi-GPU exchange ---------------------------------------- */
+
+/* One process per GPU, channels sharded in contiguous blocks of the planar layout, so
+ * the merged spectrogram tile is ONE all-gather of contiguous per-rank chunks (RCCL over
+ * xGMI).  Rank 0 obtains a 128-byte id (hipdsp_comm_unique_id) and hands it to the other
+ * ranks by whatever channel the host has (file, socket, torch store); every rank then
+ * creates its communicator.  RCCL is loaded on first use. */
+#define HIPDSP_UNIQUE_ID_BYTES 128
+typedef struct hipdsp_comm hipdsp_comm;
+int hipdsp_comm_unique_id(void *id_out);
+int hipdsp_comm_create(hipdsp_ctx *ctx, const void *unique_id, int rank, int nranks,
+                       hipdsp_comm **out);
+int hipdsp_comm_destroy(hipdsp_ctx *ctx, hipdsp_comm *comm);
+/* recv[r*count : (r+1)*count] = rank r's send[0:count], on the context's stream. */
+int hipdsp_allgather_f32(hipdsp_ctx *ctx, hipdsp_comm *comm, const float *send, float *recv,
+                         int64_t count_per_rank);
+
 /* ---- synthetic input (bench / tests) --------------------------- */
 
 /* x[c, t] = 0.5*u(seed, c, t) + 0.5*sin(2*pi*1000*(1 + (c0 + c)/c_total)*t/rate),

@@ -257,3 +257,18 @@ def test_synth_is_deterministic_and_bounded():
     assert np.all(np.abs(ha) <= 1.0)
     spec = np.abs(np.fft.rfft(ha[1]))                 # tone at 1000*(1 + 1/4) Hz
     assert np.argmax(spec[1:]) + 1 == 1250
+
+
+def test_rccl_allgather_entry_point_single_rank():
+    """hipdsp_comm_* / hipdsp_allgather_f32 with one rank (the box has one GPU): the
+    communicator comes up and the gather reproduces the tile."""
+    from audian_amd import hipdsp
+    c = gh.ctx()
+    comm = hipdsp.Comm(c, hipdsp.Comm.unique_id(), 0, 1)
+    tile = np.random.default_rng(2).standard_normal((3, 50, 129)).astype(np.float32)
+    send = hipdsp.DeviceArray.from_host(c, tile)
+    recv = hipdsp.DeviceArray(c, tile.shape, np.float32).zero_()
+    comm.allgather(send, recv, tile.size)
+    c.synchronize()
+    assert np.array_equal(recv.to_host(), tile)
+    comm.close()
