@@ -208,7 +208,7 @@ __device__ __forceinline__ void stockham_stage(float2 *v, float2 *fb, const floa
     }
 }
 
-template <int NFFT, int LPF, int R1, int R2, int R3, int WAVES, bool DB>
+template <int NFFT, int LPF, int R1, int R2, int R3, int WAVES, bool DB, bool HALF>
 __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? 3 : 1) * WAVES / 4) void spec_fast_kernel(
     const float *__restrict__ x, long long x_pitch, long long n_valid, long long frames_out,
     long long out_pitch, int hop, float scale, const float *__restrict__ tables, float *__restrict__ out,
@@ -250,22 +250,31 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? 3 : 1) * WAVES / 4) voi
     // first frame of this wave; wave-uniform (scalar) when a frame takes the whole wave
     const long long first = ((long long)blockIdx.x * NW + wave) * (long long)frames_per_wave * G;
 
-    // Raw samples of one frame: the lane keeps z[n], n = l + LPF*u + t*M/R1, at [u*R1 + t].
-    // The loads are inline asm so that the wait for them can be counted by hand: the
-    // next frame is fetched right after stage 3 (its registers are free until the next
-    // stage 1), i.e. BEFORE this frame's stores, and `s_waitcnt vmcnt(NST)` at the top
-    // of the next frame then retires the loads while the NST younger stores stay in
-    // flight.  (hipcc would wait vmcnt(0) here, i.e. for every store acknowledgement.)
-    v2f raw[PPL];
-    auto fetch = [&](long long frame) {
+    // Raw samples of one frame: the lane keeps z[n], n = l + LPF*u + t*M/R1, as two halves
+    // (t < R1/2 in `lo`, t >= R1/2 in `hi`).  The loads are inline asm so that the wait for
+    // them can be counted by hand: the next frame is fetched right after stage 3 (the
+    // registers are free until the next stage 1), i.e. BEFORE this frame's stores, and
+    // `s_waitcnt vmcnt(NST)` at the top of the next frame retires the loads while the NST
+    // younger stores stay in flight (hipcc would wait vmcnt(0), i.e. for every store
+    // acknowledgement).
+    // With 50 % overlap (HALF: hop == NFFT/2, one frame per wave) the upper half of frame f
+    // IS the lower half of frame f+1 in the same lane (n' = n - M/2 <=> t' = t - R1/2), so
+    // only the new half is fetched and the two register sets swap roles every frame: each
+    // sample is requested once instead of twice (PMC: 22.1 GB -> 14.8 GB read per launch).
+    constexpr int HP = PPL / 2;                            // points per half
+    constexpr int R1H = R1 / 2;
+    v2f ra[HP], rb[HP];
+    auto fetch_half = [&](long long frame, int upper, v2f *dst) {
         const float *seg = xc + frame * (long long)hop + 2 * l;
 #pragma unroll
         for (int u = 0; u < PPL / R1; u++)
 #pragma unroll
-            for (int t = 0; t < R1; t++) {
-                constexpr int CH = 512;                        // float2 per 4096-byte window
-                const int n = LPF * u + t * (M / R1);          // compile-time after unrolling
-                raw[u * R1 + t] = asm_load8(seg + 2 * (n / CH) * CH, (n % CH) * 8);
+            for (int t = 0; t < R1H; t++) {
+                constexpr int CH = 512;                    // float2 per 4096-byte window
+                const int n0 = LPF * u + t * (M / R1);     // compile-time after unrolling
+                const int n1 = n0 + R1H * (M / R1);
+                if (upper) dst[u * R1H + t] = asm_load8(seg + 2 * (n1 / CH) * CH, (n1 % CH) * 8);
+                else dst[u * R1H + t] = asm_load8(seg + 2 * (n0 / CH) * CH, (n0 % CH) * 8);
             }
     };
     // stores behind a prefetch in the steady-state loop; one less than issued, so the wait
@@ -276,22 +285,28 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? 3 : 1) * WAVES / 4) voi
     const long long last_valid = n_valid > 0 ? n_valid - 1 : 0;
     const int partner = g * LPF + ((LPF - l) & (LPF - 1));
 
-    // One frame per lane group.  `keep` masks the stores of lane groups whose frame is not
-    // valid (only in the one mixed iteration of a wave).  With PF the next frame is
-    // prefetched; the steady-state body has no divergent branch around its stores.
-    auto body = [&](long long frame, bool keep, auto full, auto pf) {
+    // One frame per lane group from the raw halves (lo, hi).  `keep` masks the stores of
+    // lane groups whose frame is not valid (only in the one mixed iteration of a wave).
+    // With PF the next frame is prefetched (HALF: its new half, into `lo`); the steady-state
+    // body has no divergent branch around its stores so that their count is exact.
+    auto body = [&](long long frame, bool keep, auto full, auto pf, auto waitn, v2f *lo, v2f *hi) {
         constexpr bool FULL = decltype(full)::value;
         constexpr bool PF = decltype(pf)::value;
+        constexpr int WAITN = decltype(waitn)::value;
+        if (WAITN >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN < 0 ? 0 : WAITN) : "memory");
         float *o = oc + frame * (long long)F;
         float *od = DB ? dc + frame * (long long)F : nullptr;
         float2 v[PPL];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < PPL; i++) {
-            asm volatile("" : "+v"(raw[i]));              // not before the counted wait
-            v[i] = make_float2(raw[i].x, raw[i].y);
-            s += v[i].x + v[i].y;
-        }
+        for (int u = 0; u < PPL / R1; u++)
+#pragma unroll
+            for (int t = 0; t < R1; t++) {
+                v2f &r = t < R1H ? lo[u * R1H + t] : hi[u * R1H + t - R1H];
+                asm volatile("" : "+v"(r));               // not before the counted wait
+                v[u * R1 + t] = make_float2(r.x, r.y);
+                s += r.x + r.y;
+            }
 #pragma unroll
         for (int d = LPF / 2; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
         const float mean = s * (1.0f / (float)NFFT);
@@ -308,7 +323,13 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? 3 : 1) * WAVES / 4) voi
         stockham_stage<R3, R1 * R2, M, LPF, true, false, true>(v, fb, tw3, l);
         if (PF) {
             const long long nf = frame + G;
-            fetch(nf < last_valid ? nf : last_valid);
+            const long long cf = nf < last_valid ? nf : last_valid;
+            if (HALF) {
+                fetch_half(cf, 1, lo);                    // hi stays: it is the next lower half
+            } else {
+                fetch_half(cf, 0, lo);
+                fetch_half(cf, 1, hi);
+            }
         }
         // Now v[u*R3 + t] = Z[k], k = l + LPF*m, m = u + NB3*t.  Split step for m < PPL/2
         // (k < M/2): X[k] = E + W^k O, X[M-k] = conj(E - W^k O); the partner bin Z[M-k] sits
@@ -363,33 +384,51 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? 3 : 1) * WAVES / 4) voi
         }
     };
 
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    using W0 = std::integral_constant<int, 0>;
+    using WN = std::integral_constant<int, NST>;
+    using WX = std::integral_constant<int, -1>;
     // iterations in which every lane group of the wave has a valid frame
     long long n_main = (n_valid - first) / G;
     if (n_main < 0) n_main = 0;
     if (n_main > frames_per_wave) n_main = frames_per_wave;
     {
         const long long f0 = first + g;
-        fetch(f0 < last_valid ? f0 : last_valid);
+        const long long c0 = f0 < last_valid ? f0 : last_valid;
+        fetch_half(c0, 0, ra);
+        fetch_half(c0, 1, rb);
     }
+    int it = 0;
     if (n_main > 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        body(first + g, true, std::true_type(), std::true_type());
+        body(first + g, true, T_(), T_(), W0(), ra, rb);
+        it = 1;
     }
-    for (int it = 1; it < (int)n_main; it++) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
-        body(first + (long long)it * G + g, true, std::true_type(), std::true_type());
+    if (HALF) {
+        // the register sets swap roles every frame: (lo, hi) = (rb, ra), (ra, rb), ...
+        for (; it + 1 < (int)n_main; it += 2) {
+            body(first + (long long)it * G + g, true, T_(), T_(), WN(), rb, ra);
+            body(first + (long long)(it + 1) * G + g, true, T_(), T_(), WN(), ra, rb);
+        }
+        if (it < (int)n_main) {
+            body(first + (long long)it * G + g, true, T_(), T_(), WN(), rb, ra);
+            it++;
+        }
+    } else {
+        for (; it < (int)n_main; it++)
+            body(first + (long long)it * G + g, true, T_(), T_(), WN(), ra, rb);
     }
     // retire the last prefetch before anything else may reuse its registers
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < PPL; i++) asm volatile("" : "+v"(raw[i]));
-    // at most one mixed iteration, then the zero tail (bufferedspectrogram.py:59)
-    for (int it = (int)n_main; it < frames_per_wave; it++) {
+    for (int i = 0; i < HP; i++) { asm volatile("" : "+v"(ra[i])); asm volatile("" : "+v"(rb[i])); }
+    // at most one mixed iteration (G > 1 only, never HALF), then the zero tail
+    // (bufferedspectrogram.py:59)
+    for (; it < frames_per_wave; it++) {
         const long long frame = first + (long long)it * G + g;
         if (first + (long long)it * G >= frames_out) break;
         if (G > 1 && it == (int)n_main && first + (long long)it * G < n_valid)
-            body(frame < last_valid ? frame : last_valid, frame < n_valid, std::false_type(),
-                 std::false_type());
+            body(frame < last_valid ? frame : last_valid, frame < n_valid, F_(), F_(), WX(), ra, rb);
         if (frame >= n_valid && frame < frames_out) {
             float *o = oc + frame * (long long)F;
             for (int f = l; f < F; f += LPF) {
@@ -574,14 +613,21 @@ int launch_fast(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long ch
     const int fpw = frames_per_wave(ctx, channels, frames_out, G);
     long long per_block = (long long)WAVES * fpw * G;
     long long bx = (frames_out + per_block - 1) / per_block;
-    if (db_out)
-        hipLaunchKernelGGL((spec_fast_kernel<NFFT, LPF, R1, R2, R3, WAVES, true>),
-                           dim3((unsigned)bx, (unsigned)channels), dim3(64 * WAVES), 0, ctx->stream, x, x_pitch,
-                           n_valid, frames_out, out_pitch, hop, scale, tables, out, db_out, fpw, ctx->spec_flags);
-    else
-        hipLaunchKernelGGL((spec_fast_kernel<NFFT, LPF, R1, R2, R3, WAVES, false>),
-                           dim3((unsigned)bx, (unsigned)channels), dim3(64 * WAVES), 0, ctx->stream, x, x_pitch,
-                           n_valid, frames_out, out_pitch, hop, scale, tables, out, db_out, fpw, ctx->spec_flags);
+    // 50 % overlap with one frame per wave: reuse the overlapped half from registers
+    const bool half = (LPF == 64) && hop * 2 == NFFT && !ctx->spec_no_half;
+    dim3 grid((unsigned)bx, (unsigned)channels), block(64 * WAVES);
+#define HD_SPEC_LAUNCH(DBV, HALFV)                                                                  \
+    hipLaunchKernelGGL((spec_fast_kernel<NFFT, LPF, R1, R2, R3, WAVES, DBV, HALFV>), grid, block, 0,  \
+                       ctx->stream, x, x_pitch, n_valid, frames_out, out_pitch, hop, scale, tables,   \
+                       out, db_out, fpw, ctx->spec_flags)
+    if (LPF == 64 && half) {
+        if (db_out) HD_SPEC_LAUNCH(true, (LPF == 64));
+        else HD_SPEC_LAUNCH(false, (LPF == 64));
+    } else {
+        if (db_out) HD_SPEC_LAUNCH(true, false);
+        else HD_SPEC_LAUNCH(false, false);
+    }
+#undef HD_SPEC_LAUNCH
     return hd_launch_status("spec_fast_kernel");
 }
 

@@ -33,14 +33,18 @@ def kernels(lines):
             name = None
 
 
+VMEM = re.compile(r'^\s*(global_|buffer_|scratch_|flat_)(load|store|atomic)')
+
+
 def check(name, body, width):
-    """Find runs of >= 8 consecutive-ish asm loads (marked by ';APP' regions are not kept
-    by hipcc -S, so identify them as `global_load_dwordxN ... off` groups of equal width
-    that are followed by a counted vmcnt wait earlier in the same loop)."""
+    """Groups of >= 4 close-together `global_load_dwordxN ... off` inside a loop are taken
+    to be a hand-counted prefetch.  From the last load of a group the scan walks forward
+    (following the loop's back edge once), counting the younger VMEM operations, until an
+    `s_waitcnt vmcnt(k)` with k <= that count retires the loads; any instruction touching
+    the destination registers before that point is reported."""
     loads = [i for i, l in enumerate(body) if re.search(r'global_load_dwordx%d\s' % width, l)]
     if not loads:
         return None
-    # cluster loads that are close together
     groups, cur = [], [loads[0]]
     for i in loads[1:]:
         if i - cur[-1] <= 8:
@@ -49,35 +53,61 @@ def check(name, body, width):
             groups.append(cur)
             cur = [i]
     groups.append(cur)
-    problems = []
-    checked = 0
+    labels = {}
+    for k, l in enumerate(body):
+        m = re.match(r'^(\.LBB\w+):', l)
+        if m:
+            labels[m.group(1)] = k
+    problems, checked = [], 0
     for g in groups:
-        if len(g) < 8:
+        if len(g) < 4:
             continue
-        # inside a loop?  next backward branch target label after the group
         dest = set()
         for i in g:
             m = re.search(r'global_load_dwordx\d+\s+v\[(\d+):(\d+)\]', body[i])
             dest.update(range(int(m.group(1)), int(m.group(2)) + 1))
-        # scan forward until a backward branch (loop end) or s_endpgm
-        labels = {re.match(r'^(\.LBB\w+):', l).group(1): k for k, l in enumerate(body)
-                  if re.match(r'^(\.LBB\w+):', l)}
-        end = None
-        for k in range(g[-1] + 1, len(body)):
-            m = re.search(r's_cbranch_\w+\s+(\.LBB\w+)', body[k]) or re.search(r's_branch\s+(\.LBB\w+)', body[k])
-            if m and labels.get(m.group(1), 10**9) < g[0]:
-                end = k
-                break
-        if end is None:
-            continue            # not in a loop (prologue fetch): waited for by vmcnt(0) right after
-        checked += 1
-        for k in range(g[-1] + 1, end):
+        # in-order model of the vector-memory queue from the first load of the group on
+        k, jumped, steps = g[0], False, 0
+        queue = []                               # destination register sets, oldest first
+        seen_group = False
+        while k < len(body) and steps < 40000:
+            steps += 1
             l = body[k].strip()
-            if not l or l.startswith(';') or l.startswith('.'):
+            m = re.search(r's_waitcnt.*vmcnt\((\d+)\)', l)
+            if m:
+                n = int(m.group(1))
+                queue = queue[-n:] if n > 0 else []
+            if seen_group and not any(q & dest for q in queue):
+                break                            # every load of the group has been retired
+            if 's_endpgm' in l:
+                break
+            br = re.search(r's_cbranch_\w+\s+(\.LBB\w+)', l) or re.search(r's_branch\s+(\.LBB\w+)', l)
+            if br and labels.get(br.group(1), 10**9) < g[0] and not jumped and k > g[-1]:
+                jumped = True                    # loop back edge: continue at the loop head
+                k = labels[br.group(1)]
                 continue
-            hit = regs_of(l) & dest
-            if hit:
-                problems.append((name, k, l, sorted(hit)))
+            if l and not l.startswith(';') and not l.startswith('.'):
+                pending = set().union(*queue) if queue else set()
+                ld = re.search(r'^(global|scratch|buffer)_load_\w+\s+v\[(\d+):(\d+)\]', l) or \
+                    re.search(r'^(global|scratch|buffer)_load_\w+\s+v(\d+)()\b', l)
+                used = regs_of(l)
+                if ld:
+                    lo_ = int(ld.group(2))
+                    hi_ = int(ld.group(3)) if ld.group(3) else lo_
+                    d = set(range(lo_, hi_ + 1))
+                    src = regs_of(l.split(',', 1)[1]) if ',' in l else set()
+                    if (src | d) & pending & dest:
+                        problems.append((name, k, l, sorted((src | d) & pending & dest)))
+                    queue.append(d)
+                    if k in g:
+                        seen_group = seen_group or k == g[-1]
+                else:
+                    if used & pending & dest:
+                        problems.append((name, k, l, sorted(used & pending & dest)))
+                    if VMEM.match(l):
+                        queue.append(set())
+            k += 1
+        checked += 1
     return checked, problems
 
 

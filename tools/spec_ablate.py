@@ -15,7 +15,7 @@ def run(nfft, hop, **opts):
     ds = hipdsp.DeviceArray(ctx, (C, nd, nfft//2 + 1), np.float32)
     for k, v in opts.items():
         ctx.set_option(k, v)
-    for _ in range(2):
+    for _ in range(3):
         hipdsp.spectrogram(ctx, dx, T, C, T, nfft, hop, rate, ds, nd)
     ctx.record(e0)
     for _ in range(5):
@@ -26,9 +26,9 @@ def run(nfft, hop, **opts):
     print(f'nfft {nfft} hop {hop} {opts}: {ms:.3f} ms  {gb/ms*1e3:.0f} GB/s', flush=True)
     ds.free()
 
-for fpw in (0, 16, 64):
-    run(2048, 1024, spec_kernel=0, spec_fpw=fpw)
-run(2048, 1024, spec_kernel=2, spec_fpw=0)
-for nfft, hop in ((256, 128), (512, 256), (1024, 512), (1024, 256), (4096, 2048)):
-    for kern in (0, 2, 3):
-        run(nfft, hop, spec_kernel=kern, spec_fpw=0)
+run(2048, 1024, spec_no_half=1)
+for nh in (0, 1, 0, 1):
+    run(2048, 1024, spec_no_half=nh)
+for nfft, hop in ((1024, 512), (4096, 2048)):
+    for nh in (0, 1):
+        run(nfft, hop, spec_no_half=nh)
