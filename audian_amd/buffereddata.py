@@ -240,6 +240,35 @@ class BufferedData(BufferedArray):
             hipdsp.unpack(self.ctx, ddst, pitch, tmp, n, self.channels)
         dest[...] = tmp.to_host().reshape(dest.shape)
 
+    def minmax_decimate(self, start, stop, step, channel=None):
+        """Min/max screen decimation of frames [start, stop) (absolute frame indices inside
+        the current buffer), `step` frames per plot point: what TraceItem.update_plot computes
+        with np.minimum/maximum.reduceat (src/audian/traceitem.py:55-61), interleaved as
+        min, max, min, max, ...  Runs on the device mirror when it is valid there and returns
+        float64 like the reference's plot_data: (2*n,) for one channel, (channels, 2*n) for all.
+        """
+        from . import hipdsp
+        if self._inner() != 1:
+            raise ValueError('minmax_decimate is for traces, not spectrograms')
+        a, b = int(start) - self.offset, int(stop) - self.offset
+        n = len(self._hostbuf)
+        if a < 0 or b > n or b < a or step < 1:
+            raise IndexError('range outside the loaded buffer')
+        nseg = (b - a + step - 1)//step
+        if nseg == 0:
+            return np.zeros(0) if channel is not None else np.zeros((self.channels, 0))
+        if self._dev is not None and _covers(self._dev_valid, a, b):
+            out = hipdsp.DeviceArray(self.ctx, (self.channels, 2*nseg), np.float32)
+            hipdsp.minmax_decimate(self.ctx, self._dev, n, self.channels, a, b, step, out, 2*nseg)
+            res = out.to_host().astype(np.float64)
+        else:
+            seg = np.arange(0, b - a, step)
+            buf = self.buffer[a:b]
+            res = np.empty((self.channels, 2*nseg))
+            res[:, 0::2] = np.minimum.reduceat(buf, seg, axis=0).T
+            res[:, 1::2] = np.maximum.reduceat(buf, seg, axis=0).T
+        return res[channel] if channel is not None else res
+
     # ---- the reference's surface ----------------------------------------------------
     def expand_times(self, tbefore, tafter):
         self.tbefore += tbefore

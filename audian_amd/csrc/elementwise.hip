@@ -94,6 +94,61 @@ __global__ void unpack_spectrum_kernel(const float *__restrict__ src, long long 
     for (long long f = threadIdx.x; f < F; f += blockDim.x) d[f] = (double)s[f];
 }
 
+// np.minimum / np.maximum semantics: a NaN in either operand wins
+__device__ __forceinline__ float np_min(float a, float b) { return (a < b || a != a) ? a : b; }
+__device__ __forceinline__ float np_max(float a, float b) { return (a > b || a != a) ? a : b; }
+
+// Screen-resolution decimation of traces (TraceItem.update_plot, src/audian/traceitem.py:55-61;
+// compresseddata.py:48-52): out[c][2i] = min, out[c][2i+1] = max of x[c][start + i*step :
+// min(start + (i+1)*step, stop)]  (np.minimum/maximum.reduceat over arange(0, stop-start, step)).
+// WIDE: one wave per segment, lanes stride over it (step >= 64); else one lane per segment.
+template <bool WIDE>
+__global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ x, long long pitch,
+                                                     long long start, long long stop, long long step,
+                                                     long long nseg, float *__restrict__ out,
+                                                     long long out_pitch)
+{
+    const long long c = blockIdx.y;
+    const float *row = x + c * pitch;
+    float *orow = out + c * out_pitch;
+    if (WIDE) {
+        const int lane = threadIdx.x & 63;
+        const long long waves = (long long)gridDim.x * 4;
+        for (long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); i < nseg; i += waves) {
+            const long long lo = start + i * step;
+            long long hi = lo + step;
+            if (hi > stop) hi = stop;
+            float mn = row[lo], mx = mn;            // every segment has at least one sample
+            for (long long j = lo + lane; j < hi; j += 64) {
+                const float v = row[j];
+                mn = np_min(v, mn);
+                mx = np_max(v, mx);
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                mn = np_min(__shfl_xor(mn, d, 64), mn);
+                mx = np_max(__shfl_xor(mx, d, 64), mx);
+            }
+            if (lane == 0) { orow[2 * i] = mn; orow[2 * i + 1] = mx; }
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nseg;
+             i += (long long)gridDim.x * blockDim.x) {
+            const long long lo = start + i * step;
+            long long hi = lo + step;
+            if (hi > stop) hi = stop;
+            float mn = row[lo], mx = mn;
+            for (long long j = lo + 1; j < hi; j++) {
+                const float v = row[j];
+                mn = np_min(v, mn);
+                mx = np_max(v, mx);
+            }
+            orow[2 * i] = mn;
+            orow[2 * i + 1] = mx;
+        }
+    }
+}
+
 __device__ __forceinline__ unsigned int mix64to32(unsigned long long z)
 {
     z += 0x9E3779B97F4A7C15ULL;                      // splitmix64 finaliser
@@ -221,6 +276,31 @@ int hipdsp_unpack_spectrum_f64(hipdsp_ctx *ctx, const float *src, int64_t src_pi
                        ctx->stream, src, (long long)src_pitch, dst_tcf, (long long)frames,
                        (long long)channels, (long long)nfreq);
     return hd_launch_status("unpack_spectrum_kernel");
+}
+
+int hipdsp_minmax_decimate(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, int64_t channels,
+                           int64_t start, int64_t stop, int64_t step, float *out, int64_t out_pitch)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    HD_REQUIRE(channels >= 0 && start >= 0 && stop >= start && step >= 1, "bad range");
+    const long long nseg = (stop - start + step - 1) / step;
+    if (channels == 0 || nseg == 0) return HIPDSP_OK;
+    HD_REQUIRE(x != nullptr && out != nullptr, "NULL data pointer");
+    HD_REQUIRE(x_pitch >= stop && out_pitch >= 2 * nseg, "pitch too small");
+    HD_REQUIRE(channels <= 65535, "too many channels");
+    HD_CHECK_HIP(hipSetDevice(ctx->device));
+    if (step >= 64) {
+        unsigned gx = grid1d(nseg, 4, 16384);
+        hipLaunchKernelGGL(minmax_kernel<true>, dim3(gx, (unsigned)channels), dim3(256), 0, ctx->stream, x,
+                           (long long)x_pitch, (long long)start, (long long)stop, (long long)step, nseg, out,
+                           (long long)out_pitch);
+    } else {
+        unsigned gx = grid1d(nseg, 256, 16384);
+        hipLaunchKernelGGL(minmax_kernel<false>, dim3(gx, (unsigned)channels), dim3(256), 0, ctx->stream, x,
+                           (long long)x_pitch, (long long)start, (long long)stop, (long long)step, nseg, out,
+                           (long long)out_pitch);
+    }
+    return hd_launch_status("minmax_kernel");
 }
 
 int hipdsp_synth(hipdsp_ctx *ctx, float *x, int64_t x_pitch, int64_t channels, int64_t frames, double rate,

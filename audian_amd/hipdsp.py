@@ -316,6 +316,11 @@ def unpack_spectrum(ctx, src, dst_tcf, frames, channels, nfreq, src_pitch=0):
                                          int(frames), int(channels), int(nfreq)))
 
 
+def minmax_decimate(ctx, x, x_pitch, channels, start, stop, step, out, out_pitch):
+    check(lib.hipdsp_minmax_decimate(ctx.handle, _p(x), int(x_pitch), int(channels), int(start),
+                                     int(stop), int(step), _p(out), int(out_pitch)))
+
+
 def memcpy2d(ctx, dst, dst_pitch_bytes, src, src_pitch_bytes, width_bytes, height):
     check(lib.hipdsp_memcpy2d_d2d(ctx.handle, _p(dst), int(dst_pitch_bytes), _p(src),
                                   int(src_pitch_bytes), int(width_bytes), int(height)))

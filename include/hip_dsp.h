@@ -198,6 +198,19 @@ int hipdsp_decibel(hipdsp_ctx *ctx, const float *p, float *out, int64_t n, doubl
 int hipdsp_decibel_image(hipdsp_ctx *ctx, const float *spec_tf, float *image_ft,
                          int64_t frames, int64_t nfreq, double ref_power, double min_power);
 
+/* ---- next rows --------------------------------------------------- */
+
+/* Screen-resolution decimation of traces on the device (TraceItem.update_plot,
+ * traceitem.py:55-61; the same reduction fills the overview cache, compresseddata.py:48-52):
+ *   segments = arange(0, stop - start, step)
+ *   out[c, 0::2] = np.minimum.reduceat(x[c, start:stop], segments)
+ *   out[c, 1::2] = np.maximum.reduceat(x[c, start:stop], segments)
+ * for every channel; out is (channels, out_pitch) float32 with 2*ceil((stop-start)/step)
+ * valid values per row.  Only the few thousand plot points then cross PCIe (or xGMI). */
+int hipdsp_minmax_decimate(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, int64_t channels,
+                           int64_t start, int64_t stop, int64_t step, float *out,
+                           int64_t out_pitch);
+
 /* ---- multi-GPU exchange ---------------------------------------- */
 
 /* One process per GPU, channels sharded in contiguous blocks of the planar layout, so

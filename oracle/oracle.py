@@ -245,3 +245,15 @@ def spectrogram_process(source, dest, rate, nfft, hop):
         return freq
     dest[:] = 0
     return None
+
+
+def minmax_decimate(data, start, stop, step):
+    """TraceItem.update_plot's screen decimation (src/audian/traceitem.py:55-61; the same
+    reduction in compresseddata.py:48-52): min and max of every `step` frames of
+    data[start:stop] (1-D or (T, C)), interleaved min, max, ... along axis 0."""
+    seg = np.arange(0, stop - start, step)
+    block = np.asarray(data)[start:stop]
+    out = np.zeros((2*len(seg),) + block.shape[1:])
+    np.minimum.reduceat(block, seg, out=out[0::2])
+    np.maximum.reduceat(block, seg, out=out[1::2])
+    return out

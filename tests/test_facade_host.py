@@ -235,3 +235,23 @@ def test_host_decibel():
     assert d[0] == -np.inf and d[1] == -np.inf
     assert np.allclose(d[2:], [-190.0, 0.0, 20.0])
     assert decibel(10.0) == 10.0
+
+
+def test_minmax_decimate_host_path():
+    """Without a device mirror the facade falls back to the reference's own reduceat on the
+    host buffer (no GPU involved here: the Doubler stub computes on the host)."""
+    t = Doubler()
+    g = make_graph(t, buffer_time=10.0, back_time=0.0)
+    t.plot_items = [Item(), Item()]
+    g.set_need_update()
+    g.update_times(0.0, 5.0)
+    got = t.minmax_decimate(t.offset + 3, t.offset + 503, 50, channel=1)
+    blk = t.buffer[3:503, 1]
+    seg = np.arange(0, 500, 50)
+    want = np.zeros(20)
+    np.minimum.reduceat(blk, seg, out=want[0::2])
+    np.maximum.reduceat(blk, seg, out=want[1::2])
+    assert np.array_equal(got, want)
+    assert t.minmax_decimate(t.offset, t.offset + 1000, 7).shape == (2, 2*143)
+    with pytest.raises(IndexError):
+        t.minmax_decimate(t.offset, t.offset + len(t.buffer) + 1, 4)

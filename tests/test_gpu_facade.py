@@ -162,6 +162,13 @@ def test_scroll_update_and_recompute_match_oracle_twins(oracle):
     fin = np.isfinite(want)
     assert img.shape == want.shape and np.array_equal(np.isfinite(img), fin)
     assert np.max(np.abs(img[fin] - want[fin])) < 1e-3
+    # screen decimation from the device mirror == the reference's reduceat
+    f = g['filtered']
+    a, b = f.offset + 11, f.offset + len(f.buffer) - 3
+    for step in (5, 200):
+        got = f.minmax_decimate(a, b, step, channel=1)
+        want = oracle.minmax_decimate(f.buffer[:, 1], a - f.offset, b - f.offset, step)
+        assert np.array_equal(got, want)
     zmin, zmax = s.estimate_noiselevels(0)
     assert zmin is not None and 20 <= zmax - zmin <= 80
     assert s.spec_rect == [s.offset/s.rate, 0, len(s.buffer)/s.rate, rate/2 + s.fresolution]

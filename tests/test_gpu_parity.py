@@ -272,3 +272,22 @@ def test_rccl_allgather_entry_point_single_rank():
     c.synchronize()
     assert np.array_equal(recv.to_host(), tile)
     comm.close()
+
+
+@pytest.mark.parametrize('step', [2, 3, 17, 63, 64, 100, 1000, 4097])
+def test_minmax_decimation_bit_exact(oracle, step):
+    """np.minimum/maximum.reduceat screen decimation, bit-exact (selection only)."""
+    from audian_amd import hipdsp
+    rng = np.random.default_rng(step)
+    T, C = 50000 + step, 3
+    x = rng.standard_normal((T, C)).astype(np.float32)
+    c = gh.ctx()
+    dx = gh.to_planar(c, x)
+    for start, stop in [(0, T), (7, T - 5), (step*3, step*3 + 1), (100, 100 + 10*step)]:
+        nseg = (stop - start + step - 1)//step
+        out = hipdsp.DeviceArray(c, (C, 2*nseg), np.float32)
+        hipdsp.minmax_decimate(c, dx, T, C, start, stop, step, out, 2*nseg)
+        want = oracle.minmax_decimate(x.astype(np.float64), start, stop, step)     # (2n, C)
+        assert np.array_equal(out.to_host().astype(np.float64), want.T), (step, start, stop)
+    with pytest.raises(ValueError):
+        hipdsp.minmax_decimate(c, dx, T, C, 10, 5, step, dx, 2)
