@@ -97,6 +97,7 @@ _SIGNATURES = {
     'hipdsp_decibel': ([_vp, _vp, _vp, _i64, _dbl, _dbl], _int),
     'hipdsp_decibel_image': ([_vp, _vp, _vp, _i64, _i64, _dbl, _dbl], _int),
     'hipdsp_minmax_decimate': ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64], _int),
+    'hipdsp_mean_spectrum_db': ([_vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _dbl, _vp], _int),
     'hipdsp_comm_unique_id': ([_vp], _int),
     'hipdsp_comm_create': ([_vp, _vp, _int, _int, _pp], _int),
     'hipdsp_comm_destroy': ([_vp, _vp], _int),

@@ -128,6 +128,27 @@ class BufferedSpectrogram(BufferedData):
             return img.to_host()
         return decibel(self.buffer[:, channel, :].T, ref_power, min_power).astype(np.float32)
 
+    def mean_power_db(self, i0, i1, channel, floor_db=-200.0):
+        """Power spectrum of frames [i0, i1) (absolute frame indices) of one channel as
+        SpectrogramPlot.update_plot shows it (src/audian/spectrogramplot.py:158-160):
+        decibel(mean over frames), floored at -200 dB.  Device reduction when the mirror is
+        valid; returns float64 (F,)."""
+        from . import hipdsp
+        from .buffereddata import _covers
+        F = self.nfft//2 + 1
+        a, b = int(i0) - self.offset, int(i1) - self.offset
+        n = len(self._hostbuf)
+        if a < 0 or b > n or b <= a:
+            raise IndexError('range outside the loaded buffer')
+        if self._dev is not None and _covers(self._dev_valid, a, b):
+            out = hipdsp.DeviceArray(self.ctx, (F,), np.float32)
+            hipdsp.mean_spectrum_db(self.ctx, self._dev.view(channel*n*F, (1,)), F, a, b, out,
+                                    floor_db=floor_db)
+            return out.to_host().astype(np.float64)
+        power = decibel(np.mean(self.buffer[a:b, channel, :], axis=0))
+        power[power < floor_db] = floor_db
+        return power
+
     def estimate_noiselevels(self, channel):
         if not self.init or len(self._hostbuf) == 0 or len(self._hostbuf.shape) < 3:
             return None, None

@@ -149,6 +149,37 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ x
     }
 }
 
+// Power spectrum of the visible window (SpectrogramPlot.update_plot, spectrogramplot.py:158-160):
+// mean over frames of one channel's (frames, F) slab, then decibel, then the -200 dB floor.
+// Stage 1: partial[s][f] = sum over the s-th slice of frames (float64); stage 2 finishes.
+__global__ __launch_bounds__(256) void mean_spectrum_partial(const float *__restrict__ spec, long long F,
+                                                             long long i0, long long i1, int nsplit,
+                                                             double *__restrict__ partial)
+{
+    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int sidx = blockIdx.y;
+    const long long n = i1 - i0;
+    const long long a = i0 + n * sidx / nsplit, b = i0 + n * (sidx + 1) / nsplit;
+    if (f >= F) return;
+    double acc = 0.0;
+    for (long long t = a; t < b; t++) acc += (double)spec[t * F + f];
+    partial[(long long)sidx * F + f] = acc;
+}
+
+__global__ __launch_bounds__(256) void mean_spectrum_finish(const double *__restrict__ partial, long long F,
+                                                            int nsplit, double inv_n, float inv_ref,
+                                                            float min_power, float floor_db,
+                                                            float *__restrict__ out)
+{
+    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    double acc = 0.0;
+    for (int s = 0; s < nsplit; s++) acc += partial[(long long)s * F + f];
+    const float p = (float)(acc * inv_n);
+    float d = (p <= min_power) ? -INFINITY : 10.0f * log10f(p * inv_ref);
+    out[f] = d < floor_db ? floor_db : d;
+}
+
 __device__ __forceinline__ unsigned int mix64to32(unsigned long long z)
 {
     z += 0x9E3779B97F4A7C15ULL;                      // splitmix64 finaliser
@@ -301,6 +332,30 @@ int hipdsp_minmax_decimate(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, int
                            (long long)out_pitch);
     }
     return hd_launch_status("minmax_kernel");
+}
+
+int hipdsp_mean_spectrum_db(hipdsp_ctx *ctx, const float *spec_tf, int64_t nfreq, int64_t i0, int64_t i1,
+                            double ref_power, double min_power, double floor_db, float *out)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    HD_REQUIRE(nfreq >= 1 && i0 >= 0 && i1 > i0, "bad range");
+    HD_REQUIRE(ref_power > 0, "ref_power must be positive");
+    HD_REQUIRE(spec_tf != nullptr && out != nullptr, "NULL data pointer");
+    HD_CHECK_HIP(hipSetDevice(ctx->device));
+    const long long n = i1 - i0;
+    int nsplit = (int)(n < 64 ? n : 64);
+    void *work = nullptr;
+    int rc = hipdsp_scratch(ctx, sizeof(double) * (size_t)nsplit * (size_t)nfreq, &work);
+    if (rc != HIPDSP_OK) return rc;
+    unsigned gx = (unsigned)((nfreq + 255) / 256);
+    hipLaunchKernelGGL(mean_spectrum_partial, dim3(gx, (unsigned)nsplit), dim3(256), 0, ctx->stream, spec_tf,
+                       (long long)nfreq, (long long)i0, (long long)i1, nsplit, (double *)work);
+    rc = hd_launch_status("mean_spectrum_partial");
+    if (rc != HIPDSP_OK) return rc;
+    hipLaunchKernelGGL(mean_spectrum_finish, dim3(gx), dim3(256), 0, ctx->stream, (const double *)work,
+                       (long long)nfreq, nsplit, 1.0 / (double)n, (float)(1.0 / ref_power), (float)min_power,
+                       (float)floor_db, out);
+    return hd_launch_status("mean_spectrum_finish");
 }
 
 int hipdsp_synth(hipdsp_ctx *ctx, float *x, int64_t x_pitch, int64_t channels, int64_t frames, double rate,

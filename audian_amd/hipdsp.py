@@ -321,6 +321,12 @@ def minmax_decimate(ctx, x, x_pitch, channels, start, stop, step, out, out_pitch
                                      int(stop), int(step), _p(out), int(out_pitch)))
 
 
+def mean_spectrum_db(ctx, spec_tf, nfreq, i0, i1, out, ref_power=1.0, min_power=1e-20,
+                     floor_db=-200.0):
+    check(lib.hipdsp_mean_spectrum_db(ctx.handle, _p(spec_tf), int(nfreq), int(i0), int(i1),
+                                      float(ref_power), float(min_power), float(floor_db), _p(out)))
+
+
 def memcpy2d(ctx, dst, dst_pitch_bytes, src, src_pitch_bytes, width_bytes, height):
     check(lib.hipdsp_memcpy2d_d2d(ctx.handle, _p(dst), int(dst_pitch_bytes), _p(src),
                                   int(src_pitch_bytes), int(width_bytes), int(height)))

@@ -211,6 +211,15 @@ int hipdsp_minmax_decimate(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, int
                            int64_t start, int64_t stop, int64_t step, float *out,
                            int64_t out_pitch);
 
+/* Power spectrum of the visible window (SpectrogramPlot.update_plot,
+ * spectrogramplot.py:158-160):
+ *   power = np.mean(spec[i0:i1, :], axis=0); power = decibel(power); power[power < floor] = floor
+ * on one channel's (frames, nfreq) slab; out gets nfreq float32 values (floor_db = -200 in
+ * the reference).  Uses the context scratch (shared with the envelope). */
+int hipdsp_mean_spectrum_db(hipdsp_ctx *ctx, const float *spec_tf, int64_t nfreq, int64_t i0,
+                            int64_t i1, double ref_power, double min_power, double floor_db,
+                            float *out);
+
 /* ---- multi-GPU exchange ---------------------------------------- */
 
 /* One process per GPU, channels sharded in contiguous blocks of the planar layout, so

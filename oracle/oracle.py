@@ -257,3 +257,11 @@ def minmax_decimate(data, start, stop, step):
     np.minimum.reduceat(block, seg, out=out[0::2])
     np.maximum.reduceat(block, seg, out=out[1::2])
     return out
+
+
+def mean_power_db(spec_tcf, i0, i1, channel, floor_db=-200.0):
+    """SpectrogramPlot.update_plot's power spectrum (src/audian/spectrogramplot.py:158-160)."""
+    power = np.mean(np.asarray(spec_tcf, dtype=np.float64)[i0:i1, channel, :], axis=0)
+    power = decibel(power)
+    power[power < floor_db] = floor_db
+    return power

@@ -169,6 +169,11 @@ def test_scroll_update_and_recompute_match_oracle_twins(oracle):
         got = f.minmax_decimate(a, b, step, channel=1)
         want = oracle.minmax_decimate(f.buffer[:, 1], a - f.offset, b - f.offset, step)
         assert np.array_equal(got, want)
+    # visible-window power spectrum from the device mirror
+    for i0, i1 in [(s.offset, s.offset + 1), (s.offset + 2, s.offset + len(s.buffer))]:
+        got = s.mean_power_db(i0, i1, 1)
+        want = oracle.mean_power_db(s.buffer, i0 - s.offset, i1 - s.offset, 1)
+        assert got.shape == want.shape and np.max(np.abs(got - want)) < 1e-3
     zmin, zmax = s.estimate_noiselevels(0)
     assert zmin is not None and 20 <= zmax - zmin <= 80
     assert s.spec_rect == [s.offset/s.rate, 0, len(s.buffer)/s.rate, rate/2 + s.fresolution]

@@ -291,3 +291,21 @@ def test_minmax_decimation_bit_exact(oracle, step):
         assert np.array_equal(out.to_host().astype(np.float64), want.T), (step, start, stop)
     with pytest.raises(ValueError):
         hipdsp.minmax_decimate(c, dx, T, C, 10, 5, step, dx, 2)
+
+
+def test_mean_spectrum_db(oracle):
+    """decibel(mean over frames) with the -200 dB floor."""
+    from audian_amd import hipdsp
+    rng = np.random.default_rng(4)
+    c = gh.ctx()
+    for frames, F in [(1, 129), (63, 513), (1000, 1025)]:
+        spec = (10.0**rng.uniform(-24, 2, size=(frames, F))).astype(np.float32)
+        spec[:, 3] = 0.0                              # -inf -> floored
+        ds = hipdsp.DeviceArray.from_host(c, spec)
+        out = hipdsp.DeviceArray(c, (F,), np.float32)
+        for i0, i1 in [(0, frames), (frames//3, frames//3 + 1), (frames//2, frames)]:
+            hipdsp.mean_spectrum_db(c, ds, F, i0, i1, out)
+            want = oracle.mean_power_db(spec[:, None, :], i0, i1, 0)
+            got = out.to_host().astype(np.float64)
+            assert got[3] == -200.0
+            assert np.max(np.abs(got - want)) < 1e-3, (frames, F, i0, i1)
