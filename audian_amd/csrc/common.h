@@ -22,7 +22,7 @@ struct hipdsp_ctx {
     void *fft_tables2[20]; // same for the two-stage kernel: tw2 | twn | window
     int sos_waves_per_cu;  // experiments: resident waves per CU the IIR planner aims for
     int spec_no_half;      // experiments/tests: do not reuse the overlapped half frame
-    int spec_fpw, spec_flags, spec_waves, spec_kernel;   // experiments (tools/), 0 = defaults
+    int spec_fpw, spec_kernel;   // experiments (tools/), 0 = defaults
 };
 
 struct hipdsp_graph {

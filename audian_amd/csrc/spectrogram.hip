@@ -212,7 +212,7 @@ template <int NFFT, int LPF, int R1, int R2, int R3, int WAVES, bool DB, bool HA
 __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? 3 : 1) * WAVES / 4) void spec_fast_kernel(
     const float *__restrict__ x, long long x_pitch, long long n_valid, long long frames_out,
     long long out_pitch, int hop, float scale, const float *__restrict__ tables, float *__restrict__ out,
-    float *__restrict__ db_out, int frames_per_wave, int flags)
+    float *__restrict__ db_out, int frames_per_wave)
 {
     constexpr int M = NFFT / 2;
     constexpr int PPL = M / LPF;
@@ -474,7 +474,7 @@ template <int NFFT, int LPF, int R1, int R2, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void spec2_kernel(
     const float *__restrict__ x, long long x_pitch, long long n_valid, long long frames_out,
     long long out_pitch, int hop, float scale, const float *__restrict__ tables, float *__restrict__ out,
-    float *__restrict__ db_out, int frames_per_wave, int flags)
+    float *__restrict__ db_out, int frames_per_wave)
 {
     constexpr int M = NFFT / 2;
     constexpr int PPL = M / LPF;
@@ -619,7 +619,7 @@ int launch_fast(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long ch
 #define HD_SPEC_LAUNCH(DBV, HALFV)                                                                  \
     hipLaunchKernelGGL((spec_fast_kernel<NFFT, LPF, R1, R2, R3, WAVES, DBV, HALFV>), grid, block, 0,  \
                        ctx->stream, x, x_pitch, n_valid, frames_out, out_pitch, hop, scale, tables,   \
-                       out, db_out, fpw, ctx->spec_flags)
+                       out, db_out, fpw)
     if (LPF == 64 && half) {
         if (db_out) HD_SPEC_LAUNCH(true, (LPF == 64));
         else HD_SPEC_LAUNCH(false, (LPF == 64));
@@ -734,7 +734,7 @@ int run_fast2(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long chan
     long long bx = (frames_out + per_block - 1) / per_block;
     hipLaunchKernelGGL((spec2_kernel<NFFT, LPF, R1, R2, WAVES>), dim3((unsigned)bx, (unsigned)channels),
                        dim3(64 * WAVES), 0, ctx->stream, x, x_pitch, n_valid, frames_out, out_pitch, hop, scale,
-                       tables, out, db_out, fpw, ctx->spec_flags);
+                       tables, out, db_out, fpw);
     return hd_launch_status("spec2_kernel");
 }
 

@@ -275,6 +275,14 @@ def main():
     }
     dom = max(alg_bytes, key=lambda k: ms[k])
     achieved = alg_bytes[dom]/(ms[dom]*1e-3)/1e9
+    # HBM bytes per launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE x 2
+    # on gfx950, WRITE_SIZE; tools/summarize_profiles.py) -- only valid for the profiled shape
+    traffic = None
+    pmc_file = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(pmc_file):
+        pmc = json.load(open(pmc_file))
+        if pmc.get('shape') == [C, T, args.nfft, args.hop] and dom in pmc.get('kernels', {}):
+            traffic = pmc['kernels'][dom]['hbm_bytes']
     kernels = {k: {'ms': round(ms[k], 4),
                    'GBps': round(alg_bytes[k]/(ms[k]*1e-3)/1e9, 1) if k in alg_bytes and ms[k] > 0 else None}
                for k in names if k != 'allgather_tile_exposed' or multi}
@@ -312,7 +320,8 @@ def main():
             },
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved/HBM_PEAK_GBS, 4), 'traffic': None,
+                         'frac': round(achieved/HBM_PEAK_GBS, 4), 'traffic': traffic,
+                         'algorithmic_bytes': alg_bytes[dom],
                          'device_copy_GBps': round(copy_gbps, 1)},
             'kernels': kernels,
             'chain_algorithmic_GBps': round(sum(alg_bytes.values())/(dt/args.steps)/1e9, 1),

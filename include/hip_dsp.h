@@ -60,8 +60,13 @@ int hipdsp_ctx_synchronize(hipdsp_ctx *ctx);
 /* Tuning knob: upper bound on time segments per channel of the block-parallel
  * IIR (0 = automatic).  Results do not depend on it beyond fp64 rounding. */
 int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
-/* Named tuning/testing options: "max_segments" (as above), "force_generic_fft"
- * (non-zero: every nfft takes the generic radix-2 spectrogram kernel). */
+/* Named tuning/testing options (results do not depend on them beyond rounding):
+ *   "max_segments"       as hipdsp_ctx_set_max_segments
+ *   "sos_waves_per_cu"   resident waves per CU the IIR segment planner aims for (16)
+ *   "force_generic_fft"  non-zero: every nfft takes the generic radix-2 spectrogram kernel
+ *   "spec_kernel"        0 = default per size, 2 = two-stage, 3 = three-stage FFT kernel
+ *   "spec_fpw"           consecutive frames per wave (0 = automatic)
+ *   "spec_no_half"       non-zero: do not reuse the overlapped half frame at 50 % overlap */
 int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value);
 /* Pre-size the internal scratch (envelope forward pass) so that later calls do
  * not allocate; required before stream capture into a hipGraph. */

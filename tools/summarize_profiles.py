@@ -45,6 +45,14 @@ for k, cs in counters.items():
         row['hbm_bytes'] = row['hbm_read_bytes'] + row['hbm_write_bytes']
     out[k] = row
 json.dump(out, open(dst + '_pmc.json', 'w'), indent=1, sort_keys=True)
+if len(sys.argv) > 3:
+    # shape of the profiled run "C,T,nfft,hop" -> the file bench.py reads `roofline.traffic` from
+    shape = [int(v) for v in sys.argv[3].split(',')]
+    json.dump({'shape': shape, 'source': os.path.basename(dst) + '_pmc.json',
+               'kernels': {k: {'hbm_bytes': row['hbm_bytes'], 'hbm_read_bytes': row['hbm_read_bytes'],
+                               'hbm_write_bytes': row['hbm_write_bytes']}
+                           for k, row in out.items() if 'hbm_bytes' in row}},
+              open(os.path.join(os.path.dirname(dst) or '.', 'pmc_traffic.json'), 'w'), indent=1, sort_keys=True)
 for k, row in out.items():
     if 'hbm_bytes' in row:
         print(f"{k:26s} read {row['hbm_read_bytes']/1e9:7.2f} GB  write {row['hbm_write_bytes']/1e9:7.2f} GB")
