@@ -26,9 +26,8 @@ def run(nfft, hop, **opts):
     print(f'nfft {nfft} hop {hop} {opts}: {ms:.3f} ms  {gb/ms*1e3:.0f} GB/s', flush=True)
     ds.free()
 
-run(2048, 1024, spec_no_half=1)
-for nh in (0, 1, 0, 1):
-    run(2048, 1024, spec_no_half=nh)
-for nfft, hop in ((1024, 512), (4096, 2048)):
-    for nh in (0, 1):
-        run(nfft, hop, spec_no_half=nh)
+run(2048, 1024, spec_stagger=0)
+for shift in (0, 3):
+    for unit in (2, 4, 8, 16):
+        run(2048, 1024, spec_stagger=(shift << 8) | unit)
+run(2048, 1024, spec_stagger=0)
