@@ -592,6 +592,212 @@ __global__ __launch_bounds__(64 * WAVES) void spec2_kernel(
     }
 }
 
+// ---- large path: nfft = 2^14 ... 2^19 (the rest of the reference's nfft combo box,
+// src/audian/databrowser.py:516) -----------------------------------------------------
+// A frame no longer fits into LDS, so the half-length complex FFT (M = nfft/2 = N1*N2) runs
+// as Bailey's four-step algorithm over a global scratch, 16 sub-transforms per workgroup so
+// that every global access moves 128 contiguous bytes:
+//   P0  mean of every frame                                   (detrend='constant')
+//   P1  for each n2: FFT over n1 of w*(x - mean) at n = N2*n1 + n2, times W_M^(n2*k1) -> B[k1][n2]
+//   P2  for each k1: FFT over n2 of B[k1][.]                  -> Z[k1 + N1*k2]
+//   P3  split step + PSD scaling (+ dB)                       -> out
+// Twiddles come from sincospif on exact dyadic arguments.  This path is about coverage of the
+// reference's parameter range, not about the roofline: it moves ~4x the minimal bytes.
+
+constexpr int BIG_W = 16;                 // sub-transforms per workgroup
+
+__global__ __launch_bounds__(256) void big_mean_kernel(const float *__restrict__ x, long long x_pitch,
+                                                       long long frames_valid, long long item0, int nfft,
+                                                       int hop, float *__restrict__ mean)
+{
+    __shared__ double red[4];
+    const long long item = item0 + blockIdx.x;
+    const long long ch = item / frames_valid, frame = item % frames_valid;
+    const float *seg = x + ch * x_pitch + frame * (long long)hop;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nfft; i += 256) s += (double)seg[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) mean[blockIdx.x] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)nfft);
+}
+
+// BIG_W radix-2 Stockham transforms of length n (power of two) side by side in LDS:
+// element e of transform j at buf[j*n + e]; returns the buffer that holds the result.
+__device__ float2 *big_fft_lds(float2 *a, float2 *b, int n)
+{
+    const int half = n >> 1;
+    for (int Ns = 1; Ns < n; Ns <<= 1) {
+        for (int i = threadIdx.x; i < BIG_W * half; i += 256) {
+            const int j = i / half, e = i - j * half;
+            const int k = e & (Ns - 1);
+            float sn, cs;
+            sincospif(-(float)k / (float)Ns, &sn, &cs);
+            const float2 v0 = a[j * n + e], v1 = a[j * n + e + half];
+            const float2 t = make_float2(v1.x * cs - v1.y * sn, v1.x * sn + v1.y * cs);
+            const int e0 = ((e - k) << 1) + k;
+            b[j * n + e0] = make_float2(v0.x + t.x, v0.y + t.y);
+            b[j * n + e0 + Ns] = make_float2(v0.x - t.x, v0.y - t.y);
+        }
+        __syncthreads();
+        float2 *tmp = a; a = b; b = tmp;
+    }
+    return a;
+}
+
+__global__ __launch_bounds__(256) void big_pass1_kernel(const float *__restrict__ x, long long x_pitch,
+                                                        long long frames_valid, long long item0, int nfft,
+                                                        int hop, int N1, int N2, const float *__restrict__ mean,
+                                                        float2 *__restrict__ B)
+{
+    extern __shared__ float2 big_lds[];                    // 2 * BIG_W * N1
+    const long long item = item0 + blockIdx.y;
+    const long long ch = item / frames_valid, frame = item % frames_valid;
+    const float *seg = x + ch * x_pitch + frame * (long long)hop;
+    const int n2_0 = blockIdx.x * BIG_W;
+    const int M = nfft >> 1;
+    const float mu = mean[blockIdx.y];
+    float2 *a = big_lds, *b = big_lds + BIG_W * N1;
+    for (int i = threadIdx.x; i < BIG_W * N1; i += 256) {
+        const int n1 = i / BIG_W, j = i - n1 * BIG_W;
+        const int n = N2 * n1 + n2_0 + j;                  // complex sample index
+        const float x0 = seg[2 * n], x1 = seg[2 * n + 1];
+        const float w0 = 0.5f - 0.5f * cospif((float)(2 * n) / (float)M);        // 2 pi (2n) / nfft
+        const float w1 = 0.5f - 0.5f * cospif((float)(2 * n + 1) / (float)M);
+        a[j * N1 + n1] = make_float2((x0 - mu) * w0, (x1 - mu) * w1);
+    }
+    __syncthreads();
+    float2 *r = big_fft_lds(a, b, N1);
+    float2 *Bi = B + (long long)blockIdx.y * M;
+    for (int i = threadIdx.x; i < BIG_W * N1; i += 256) {
+        const int k1 = i / BIG_W, j = i - k1 * BIG_W;
+        const int n2 = n2_0 + j;
+        const int t = (int)(((long long)n2 * k1) & (M - 1));
+        float sn, cs;
+        sincospif(-2.0f * (float)t / (float)M, &sn, &cs);
+        const float2 v = r[j * N1 + k1];
+        Bi[(long long)k1 * N2 + n2] = make_float2(v.x * cs - v.y * sn, v.x * sn + v.y * cs);
+    }
+}
+
+__global__ __launch_bounds__(256) void big_pass2_kernel(const float2 *__restrict__ B, int M, int N1, int N2,
+                                                        float2 *__restrict__ Z)
+{
+    extern __shared__ float2 big_lds[];                    // 2 * BIG_W * N2
+    const int k1_0 = blockIdx.x * BIG_W;
+    const float2 *Bi = B + (long long)blockIdx.y * M;
+    float2 *a = big_lds, *b = big_lds + BIG_W * N2;
+    for (int i = threadIdx.x; i < BIG_W * N2; i += 256) {
+        const int j = i / N2, n2 = i - j * N2;
+        a[j * N2 + n2] = Bi[(long long)(k1_0 + j) * N2 + n2];
+    }
+    __syncthreads();
+    float2 *r = big_fft_lds(a, b, N2);
+    float2 *Zi = Z + (long long)blockIdx.y * M;
+    for (int i = threadIdx.x; i < BIG_W * N2; i += 256) {
+        const int k2 = i / BIG_W, j = i - k2 * BIG_W;
+        Zi[(long long)k2 * N1 + k1_0 + j] = r[j * N2 + k2];
+    }
+}
+
+__global__ __launch_bounds__(256) void big_split_kernel(const float2 *__restrict__ Z, int M,
+                                                        long long frames_valid, long long frames_out,
+                                                        long long out_pitch, long long item0, float scale,
+                                                        float *__restrict__ out, float *__restrict__ db_out)
+{
+    const long long item = item0 + blockIdx.y;
+    const long long ch = item / frames_valid, frame = item % frames_valid;
+    const long long F = (long long)M + 1;
+    float *o = out + ch * out_pitch + frame * F;
+    float *od = db_out ? db_out + ch * out_pitch + frame * F : nullptr;
+    const float2 *Zi = Z + (long long)blockIdx.y * M;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k > M / 2) return;
+    const float2 zk = Zi[k];
+    const float2 zm = Zi[(M - k) & (M - 1)];
+    float pk, pm;
+    if (k == 0) {
+        const float a = zk.x + zk.y, b = zk.x - zk.y;
+        pk = a * a * scale;
+        pm = b * b * scale;
+    } else {
+        float sn, cs;
+        sincospif(-(float)k / (float)M, &sn, &cs);         // exp(-2 pi i k / nfft)
+        const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+        const float2 od2 = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
+        const float2 t = make_float2(od2.x * cs - od2.y * sn, od2.x * sn + od2.y * cs);
+        const float2 a = make_float2(e.x + t.x, e.y + t.y), b = make_float2(e.x - t.x, e.y - t.y);
+        pk = 2.f * scale * (a.x * a.x + a.y * a.y);
+        pm = 2.f * scale * (b.x * b.x + b.y * b.y);
+    }
+    o[k] = pk;
+    if (od) od[k] = to_db(pk);
+    if (k != M - k) {
+        o[M - k] = pm;
+        if (od) od[M - k] = to_db(pm);
+    }
+}
+
+__global__ void big_zero_tail_kernel(float *__restrict__ out, float *__restrict__ db_out, long long out_pitch,
+                                     long long F, long long frames_valid, long long frames_out)
+{
+    const long long ch = blockIdx.y;
+    const long long n = (frames_out - frames_valid) * F;
+    float *o = out + ch * out_pitch + frames_valid * F;
+    float *od = db_out ? db_out + ch * out_pitch + frames_valid * F : nullptr;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        o[i] = 0.f;
+        if (od) od[i] = -INFINITY;
+    }
+}
+
+int run_big(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long channels, long long n_valid,
+            long long frames_out, long long out_pitch, int nfft, int hop, float scale, float *out, float *db_out)
+{
+    const int M = nfft / 2;
+    int m = 0;
+    while ((1 << m) < M) m++;
+    const int N1 = 1 << ((m + 1) / 2), N2 = 1 << (m / 2);
+    const long long F = (long long)M + 1;
+    if (frames_out > n_valid) {
+        hipLaunchKernelGGL(big_zero_tail_kernel, dim3(256, (unsigned)channels), dim3(256), 0, ctx->stream, out, db_out,
+                           out_pitch, F, n_valid, frames_out);
+        int rc = hd_launch_status("big_zero_tail_kernel");
+        if (rc != HIPDSP_OK) return rc;
+    }
+    const long long items = channels * n_valid;
+    if (items == 0) return HIPDSP_OK;
+    // scratch: mean | B | Z for one batch of (channel, frame) items, at most ~512 MiB
+    long long batch = (512LL << 20) / (16LL * M + 4);
+    if (batch < 1) batch = 1;
+    if (batch > items) batch = items;
+    if (batch > 65535) batch = 65535;
+    const size_t off_b = (size_t)((batch * 4 + 255) / 256 * 256);
+    const size_t bytes = off_b + 2 * (size_t)batch * (size_t)M * sizeof(float2);
+    void *work = nullptr;
+    int rc = hipdsp_scratch(ctx, bytes, &work);
+    if (rc != HIPDSP_OK) return rc;
+    float *mean = (float *)work;
+    float2 *B = (float2 *)((char *)work + off_b);
+    float2 *Z = B + (size_t)batch * M;
+    const size_t lds1 = 2 * (size_t)BIG_W * N1 * sizeof(float2), lds2 = 2 * (size_t)BIG_W * N2 * sizeof(float2);
+    HD_CHECK_HIP(hipFuncSetAttribute((const void *)big_pass1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    HD_CHECK_HIP(hipFuncSetAttribute((const void *)big_pass2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    for (long long item0 = 0; item0 < items; item0 += batch) {
+        const unsigned nb = (unsigned)(items - item0 < batch ? items - item0 : batch);
+        hipLaunchKernelGGL(big_mean_kernel, dim3(nb), dim3(256), 0, ctx->stream, x, x_pitch, n_valid, item0, nfft, hop, mean);
+        hipLaunchKernelGGL(big_pass1_kernel, dim3((unsigned)(N2 / BIG_W), nb), dim3(256), lds1, ctx->stream, x, x_pitch,
+                           n_valid, item0, nfft, hop, N1, N2, mean, B);
+        hipLaunchKernelGGL(big_pass2_kernel, dim3((unsigned)(N1 / BIG_W), nb), dim3(256), lds2, ctx->stream, B, M, N1, N2, Z);
+        hipLaunchKernelGGL(big_split_kernel, dim3((unsigned)((M / 2 + 1 + 255) / 256), nb), dim3(256), 0, ctx->stream, Z, M,
+                           n_valid, frames_out, out_pitch, item0, scale, out, db_out);
+        rc = hd_launch_status("big spectrogram kernels");
+        if (rc != HIPDSP_OK) return rc;
+    }
+    return HIPDSP_OK;
+}
+
 // Consecutive frames one wave (lane group) walks: long runs amortise the table load
 // and keep the 50 % overlap in cache, short runs keep small inputs spread over the chip.
 int frames_per_wave(const hipdsp_ctx *ctx, long long channels, long long frames_out, int G)
@@ -760,8 +966,8 @@ extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pit
     HD_REQUIRE(nfft >= 8, "nfft %d < 8", nfft);
     HD_REQUIRE(hop >= 1 && hop <= nfft, "hop %d not in [1, nfft=%d]", hop, nfft);
     HD_REQUIRE(fs > 0, "fs must be positive");
-    if ((nfft & (nfft - 1)) != 0 || nfft > 8192) {
-        hipdsp_set_error("nfft %d: only powers of two in [8, 8192] are implemented", nfft);
+    if ((nfft & (nfft - 1)) != 0 || nfft > (1 << 19)) {
+        hipdsp_set_error("nfft %d: only powers of two in [8, 524288] are implemented", nfft);
         return HIPDSP_ERR_UNSUPPORTED;
     }
     if (channels == 0 || frames_out == 0) return HIPDSP_OK;
@@ -804,6 +1010,8 @@ extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pit
             return run_fast<4096, 64, 16, 16, 8, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
         }
     }
+    if (nfft > 8192)
+        return run_big(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, nfft, hop, scale, out, db_out);
     size_t lds = sizeof(float2) * 2 * (size_t)nfft;
     if (lds > 48 * 1024)
         HD_CHECK_HIP(hipFuncSetAttribute((const void *)spec_generic_kernel,

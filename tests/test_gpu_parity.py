@@ -309,3 +309,29 @@ def test_mean_spectrum_db(oracle):
             got = out.to_host().astype(np.float64)
             assert got[3] == -200.0
             assert np.max(np.abs(got - want)) < 1e-3, (frames, F, i0, i1)
+
+
+@pytest.mark.parametrize('nfft,hop,nframes', [(16384, 8192, 5), (32768, 4096, 4), (65536, 16384, 3),
+                                              (262144, 131072, 3), (524288, 262144, 2)])
+def test_spectrogram_large_nfft_four_step(oracle, nfft, hop, nframes):
+    """The upper part of the reference's nfft selector (2^14 .. 2^19, databrowser.py:516):
+    four-step FFT through the context scratch, with a zero tail and the fused dB output."""
+    rng = np.random.default_rng(nfft)
+    rate = 96000.0
+    T = (nframes - 1)*hop + nfft + 3
+    x = (synth(rng, T, 2, rate) + np.float32(0.2)).astype(np.float32)
+    nd = (T + hop - 1)//hop
+    want = np.zeros((nd, 2, nfft//2 + 1))
+    oracle.spectrogram_process(x.astype(np.float64), want, rate, nfft, hop)
+    got, db = gh.gpu_spectrogram(x, rate, nfft, hop, nd, want_db=True)
+    assert got.shape == want.shape
+    for ch in range(2):
+        for j in range(nd):
+            if np.max(np.abs(want[j, ch])) == 0:
+                assert np.all(got[j, ch] == 0) and np.all(db[j, ch] == -np.inf)
+            else:
+                assert rel_err(got[j, ch], want[j, ch]) < TOL, (nfft, j, ch)
+    fin = got > 1e-20
+    assert np.max(np.abs(db[fin] - 10*np.log10(got[fin]))) < 1e-3
+    with pytest.raises(NotImplementedError):
+        gh.gpu_spectrogram(x, rate, 1 << 20, 1 << 19, 1)
