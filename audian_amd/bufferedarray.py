@@ -185,3 +185,60 @@ class ArrayLoader(BufferedArray):
 
     def load_buffer(self, offset, nframes, buffer):
         buffer[:, :] = self.data[offset:offset + nframes, :]
+
+
+class WavLoader(BufferedArray):
+    """A PCM WAV file behind the BufferedArray interface (stdlib ``wave``): stands in for
+    ``thunderlab.dataloader.DataLoader`` on plain WAV recordings such as the reference's
+    ``data/Gryllus_campestris.wav``.  Samples become float64 in [-1, 1) exactly as audioio
+    scales them (integer / 2**(bits-1)); ``pcm_slab`` additionally hands the file's own
+    bytes to the device path (``hipdsp_pcm_unpack``)."""
+
+    def __init__(self, path, buffer_time=60.0, back_time=20.0, unit='a.u.', verbose=0):
+        import wave
+        super().__init__(verbose)
+        self._wav = wave.open(path, 'rb')
+        if self._wav.getcomptype() != 'NONE' or self._wav.getsampwidth() not in (2, 3, 4):
+            raise ValueError('only uncompressed 16/24/32-bit PCM WAV files are supported')
+        self.filepath = path
+        self.sample_bytes = self._wav.getsampwidth()
+        self.scale = 1.0/float(1 << (8*self.sample_bytes - 1))
+        self.rate = float(self._wav.getframerate())
+        self.channels = self._wav.getnchannels()
+        self.frames = self._wav.getnframes()
+        self.shape = (self.frames, self.channels)
+        self.ndim = 2
+        self.size = self.frames*self.channels
+        self.unit = unit
+        self.ampl_min, self.ampl_max = -1.0, 1.0
+        self.bufferframes = min(self.frames, int(buffer_time*self.rate))
+        self.backframes = int(back_time*self.rate)
+        self.buffer_changed = np.zeros(self.channels, dtype=bool)
+        self.buffer = np.zeros((0, self.channels))
+        self.name = 'data'
+        self.dests = []
+        self.need_update = False
+        self.plot_items = [None]*self.channels
+        self.move_buffer(0, self.bufferframes)
+
+    def pcm_slab(self, offset, nframes):
+        """Raw interleaved bytes of frames [offset, offset + nframes) as a uint8 array."""
+        self._wav.setpos(int(offset))
+        raw = self._wav.readframes(int(nframes))
+        return np.frombuffer(raw, dtype=np.uint8)
+
+    def load_buffer(self, offset, nframes, buffer):
+        raw = self.pcm_slab(offset, nframes)
+        nb = self.sample_bytes
+        if nb == 2:
+            ints = raw.view('<i2').astype(np.int64)
+        elif nb == 4:
+            ints = raw.view('<i4').astype(np.int64)
+        else:
+            b = raw.reshape(-1, 3).astype(np.int64)
+            ints = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+            ints = np.where(ints >= 1 << 23, ints - (1 << 24), ints)
+        buffer[:, :] = ints.reshape(-1, self.channels)*self.scale
+
+    def close(self):
+        self._wav.close()

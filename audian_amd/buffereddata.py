@@ -203,6 +203,14 @@ class BufferedData(BufferedArray):
         if call is not None and isinstance(src, BufferedData) and src._stale:
             source = src.buffer[call.soffset:call.soffset + call.snframes]     # flushes
         n = len(source)
+        if call is not None and n > 0 and hasattr(src, 'pcm_slab'):
+            # the loader can hand over the file's own integers: upload those (2-4 bytes per
+            # sample instead of 8) and convert on the device
+            raw = src.pcm_slab(src.offset + call.soffset, n)
+            up = hipdsp.DeviceArray.from_host(self.ctx, raw)
+            planar = hipdsp.DeviceArray(self.ctx, (max(1, src.channels), n), np.float32)
+            hipdsp.pcm_unpack(self.ctx, up, src.sample_bytes, n, src.channels, src.scale, planar, n)
+            return planar, n, up
         dtype = np.float32 if source.dtype == np.float32 else np.float64
         host = np.ascontiguousarray(source.reshape(n, -1), dtype=dtype)
         up = hipdsp.DeviceArray.from_host(self.ctx, host)

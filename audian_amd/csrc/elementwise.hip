@@ -94,6 +94,39 @@ __global__ void unpack_spectrum_kernel(const float *__restrict__ src, long long 
     for (long long f = threadIdx.x; f < F; f += blockDim.x) d[f] = (double)s[f];
 }
 
+// Ingest: interleaved little-endian signed PCM (frames, channels) with 2, 3 or 4
+// bytes per sample -> planar float32 (channels, pitch) scaled by `scale` (1/2^(bits-1) gives
+// the [-1, 1) floats that audioio/thunderlab's DataLoader hands to audian, data.py:172).
+template <int BYTES>
+__global__ __launch_bounds__(256) void pcm_unpack_kernel(const unsigned char *__restrict__ pcm,
+                                                         float *__restrict__ dst, long long pitch,
+                                                         long long T, long long C, float scale)
+{
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long long t0 = (long long)blockIdx.x * 32, c0 = (long long)blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const long long t = t0 + ty + 8 * k, c = c0 + tx;
+        float v = 0.f;
+        if (t < T && c < C) {
+            const unsigned char *p = pcm + (t * C + c) * BYTES;
+            int iv;
+            if (BYTES == 2) iv = (int)(short)((unsigned)p[0] | ((unsigned)p[1] << 8));
+            else if (BYTES == 3) iv = ((int)(((unsigned)p[0] << 8) | ((unsigned)p[1] << 16) | ((unsigned)p[2] << 24))) >> 8;
+            else iv = (int)((unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16) | ((unsigned)p[3] << 24));
+            v = (float)((double)iv * (double)scale);
+        }
+        tile[ty + 8 * k][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const long long c = c0 + ty + 8 * k, t = t0 + tx;
+        if (t < T && c < C) dst[c * pitch + t] = tile[tx][ty + 8 * k];
+    }
+}
+
 // np.minimum / np.maximum semantics: a NaN in either operand wins
 __device__ __forceinline__ float np_min(float a, float b) { return (a < b || a != a) ? a : b; }
 __device__ __forceinline__ float np_max(float a, float b) { return (a > b || a != a) ? a : b; }
@@ -307,6 +340,27 @@ int hipdsp_unpack_spectrum_f64(hipdsp_ctx *ctx, const float *src, int64_t src_pi
                        ctx->stream, src, (long long)src_pitch, dst_tcf, (long long)frames,
                        (long long)channels, (long long)nfreq);
     return hd_launch_status("unpack_spectrum_kernel");
+}
+
+int hipdsp_pcm_unpack(hipdsp_ctx *ctx, const void *pcm_tc, int sample_bytes, int64_t frames, int64_t channels,
+                      double scale, float *dst, int64_t dst_pitch)
+{
+    int rc = pack_check(ctx, pcm_tc, dst, dst_pitch, frames, channels);
+    if (rc != HIPDSP_OK || frames == 0 || channels == 0) return rc;
+    dim3 grid((unsigned)((frames + 31) / 32), (unsigned)((channels + 31) / 32));
+    const unsigned char *p = (const unsigned char *)pcm_tc;
+    switch (sample_bytes) {
+    case 2: hipLaunchKernelGGL(pcm_unpack_kernel<2>, grid, dim3(256), 0, ctx->stream, p, dst, (long long)dst_pitch,
+                               (long long)frames, (long long)channels, (float)scale); break;
+    case 3: hipLaunchKernelGGL(pcm_unpack_kernel<3>, grid, dim3(256), 0, ctx->stream, p, dst, (long long)dst_pitch,
+                               (long long)frames, (long long)channels, (float)scale); break;
+    case 4: hipLaunchKernelGGL(pcm_unpack_kernel<4>, grid, dim3(256), 0, ctx->stream, p, dst, (long long)dst_pitch,
+                               (long long)frames, (long long)channels, (float)scale); break;
+    default:
+        hipdsp_set_error("sample_bytes %d: signed PCM of 2, 3 or 4 bytes only", sample_bytes);
+        return HIPDSP_ERR_UNSUPPORTED;
+    }
+    return hd_launch_status("pcm_unpack_kernel");
 }
 
 int hipdsp_minmax_decimate(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, int64_t channels,

@@ -316,6 +316,11 @@ def unpack_spectrum(ctx, src, dst_tcf, frames, channels, nfreq, src_pitch=0):
                                          int(frames), int(channels), int(nfreq)))
 
 
+def pcm_unpack(ctx, pcm_tc, sample_bytes, frames, channels, scale, dst, dst_pitch):
+    check(lib.hipdsp_pcm_unpack(ctx.handle, _p(pcm_tc), int(sample_bytes), int(frames), int(channels),
+                                float(scale), _p(dst), int(dst_pitch)))
+
+
 def minmax_decimate(ctx, x, x_pitch, channels, start, stop, step, out, out_pitch):
     check(lib.hipdsp_minmax_decimate(ctx.handle, _p(x), int(x_pitch), int(channels), int(start),
                                      int(stop), int(step), _p(out), int(out_pitch)))

@@ -218,6 +218,13 @@ int hipdsp_minmax_decimate(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, int
                            int64_t start, int64_t stop, int64_t step, float *out,
                            int64_t out_pitch);
 
+/* PCM ingest: interleaved little-endian signed PCM (frames, channels) of 2, 3 or 4 bytes per
+ * sample -> planar float32 times `scale` (1/2^(bits-1) reproduces the [-1, 1) floats that
+ * audioio / thunderlab's DataLoader give audian, data.py:172).  Uploading the file's own
+ * integers instead of float64 cuts the PCIe volume of the raw slab 2.7-4x. */
+int hipdsp_pcm_unpack(hipdsp_ctx *ctx, const void *pcm_tc, int sample_bytes, int64_t frames,
+                      int64_t channels, double scale, float *dst, int64_t dst_pitch);
+
 /* Power spectrum of the visible window (SpectrogramPlot.update_plot,
  * spectrogramplot.py:158-160):
  *   power = np.mean(spec[i0:i1, :], axis=0); power = decibel(power); power[power < floor] = floor

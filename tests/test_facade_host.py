@@ -255,3 +255,40 @@ def test_minmax_decimate_host_path():
     assert t.minmax_decimate(t.offset, t.offset + 1000, 7).shape == (2, 2*143)
     with pytest.raises(IndexError):
         t.minmax_decimate(t.offset, t.offset + len(t.buffer) + 1, 4)
+
+
+def _write_wav(path, data_int, nbytes, rate):
+    import wave
+    w = wave.open(str(path), 'wb')
+    w.setnchannels(data_int.shape[1])
+    w.setsampwidth(nbytes)
+    w.setframerate(int(rate))
+    if nbytes == 2:
+        raw = data_int.astype('<i2').tobytes()
+    elif nbytes == 4:
+        raw = data_int.astype('<i4').tobytes()
+    else:
+        u = (data_int.astype(np.int64) & 0xFFFFFF).reshape(-1)
+        raw = np.stack([u & 255, (u >> 8) & 255, (u >> 16) & 255], axis=1).astype(np.uint8).tobytes()
+    w.writeframes(raw)
+    w.close()
+
+
+@pytest.mark.parametrize('nbytes', [2, 3, 4])
+def test_wav_loader_scales_like_audioio(tmp_path, nbytes):
+    from audian_amd.bufferedarray import WavLoader
+    rng = np.random.default_rng(nbytes)
+    bits = 8*nbytes
+    ints = rng.integers(-(1 << (bits - 1)), 1 << (bits - 1), size=(5000, 3))
+    ints[0] = [-(1 << (bits - 1)), (1 << (bits - 1)) - 1, 0]
+    path = tmp_path/'x.wav'
+    _write_wav(path, ints, nbytes, 8000)
+    w = WavLoader(str(path), buffer_time=0.25, back_time=0.05)
+    assert (w.rate, w.channels, w.frames, w.shape) == (8000.0, 3, 5000, (5000, 3))
+    want = ints/float(1 << (bits - 1))
+    assert np.array_equal(w[0:100, :], want[0:100])
+    assert np.array_equal(w[4000:4500, 1], want[4000:4500, 1])       # moves the buffer
+    assert w.offset > 0 and w[4999, 2] == want[4999, 2]
+    raw = w.pcm_slab(10, 4)
+    assert raw.dtype == np.uint8 and len(raw) == 4*3*nbytes
+    w.close()

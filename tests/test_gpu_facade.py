@@ -263,3 +263,76 @@ def test_process_as_plain_function_on_host_arrays(oracle):
     s.nfft, s.hop = 100, 50
     with pytest.raises(NotImplementedError):
         s.process(x, np.zeros((10, 2, 51)), 0)
+
+
+def test_wav_recording_through_pcm_ingest(oracle, tmp_path, monkeypatch):
+    """configs[0]-style run from an actual PCM WAV: the raw slab is uploaded as the file's
+    own integers and converted on the device; results equal the float path."""
+    import wave
+    from audian_amd import hipdsp
+    from audian_amd.bufferedarray import WavLoader
+    from audian_amd.bufferedfilter import BufferedFilter
+    from audian_amd.bufferedspectrogram import BufferedSpectrogram
+    rate = 44100
+    x = recording(float(rate), 3.0, 1, seed=9)
+    ints = np.round(x*20000).astype(np.int64)
+    for nbytes in (2, 3):
+        path = tmp_path/f'rec{nbytes}.wav'
+        w = wave.open(str(path), 'wb')
+        w.setnchannels(1); w.setsampwidth(nbytes); w.setframerate(rate)
+        if nbytes == 2:
+            w.writeframes(ints.astype('<i2').tobytes())
+        else:
+            u = ((ints << 8) & 0xFFFFFF).reshape(-1)
+            w.writeframes(np.stack([u & 255, (u >> 8) & 255, (u >> 16) & 255], axis=1).astype(np.uint8).tobytes())
+        w.close()
+        src = WavLoader(str(path), buffer_time=10.0, back_time=0.0)
+        calls = []
+        real = hipdsp.pcm_unpack
+        monkeypatch.setattr(hipdsp, 'pcm_unpack', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        f = BufferedFilter()
+        f.open(src)
+        f.plot_items = [Item()]
+        s = BufferedSpectrogram(nfft=256)
+        s.open(f)
+        s.plot_items = [Item()]
+        f.set_need_update()
+        f.highpass_cutoff, f.lowpass_cutoff = 300.0, 3000.0
+        f.update()
+        f.align_buffer()
+        s.align_buffer()
+        assert calls, 'the raw PCM path was not taken'
+        xs = src.buffer
+        want = np.zeros_like(xs)
+        oracle.filter_process(f.sos, xs, want, 0)
+        assert rel_err(f.buffer[:, 0], want[:len(f.buffer), 0]) < TOL
+        wspec = np.zeros_like(s.buffer)
+        oracle.spectrogram_process(want, wspec, float(rate), 256, 128)
+        for k in range(len(wspec) - 1):
+            assert rel_err(s.buffer[k, 0], wspec[k, 0]) < TOL
+        src.close()
+        monkeypatch.undo()
+
+
+def test_pcm_unpack_bit_exact():
+    from audian_amd import hipdsp
+    import gpu_helpers as gh
+    rng = np.random.default_rng(8)
+    c = gh.ctx()
+    T, C = 3001, 5
+    for nbytes in (2, 3, 4):
+        bits = 8*nbytes
+        ints = rng.integers(-(1 << (bits - 1)), 1 << (bits - 1), size=(T, C))
+        if nbytes == 2:
+            raw = np.frombuffer(ints.astype('<i2').tobytes(), dtype=np.uint8)
+        elif nbytes == 4:
+            raw = np.frombuffer(ints.astype('<i4').tobytes(), dtype=np.uint8)
+        else:
+            u = (ints & 0xFFFFFF).reshape(-1)
+            raw = np.stack([u & 255, (u >> 8) & 255, (u >> 16) & 255], axis=1).astype(np.uint8).reshape(-1)
+        up = hipdsp.DeviceArray.from_host(c, raw)
+        dst = hipdsp.DeviceArray(c, (C, T), np.float32)
+        scale = 1.0/float(1 << (bits - 1))
+        hipdsp.pcm_unpack(c, up, nbytes, T, C, scale, dst, T)
+        want = (ints*scale).astype(np.float32).T
+        assert np.array_equal(dst.to_host(), want), nbytes
