@@ -150,14 +150,33 @@ class BufferedSpectrogram(BufferedData):
         return power
 
     def estimate_noiselevels(self, channel):
+        """Colour range for the spectrogram image (bufferedspectrogram.py:109-126): 95th
+        percentile of the dB values in the top 1/16 of the band, and the maximum dB.  With a
+        valid device mirror only the top-band slab (a strided device gather) and one scalar
+        (device max reduction; dB is monotonic) cross PCIe instead of the whole slab."""
         if not self.init or len(self._hostbuf) == 0 or len(self._hostbuf.shape) < 3:
             return None, None
-        nf = self._hostbuf.shape[2]//16
+        from . import hipdsp
+        from .buffereddata import _covers
+        F = self._hostbuf.shape[2]
+        n = len(self._hostbuf)
+        nf = F//16
         if nf < 1:
             nf = 1
-        with np.errstate(all='ignore'):
-            zmin = np.percentile(decibel(self.buffer[:, channel, -nf:]), 95)
-        zmax = np.max(decibel(self.buffer[:, channel, :]))
+        if self._dev is not None and _covers(self._dev_valid, 0, n) and self._stale:
+            base = self._dev.view(channel*n*F, (1,))
+            band = hipdsp.DeviceArray(self.ctx, (n, nf), np.float32)
+            hipdsp.memcpy2d(self.ctx, band, 4*nf, self._dev.view(channel*n*F + F - nf, (1,)), 4*F,
+                            4*nf, n)
+            top = hipdsp.DeviceArray(self.ctx, (1,), np.float32)
+            hipdsp.max_nonneg(self.ctx, base, n*F, top)
+            with np.errstate(all='ignore'):
+                zmin = np.percentile(decibel(band.to_host()), 95)
+            zmax = decibel(float(top.to_host()[0]))
+        else:
+            with np.errstate(all='ignore'):
+                zmin = np.percentile(decibel(self.buffer[:, channel, -nf:]), 95)
+            zmax = np.max(decibel(self.buffer[:, channel, :]))
         if not np.isfinite(zmin) or not np.isfinite(zmax):
             return None, None
         self.init = False

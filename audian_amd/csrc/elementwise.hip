@@ -127,6 +127,25 @@ __global__ __launch_bounds__(256) void pcm_unpack_kernel(const unsigned char *__
     }
 }
 
+// Maximum of a non-negative float array (PSD values): per-wave reduction, then one integer
+// atomicMax per wave on the bit pattern (order-preserving for floats >= 0).
+__global__ __launch_bounds__(256) void max_nonneg_kernel(const float *__restrict__ x, long long n,
+                                                         unsigned int *__restrict__ out)
+{
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        m = (v > m || v != v) ? v : m;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float o = __shfl_xor(m, d, 64);
+        m = (o > m || o != o) ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
 // np.minimum / np.maximum semantics: a NaN in either operand wins
 __device__ __forceinline__ float np_min(float a, float b) { return (a < b || a != a) ? a : b; }
 __device__ __forceinline__ float np_max(float a, float b) { return (a > b || a != a) ? a : b; }
@@ -340,6 +359,19 @@ int hipdsp_unpack_spectrum_f64(hipdsp_ctx *ctx, const float *src, int64_t src_pi
                        ctx->stream, src, (long long)src_pitch, dst_tcf, (long long)frames,
                        (long long)channels, (long long)nfreq);
     return hd_launch_status("unpack_spectrum_kernel");
+}
+
+int hipdsp_max_nonneg(hipdsp_ctx *ctx, const float *x, int64_t n, float *out)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    HD_REQUIRE(n >= 0 && out != nullptr, "bad argument");
+    HD_CHECK_HIP(hipSetDevice(ctx->device));
+    HD_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float), ctx->stream));
+    if (n == 0) return HIPDSP_OK;
+    HD_REQUIRE(x != nullptr, "NULL data pointer");
+    hipLaunchKernelGGL(max_nonneg_kernel, dim3(grid1d(n, 1024, 4096)), dim3(256), 0, ctx->stream, x, (long long)n,
+                       (unsigned int *)out);
+    return hd_launch_status("max_nonneg_kernel");
 }
 
 int hipdsp_pcm_unpack(hipdsp_ctx *ctx, const void *pcm_tc, int sample_bytes, int64_t frames, int64_t channels,

@@ -316,6 +316,10 @@ def unpack_spectrum(ctx, src, dst_tcf, frames, channels, nfreq, src_pitch=0):
                                          int(frames), int(channels), int(nfreq)))
 
 
+def max_nonneg(ctx, x, n, out):
+    check(lib.hipdsp_max_nonneg(ctx.handle, _p(x), int(n), _p(out)))
+
+
 def pcm_unpack(ctx, pcm_tc, sample_bytes, frames, channels, scale, dst, dst_pitch):
     check(lib.hipdsp_pcm_unpack(ctx.handle, _p(pcm_tc), int(sample_bytes), int(frames), int(channels),
                                 float(scale), _p(dst), int(dst_pitch)))

@@ -218,6 +218,11 @@ int hipdsp_minmax_decimate(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, int
                            int64_t start, int64_t stop, int64_t step, float *out,
                            int64_t out_pitch);
 
+/* Maximum of n non-negative floats (PSD values) into out[0]; with the strided gather of
+ * hipdsp_memcpy2d_d2d it serves BufferedSpectrogram.estimate_noiselevels
+ * (bufferedspectrogram.py:109-126: max dB = decibel(max power), P95 of the top 1/16 band). */
+int hipdsp_max_nonneg(hipdsp_ctx *ctx, const float *x, int64_t n, float *out);
+
 /* PCM ingest: interleaved little-endian signed PCM (frames, channels) of 2, 3 or 4 bytes per
  * sample -> planar float32 times `scale` (1/2^(bits-1) reproduces the [-1, 1) floats that
  * audioio / thunderlab's DataLoader give audian, data.py:172).  Uploading the file's own

@@ -174,8 +174,23 @@ def test_scroll_update_and_recompute_match_oracle_twins(oracle):
         got = s.mean_power_db(i0, i1, 1)
         want = oracle.mean_power_db(s.buffer, i0 - s.offset, i1 - s.offset, 1)
         assert got.shape == want.shape and np.max(np.abs(got - want)) < 1e-3
+    # colour range: device gather + max reduction must equal the reference's host formula
+    s.reload_buffer()                  # host copy stale again -> the device path is taken
+    assert s._stale
     zmin, zmax = s.estimate_noiselevels(0)
+    assert s._stale                    # ... and it did not pull the whole slab back
     assert zmin is not None and 20 <= zmax - zmin <= 80
+    nf = s.buffer.shape[2]//16
+    with np.errstate(all='ignore'):
+        rmin = np.percentile(oracle.decibel(s.buffer[:, 0, -nf:]), 95)
+    rmax = np.max(oracle.decibel(s.buffer[:, 0, :]))
+    rmax = rmin + 0.95*(rmax - rmin)
+    if rmax - rmin < 20:
+        rmax = rmin + 20
+    if rmax - rmin > 80:
+        rmin = rmax - 80
+    assert abs(zmin - rmin) < 1e-3 and abs(zmax - rmax) < 1e-3
+    assert s.estimate_noiselevels(0) == (None, None)      # only once per trace (init flag)
     assert s.spec_rect == [s.offset/s.rate, 0, len(s.buffer)/s.rate, rate/2 + s.fresolution]
 
 
