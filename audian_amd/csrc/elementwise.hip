@@ -127,6 +127,38 @@ __global__ __launch_bounds__(256) void pcm_unpack_kernel(const unsigned char *__
     }
 }
 
+// Playback chain (DataBrowser.play_region, databrowser.py:1711-1729): mean over a group of
+// channels of frames [start, start + n), optionally times the heterodyne carrier
+// sin(2 pi f k / rate) with k counted from the start of the region.
+struct ChannelList {
+    int count;
+    int idx[64];
+};
+
+__global__ void channel_mean_kernel(const float *__restrict__ x, long long pitch, ChannelList ch, long long start,
+                                    long long n, double cycles_per_sample, float *__restrict__ out)
+{
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+         k += (long long)gridDim.x * blockDim.x) {
+        double acc = 0.0;
+        for (int c = 0; c < ch.count; c++) acc += (double)x[(long long)ch.idx[c] * pitch + start + k];
+        float v = (float)(acc / (double)ch.count);
+        if (cycles_per_sample != 0.0) {
+            double ph = cycles_per_sample * (double)k;
+            ph -= floor(ph);
+            v *= sinpif(2.0f * (float)ph);
+        }
+        out[k] = v;
+    }
+}
+
+__global__ void stride_copy_kernel(const float *__restrict__ x, long long step, long long m, float *__restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m;
+         i += (long long)gridDim.x * blockDim.x)
+        out[i] = x[i * step];
+}
+
 // Maximum of a non-negative float array (PSD values): per-wave reduction, then one integer
 // atomicMax per wave on the bit pattern (order-preserving for floats >= 0).
 __global__ __launch_bounds__(256) void max_nonneg_kernel(const float *__restrict__ x, long long n,
@@ -359,6 +391,37 @@ int hipdsp_unpack_spectrum_f64(hipdsp_ctx *ctx, const float *src, int64_t src_pi
                        ctx->stream, src, (long long)src_pitch, dst_tcf, (long long)frames,
                        (long long)channels, (long long)nfreq);
     return hd_launch_status("unpack_spectrum_kernel");
+}
+
+int hipdsp_channel_mean(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, const int *host_channels, int count,
+                        int64_t start, int64_t n, double heterodyne_cycles_per_sample, float *out)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    HD_REQUIRE(count >= 1 && count <= 64, "1..64 channels per group, got %d", count);
+    HD_REQUIRE(start >= 0 && n >= 0 && x_pitch >= start + n, "bad range");
+    if (n == 0) return HIPDSP_OK;
+    HD_REQUIRE(x != nullptr && out != nullptr && host_channels != nullptr, "NULL pointer");
+    HD_CHECK_HIP(hipSetDevice(ctx->device));
+    ChannelList cl;
+    cl.count = count;
+    for (int i = 0; i < 64; i++) cl.idx[i] = i < count ? host_channels[i] : 0;
+    for (int i = 0; i < count; i++) HD_REQUIRE(cl.idx[i] >= 0, "negative channel index");
+    hipLaunchKernelGGL(channel_mean_kernel, dim3(grid1d(n, 256, 4096)), dim3(256), 0, ctx->stream, x,
+                       (long long)x_pitch, cl, (long long)start, (long long)n, heterodyne_cycles_per_sample, out);
+    return hd_launch_status("channel_mean_kernel");
+}
+
+int hipdsp_stride_copy(hipdsp_ctx *ctx, const float *x, int64_t n, int64_t step, float *out)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    HD_REQUIRE(n >= 0 && step >= 1, "bad argument");
+    const long long m = (n + step - 1) / step;
+    if (m == 0) return HIPDSP_OK;
+    HD_REQUIRE(x != nullptr && out != nullptr, "NULL data pointer");
+    HD_CHECK_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(stride_copy_kernel, dim3(grid1d(m, 256, 4096)), dim3(256), 0, ctx->stream, x,
+                       (long long)step, m, out);
+    return hd_launch_status("stride_copy_kernel");
 }
 
 int hipdsp_max_nonneg(hipdsp_ctx *ctx, const float *x, int64_t n, float *out)

@@ -316,6 +316,16 @@ def unpack_spectrum(ctx, src, dst_tcf, frames, channels, nfreq, src_pitch=0):
                                          int(frames), int(channels), int(nfreq)))
 
 
+def channel_mean(ctx, x, x_pitch, channels, start, n, out, heterodyne_cycles_per_sample=0.0):
+    arr = (ctypes.c_int*len(channels))(*[int(c) for c in channels])
+    check(lib.hipdsp_channel_mean(ctx.handle, _p(x), int(x_pitch), arr, len(channels), int(start),
+                                  int(n), float(heterodyne_cycles_per_sample), _p(out)))
+
+
+def stride_copy(ctx, x, n, step, out):
+    check(lib.hipdsp_stride_copy(ctx.handle, _p(x), int(n), int(step), _p(out)))
+
+
 def max_nonneg(ctx, x, n, out):
     check(lib.hipdsp_max_nonneg(ctx.handle, _p(x), int(n), _p(out)))
 

@@ -218,6 +218,16 @@ int hipdsp_minmax_decimate(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, int
                            int64_t start, int64_t stop, int64_t step, float *out,
                            int64_t out_pitch);
 
+/* Playback chain (DataBrowser.play_region, databrowser.py:1711-1729): out[k] = mean over the
+ * listed channels of x[c, start + k], k < n, optionally times the heterodyne carrier
+ * sin(2 pi k * heterodyne_cycles_per_sample) (0 = none).  The low-pass that follows is
+ * hipdsp_envelope(rectify = 0, clamp = 0), i.e. plain sosfiltfilt, and `[::nstep]` is
+ * hipdsp_stride_copy (out[i] = x[i*step], ceil(n/step) values). */
+int hipdsp_channel_mean(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, const int *host_channels,
+                        int count, int64_t start, int64_t n, double heterodyne_cycles_per_sample,
+                        float *out);
+int hipdsp_stride_copy(hipdsp_ctx *ctx, const float *x, int64_t n, int64_t step, float *out);
+
 /* Maximum of n non-negative floats (PSD values) into out[0]; with the strided gather of
  * hipdsp_memcpy2d_d2d it serves BufferedSpectrogram.estimate_noiselevels
  * (bufferedspectrogram.py:109-126: max dB = decibel(max power), P95 of the top 1/16 band). */

@@ -265,3 +265,24 @@ def mean_power_db(spec_tcf, i0, i1, channel, floor_db=-200.0):
     power = decibel(power)
     power[power < floor_db] = floor_db
     return power
+
+
+def play_data(data, rate, i0, i1, show_channels, heterodyne_freq=None, sos=None):
+    """DataBrowser.play_region's arithmetic (src/audian/databrowser.py:1711-1727) on a (T, C)
+    array: channel-group means, optional heterodyne * sin, sosfiltfilt with `sos`
+    (= butter(2, 20000, 'low', fs=rate)), [::nstep]."""
+    n2 = (len(show_channels) + 1)//2
+    playdata = np.zeros((i1 - i0, min(2, len(show_channels))))
+    playdata[:, 0] = np.mean(data[i0:i1, show_channels[:n2]], 1)
+    if len(show_channels) > 1:
+        playdata[:, 1] = np.mean(data[i0:i1, show_channels[n2:]], 1)
+    if heterodyne_freq:
+        heterodyne = np.sin(2*np.pi*heterodyne_freq*np.arange(len(playdata))/rate)
+        playdata = (playdata.T*heterodyne).T
+        fcutoff = 20000.0
+        nstep = int(np.round(rate/(2*fcutoff)))
+        if nstep < 1:
+            nstep = 1
+        playdata = sosfiltfilt(sos, playdata)[::nstep]
+        rate /= nstep
+    return playdata, rate

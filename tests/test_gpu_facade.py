@@ -351,3 +351,31 @@ def test_pcm_unpack_bit_exact():
         hipdsp.pcm_unpack(c, up, nbytes, T, C, scale, dst, T)
         want = (ints*scale).astype(np.float32).T
         assert np.array_equal(dst.to_host(), want), nbytes
+
+
+def test_playback_chain_matches_reference_arithmetic(oracle):
+    """DataBrowser.play_region (channel means, heterodyne, zero-phase 20 kHz
+    low-pass, down-sampling) from the filtered trace's device mirror."""
+    from audian_amd.bufferedfilter import BufferedFilter
+    from audian_amd.bufferedenvelope import BufferedEnvelope
+    from audian_amd.bufferedspectrogram import BufferedSpectrogram
+    from audian_amd.design import butter_sos
+    from audian_amd.playback import play_data
+    rate = 192000.0
+    x = recording(rate, 4.0, 4, seed=21)
+    g = build((BufferedFilter, BufferedEnvelope, BufferedSpectrogram), x, rate, 4.0, 0.0, nfft=256)
+    f = g['filtered']
+    f.highpass_cutoff, f.lowpass_cutoff = 2000.0, 60000.0
+    f.update()
+    g.update_times(0.0, 3.0)
+    ref = f.buffer.copy()
+    sos = butter_sos(2, 20000.0, 'lowpass', rate)
+    for chans, het in [([0, 1, 2, 3], None), ([2], None), ([0, 2, 3], 40000.0), ([1, 3], 25000.0)]:
+        f.reload_buffer()                       # device mirror valid, host stale
+        got, grate = play_data(f, 0.5, 2.25, chans, heterodyne_freq=het)
+        i0, i1 = int(round(0.5*rate)) - f.offset, int(round(2.25*rate)) - f.offset
+        want, wrate = oracle.play_data(ref, rate, i0, i1, chans, het, sos)
+        assert got.shape == want.shape and grate == wrate
+        for k in range(want.shape[1]):
+            assert rel_err(got[:, k], want[:, k]) < TOL, (chans, het, k)
+    assert grate == rate/5                      # round(192000 / 40000) = 5
