@@ -159,11 +159,12 @@ __global__ void stride_copy_kernel(const float *__restrict__ x, long long step, 
         out[i] = x[i * step];
 }
 
-// Maximum of a non-negative float array (PSD values): per-wave reduction, then one integer
-// atomicMax per wave on the bit pattern (order-preserving for floats >= 0).
+// Maximum of a non-negative float array (PSD values): workgroup reduction, then one integer
+// atomicMax per workgroup on the bit pattern (order-preserving for floats >= 0).
 __global__ __launch_bounds__(256) void max_nonneg_kernel(const float *__restrict__ x, long long n,
                                                          unsigned int *__restrict__ out)
 {
+    __shared__ float red[4];
     float m = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
@@ -175,7 +176,12 @@ __global__ __launch_bounds__(256) void max_nonneg_kernel(const float *__restrict
         const float o = __shfl_xor(m, d, 64);
         m = (o > m || o != o) ? o : m;
     }
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) m = (red[w] > m || red[w] != red[w]) ? red[w] : m;
+        atomicMax(out, __float_as_uint(m));
+    }
 }
 
 // np.minimum / np.maximum semantics: a NaN in either operand wins
@@ -185,51 +191,41 @@ __device__ __forceinline__ float np_max(float a, float b) { return (a > b || a !
 // Screen-resolution decimation of traces (TraceItem.update_plot, src/audian/traceitem.py:55-61;
 // compresseddata.py:48-52): out[c][2i] = min, out[c][2i+1] = max of x[c][start + i*step :
 // min(start + (i+1)*step, stop)]  (np.minimum/maximum.reduceat over arange(0, stop-start, step)).
-// WIDE: one wave per segment, lanes stride over it (step >= 64); else one lane per segment.
-template <bool WIDE>
+// A group of GL lanes (a power of two >= min(step, 64)) owns a segment and strides over it, so
+// a wave always reads (nearly) contiguous memory whatever the step; 64/GL segments per wave.
+template <int GL>
 __global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ x, long long pitch,
                                                      long long start, long long stop, long long step,
                                                      long long nseg, float *__restrict__ out,
                                                      long long out_pitch)
 {
+    constexpr int SPW = 64 / GL;                       // segments per wave
     const long long c = blockIdx.y;
     const float *row = x + c * pitch;
     float *orow = out + c * out_pitch;
-    if (WIDE) {
-        const int lane = threadIdx.x & 63;
-        const long long waves = (long long)gridDim.x * 4;
-        for (long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); i < nseg; i += waves) {
-            const long long lo = start + i * step;
-            long long hi = lo + step;
-            if (hi > stop) hi = stop;
-            float mn = row[lo], mx = mn;            // every segment has at least one sample
-            for (long long j = lo + lane; j < hi; j += 64) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane / GL, l = lane % GL;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long waves = (long long)gridDim.x * 4;
+    for (long long i0 = wave * SPW; i0 < nseg; i0 += waves * SPW) {
+        const long long i = i0 + g;
+        const bool active = i < nseg;
+        const long long lo = start + (active ? i : 0) * step;
+        long long hi = lo + step;
+        if (hi > stop) hi = stop;
+        float mn = row[lo], mx = mn;                   // every segment has at least one sample
+        if (active)
+            for (long long j = lo + l; j < hi; j += GL) {
                 const float v = row[j];
                 mn = np_min(v, mn);
                 mx = np_max(v, mx);
             }
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                mn = np_min(__shfl_xor(mn, d, 64), mn);
-                mx = np_max(__shfl_xor(mx, d, 64), mx);
-            }
-            if (lane == 0) { orow[2 * i] = mn; orow[2 * i + 1] = mx; }
+        for (int d = GL / 2; d >= 1; d >>= 1) {
+            mn = np_min(__shfl_xor(mn, d, 64), mn);
+            mx = np_max(__shfl_xor(mx, d, 64), mx);
         }
-    } else {
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nseg;
-             i += (long long)gridDim.x * blockDim.x) {
-            const long long lo = start + i * step;
-            long long hi = lo + step;
-            if (hi > stop) hi = stop;
-            float mn = row[lo], mx = mn;
-            for (long long j = lo + 1; j < hi; j++) {
-                const float v = row[j];
-                mn = np_min(v, mn);
-                mx = np_max(v, mx);
-            }
-            orow[2 * i] = mn;
-            orow[2 * i + 1] = mx;
-        }
+        if (active && l == 0) { orow[2 * i] = mn; orow[2 * i + 1] = mx; }
     }
 }
 
@@ -432,7 +428,7 @@ int hipdsp_max_nonneg(hipdsp_ctx *ctx, const float *x, int64_t n, float *out)
     HD_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float), ctx->stream));
     if (n == 0) return HIPDSP_OK;
     HD_REQUIRE(x != nullptr, "NULL data pointer");
-    hipLaunchKernelGGL(max_nonneg_kernel, dim3(grid1d(n, 1024, 4096)), dim3(256), 0, ctx->stream, x, (long long)n,
+    hipLaunchKernelGGL(max_nonneg_kernel, dim3(grid1d(n, 4096, 1024)), dim3(256), 0, ctx->stream, x, (long long)n,
                        (unsigned int *)out);
     return hd_launch_status("max_nonneg_kernel");
 }
@@ -469,17 +465,25 @@ int hipdsp_minmax_decimate(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, int
     HD_REQUIRE(x_pitch >= stop && out_pitch >= 2 * nseg, "pitch too small");
     HD_REQUIRE(channels <= 65535, "too many channels");
     HD_CHECK_HIP(hipSetDevice(ctx->device));
-    if (step >= 64) {
-        unsigned gx = grid1d(nseg, 4, 16384);
-        hipLaunchKernelGGL(minmax_kernel<true>, dim3(gx, (unsigned)channels), dim3(256), 0, ctx->stream, x,
-                           (long long)x_pitch, (long long)start, (long long)stop, (long long)step, nseg, out,
-                           (long long)out_pitch);
-    } else {
-        unsigned gx = grid1d(nseg, 256, 16384);
-        hipLaunchKernelGGL(minmax_kernel<false>, dim3(gx, (unsigned)channels), dim3(256), 0, ctx->stream, x,
-                           (long long)x_pitch, (long long)start, (long long)stop, (long long)step, nseg, out,
-                           (long long)out_pitch);
+    int gl = 1;                                      // steps up to 8: one lane per segment
+    if (step > 8)
+        while (gl < 64 && gl < step) gl <<= 1;
+    const long long spw = 64 / gl;
+    unsigned gx = grid1d((nseg + spw - 1) / spw, 4, 16384);
+    dim3 grid(gx, (unsigned)channels), block(256);
+#define HD_MINMAX(GLV)                                                                                   \
+    hipLaunchKernelGGL(minmax_kernel<GLV>, grid, block, 0, ctx->stream, x, (long long)x_pitch, (long long)start, \
+                       (long long)stop, (long long)step, nseg, out, (long long)out_pitch)
+    switch (gl) {
+    case 1: HD_MINMAX(1); break;
+    case 2: HD_MINMAX(2); break;
+    case 4: HD_MINMAX(4); break;
+    case 8: HD_MINMAX(8); break;
+    case 16: HD_MINMAX(16); break;
+    case 32: HD_MINMAX(32); break;
+    default: HD_MINMAX(64); break;
     }
+#undef HD_MINMAX
     return hd_launch_status("minmax_kernel");
 }
 
