@@ -200,93 +200,15 @@ __global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *__restri
         }
         __syncthreads();
 
-        // ---- phase 1: zero-state end state of this lane's L samples
-        double f[D];
-#pragma unroll
-        for (int r = 0; r < D; r++) f[r] = 0.0;
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const SosPlanDev *P = PLAN();
-            const float4 v = lds[lds_slot(lane, q)];
-            const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const double xd = (double)e[k];
-#pragma unroll
-                for (int r = 0; r < D; r++) f[r] = fma(P->G[4 * q + k][r], xd, f[r]);
-            }
-        }
-        // fold the tile's incoming state into lane 0: P_0 = A^L carry + f_0
-        {
-            const SosPlanDev *P = PLAN();
-            double t[D];
-#pragma unroll
-            for (int r = 0; r < D; r++) {
-                double acc = 0.0;
-#pragma unroll
-                for (int c = 0; c < D; c++) acc = fma(P->M[0][r][c], carry[c], acc);
-                t[r] = acc;
-            }
-#pragma unroll
-            for (int r = 0; r < D; r++) f[r] += (lane == 0) ? t[r] : 0.0;
-        }
-        // ---- inclusive scan over lanes: P_i += A^(L*d) P_(i-d)
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const SosPlanDev *P = PLAN();
-            const int d = 1 << k;
-            double q[D];
-#pragma unroll
-            for (int c = 0; c < D; c++) {
-                double s = __shfl_up(f[c], d, 64);
-                q[c] = (lane >= d) ? s : 0.0;
-            }
-#pragma unroll
-            for (int r = 0; r < D; r++) {
-                double acc = f[r];
-#pragma unroll
-                for (int c = 0; c < D; c++) acc = fma(P->M[k][r][c], q[c], acc);
-                f[r] = acc;
-            }
-        }
-        // state at the start of this lane's samples, and the tile's outgoing state
-        double z[D];
-#pragma unroll
-        for (int r = 0; r < D; r++) {
-            double s = __shfl_up(f[r], 1, 64);
-            z[r] = (lane == 0) ? carry[r] : s;
-        }
-#pragma unroll
-        for (int r = 0; r < D; r++) carry[r] = __shfl(f[r], 63, 64);
-
-        // ---- phase 3: the cascade itself (scipy _sosfilt order: samples outer, sections
-        // inner); the lane re-reads its row from LDS and overwrites it with the outputs
-        {
-            const SosPlanDev *P = PLAN();
-            double cf[S][5];
-#pragma unroll
-            for (int s = 0; s < S; s++)
-#pragma unroll
-                for (int k = 0; k < 5; k++) cf[s][k] = P->coef[s][k];
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const float4 v = lds[lds_slot(lane, q)];
-                float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    double cur = (double)e[k];
-#pragma unroll
-                    for (int s = 0; s < S; s++) {
-                        double y = fma(cf[s][0], cur, z[2 * s]);
-                        z[2 * s] = fma(-cf[s][3], y, fma(cf[s][1], cur, z[2 * s + 1]));
-                        z[2 * s + 1] = fma(-cf[s][4], y, cf[s][2] * cur);
-                        cur = y;
-                    }
-                    e[k] = (float)cur;
-                }
-                lds[lds_slot(lane, q)] = make_float4(e[0], e[1], e[2], e[3]);
-            }
-        }
+#define CASC_S S
+#define CASC_PLAN() PLAN()
+#define CASC_CARRY carry
+#define CASC_IN(v) (v)
+#include "sos_cascade.inc"
+#undef CASC_S
+#undef CASC_PLAN
+#undef CASC_CARRY
+#undef CASC_IN
         __syncthreads();
         if (tile + TILE > lo) {      // warm-up tiles produce no output
 #pragma unroll
@@ -298,6 +220,202 @@ __global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *__restri
         }
         __syncthreads();
     }
+}
+
+// ---- fused band-pass + envelope forward pass ----------------------------------------
+// Batch chains (whole slab: filter -> envelope of the SAME slab) re-read the filtered trace
+// only to rectify it and run the envelope's forward pass.  This kernel does both cascades
+// on the tile while it is in LDS: read x once, write the filtered trace and the forward
+// scratch (12 B per sample instead of 8 + 8).  The backward pass stays the plain
+// MODE_ENV_BWD launch.  Sequence handling of scipy's sosfiltfilt in sample coordinates:
+//   * left odd extension: `edge` serial steps before tile 0 from zi * ext[0] (wave-uniform);
+//   * right odd extension: the samples T .. T+edge-1 of the last tile(s) are replaced by the
+//     extension values, so the cascade itself produces the padded outputs;
+//   * scratch index = sample index + edge, exactly what the backward kernel expects.
+struct FusedArgs {
+    const float *in;
+    float *yf, *w;
+    long long in_pitch, yf_pitch, w_pitch;
+    long long T, seg_len;
+    int n_seg, edge, rectify;
+    float gain;
+};
+
+__device__ __forceinline__ int lds_float_index(int s) { return lds_slot(s >> 5, (s & 31) >> 2) * 4 + (s & 3); }
+
+template <int SF, int SE>
+__global__ __launch_bounds__(64) void sos_fused_kernel(const SosPlanDev *__restrict__ PF0,
+                                                       const SosPlanDev *__restrict__ PE0, FusedArgs a)
+{
+#define PLANF() (reinterpret_cast<const SosPlanDev *>(reinterpret_cast<const char *>(PF0) + opaque_zero()))
+#define PLANE() (reinterpret_cast<const SosPlanDev *>(reinterpret_cast<const char *>(PE0) + opaque_zero()))
+    constexpr int DF = 2 * SF, DE = 2 * SE;
+    __shared__ float4 lds[64 * 8];
+    __shared__ float rprev[64];            // rectified samples of the previous tile's last two rows
+    float *ldsf = reinterpret_cast<float *>(lds);
+    const int lane = threadIdx.x;
+    const int seg = blockIdx.x % a.n_seg;
+    const long long ch = blockIdx.x / a.n_seg;
+    const float *in = a.in + ch * a.in_pitch;
+    float *yf = a.yf + ch * a.yf_pitch;
+    float *w = a.w + ch * a.w_pitch;
+    const long long T = a.T;
+    const int edge = a.edge;
+
+    const long long lo = (long long)seg * a.seg_len;
+    long long hi = lo + a.seg_len;
+    const bool last_seg = hi >= T;
+    if (hi > T) hi = T;
+    long long env_start = lo - PE0->warm;
+    const bool env_true = env_start <= 0;
+    if (env_start < 0) env_start = 0;
+    long long start = env_start - PF0->warm;
+    if (start < 0) start = 0;               // zero state at sample 0 is the filter's true state
+    const long long loop_end = last_seg ? T + edge : hi;   // the right extension may need a tile more
+
+    double cf_[DF], ce_[DE];
+#pragma unroll
+    for (int r = 0; r < DF; r++) cf_[r] = 0.0;
+#pragma unroll
+    for (int r = 0; r < DE; r++) ce_[r] = 0.0;
+    rprev[lane] = 0.f;
+
+    for (long long tile = start; tile < loop_end; tile += TILE) {
+        // ---- x tile -> LDS
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const long long p = tile + 256 * k + 4 * lane;
+            float4 v;
+            if (p + 4 <= T) {
+                f4u t = *reinterpret_cast<const f4u *>(in + p);
+                v = make_float4(t.x, t.y, t.z, t.w);
+            } else {
+                v.x = p < T ? in[p] : 0.f;
+                v.y = p + 1 < T ? in[p + 1] : 0.f;
+                v.z = p + 2 < T ? in[p + 2] : 0.f;
+                v.w = p + 3 < T ? in[p + 3] : 0.f;
+            }
+            lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = v;
+        }
+        __syncthreads();
+        // ---- band-pass cascade: rows now hold the filtered samples
+#define CASC_S SF
+#define CASC_PLAN() PLANF()
+#define CASC_CARRY cf_
+#define CASC_IN(v) (v)
+#include "sos_cascade.inc"
+#undef CASC_S
+#undef CASC_PLAN
+#undef CASC_CARRY
+#undef CASC_IN
+        __syncthreads();
+        if (tile + TILE > lo && tile < hi) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const long long p = tile + 256 * k + 4 * lane;
+                const float4 v = lds[lds_slot(8 * k + (lane >> 3), lane & 7)];
+                if (p >= lo && p + 4 <= hi) {
+                    f4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+                    *reinterpret_cast<f4u *>(yf + p) = t;
+                } else {
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (p + q >= lo && p + q < hi) yf[p + q] = e[q];
+                }
+            }
+        }
+        if (tile < env_start) { __syncthreads(); continue; }    // band-pass warm-up only
+
+        // ---- envelope input in place: r = gain*|y|, then the odd extension past T
+        if (a.rectify) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                float4 v = lds[lds_slot(lane, q)];
+                v = make_float4(a.gain * fabsf(v.x), a.gain * fabsf(v.y), a.gain * fabsf(v.z), a.gain * fabsf(v.w));
+                lds[lds_slot(lane, q)] = v;
+            }
+        }
+        __syncthreads();
+        auto rval = [&](long long j) -> float {          // r(j) for j in this tile or the row before it
+            return j >= tile ? ldsf[lds_float_index((int)(j - tile))] : rprev[64 - (int)(tile - j)];
+        };
+        if (tile + TILE > T) {
+            // ext[T + i] = 2 r(T-1) - r(T-2-i), i < edge (scipy odd_ext); zeros beyond
+            float pv = 0.f;
+            long long pj = -1;
+            if (lane < edge) {
+                pj = T + lane;
+                if (pj >= tile && pj < tile + TILE) pv = 2.f * rval(T - 1) - rval(T - 2 - lane);
+            }
+            __syncthreads();
+            if (lane < edge && pj >= tile && pj < tile + TILE) ldsf[lds_float_index((int)(pj - tile))] = pv;
+            __syncthreads();
+        }
+        if (env_true && tile == 0) {
+            // left odd extension: ext[i] = 2 r(0) - r(edge - i), i < edge, from zi * ext[0];
+            // wave-uniform serial steps, lane 0 stores the padded outputs
+            const SosPlanDev *P = PLANE();
+            const float r0 = ldsf[lds_float_index(0)];
+            const double x0 = (double)(2.f * r0 - ldsf[lds_float_index(edge)]);
+#pragma unroll
+            for (int r = 0; r < DE; r++) ce_[r] = P->zi[r] * x0;
+            for (int i = 0; i < edge; i++) {
+                double cur = (double)(2.f * r0 - ldsf[lds_float_index(edge - i)]);
+#pragma unroll
+                for (int s2 = 0; s2 < SE; s2++) {
+                    const double y = fma(P->coef[s2][0], cur, ce_[2 * s2]);
+                    ce_[2 * s2] = fma(-P->coef[s2][3], y, fma(P->coef[s2][1], cur, ce_[2 * s2 + 1]));
+                    ce_[2 * s2 + 1] = fma(-P->coef[s2][4], y, P->coef[s2][2] * cur);
+                    cur = y;
+                }
+                if (lane == 0) w[i] = (float)cur;
+            }
+        }
+        // keep the last two rows for an extension that reaches back over the tile border
+        {
+            const float4 keep0 = lds[lds_slot(62 + ((lane >> 3) & 1), lane & 7)];
+            __syncthreads();
+            if (lane < 16) {
+                rprev[4 * lane] = keep0.x; rprev[4 * lane + 1] = keep0.y;
+                rprev[4 * lane + 2] = keep0.z; rprev[4 * lane + 3] = keep0.w;
+            }
+        }
+        // ---- envelope forward cascade
+#define CASC_S SE
+#define CASC_PLAN() PLANE()
+#define CASC_CARRY ce_
+#define CASC_IN(v) (v)
+#include "sos_cascade.inc"
+#undef CASC_S
+#undef CASC_PLAN
+#undef CASC_CARRY
+#undef CASC_IN
+        __syncthreads();
+        {
+            // scratch index = sample + edge; this wave owns samples [lo, hi) (+ the extension)
+            const long long wlo = lo, whi = last_seg ? T + edge : hi;
+            if (tile + TILE > wlo) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const long long p = tile + 256 * k + 4 * lane;
+                    const float4 v = lds[lds_slot(8 * k + (lane >> 3), lane & 7)];
+                    if (p >= wlo && p + 4 <= whi) {
+                        f4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+                        *reinterpret_cast<f4u *>(w + p + edge) = t;
+                    } else {
+                        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (p + q >= wlo && p + q < whi) w[p + q + edge] = e[q];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#undef PLANF
+#undef PLANE
 }
 
 // pass-through / zero fill for the sos-is-None branches
@@ -644,6 +762,70 @@ int hipdsp_sosfilt(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const float *x, 
     a.T = frames; a.N = frames; a.skip = skip; a.edge = 0; a.rectify = 0; a.gain = 1.f; a.clamp = 0;
     return launch_scan<MODE_FILT>(ctx, plan, plan->dev, plan->host->n_sections, a, channels,
                                   plan->host->warm);
+}
+
+int hipdsp_sosfilt_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hipdsp_sosplan *eplan,
+                            const float *x, int64_t x_pitch, float *yf, int64_t yf_pitch, float *env,
+                            int64_t env_pitch, int64_t channels, int64_t frames, int rectify, double gain,
+                            int clamp, int phase)
+{
+    HD_REQUIRE(ctx != nullptr && fplan != nullptr && eplan != nullptr, "NULL argument");
+    HD_REQUIRE(phase >= 0 && phase <= 2, "phase must be 0 (both), 1 (forward) or 2 (backward)");
+    HD_REQUIRE(channels >= 0 && frames >= 0, "negative size");
+    HD_REQUIRE(fplan->host->n_sections > 0 && eplan->host->n_sections > 0, "plan has no coefficients");
+    HD_CHECK_HIP(hipSetDevice(ctx->device));
+    const int edge = eplan->host->edge;
+    if (frames <= edge) {
+        hipdsp_set_error("The length of the input vector x must be greater than padlen, which is %d.", edge);
+        return HIPDSP_ERR_TOO_SHORT;
+    }
+    if (channels == 0) return HIPDSP_OK;
+    HD_REQUIRE(x != nullptr && yf != nullptr && env != nullptr, "NULL data pointer");
+    HD_REQUIRE(x_pitch >= frames && yf_pitch >= frames && env_pitch >= frames, "pitch smaller than row length");
+    const long long N = frames + 2LL * edge;
+    const long long wpitch = (N + 3) / 4 * 4;
+    void *work = nullptr;
+    int rc = hipdsp_scratch(ctx, sizeof(float) * (size_t)wpitch * (size_t)channels, &work);
+    if (rc != HIPDSP_OK) return rc;
+    FusedArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.in = x; fa.yf = yf; fa.w = (float *)work;
+    fa.in_pitch = x_pitch; fa.yf_pitch = yf_pitch; fa.w_pitch = wpitch;
+    fa.T = frames; fa.edge = edge; fa.rectify = rectify; fa.gain = (float)gain;
+    long long warm = fplan->host->warm + eplan->host->warm;
+    if (fplan->host->warm >= (1LL << 40) || eplan->host->warm >= (1LL << 40)) warm = 1LL << 50;
+    plan_segments(ctx, frames, channels, warm, &fa.seg_len, &fa.n_seg);
+    long long blocks = channels * fa.n_seg;
+    HD_REQUIRE(blocks <= 0x7fffffffLL, "grid too large");
+    dim3 grid((unsigned)blocks), block(64);
+    const int SF = fplan->host->n_sections, SE = eplan->host->n_sections;
+    if (phase != 2) {
+#define HD_FUSED(A, B)                                                                                  \
+    case (A) * 8 + (B):                                                                                 \
+        hipLaunchKernelGGL((sos_fused_kernel<A, B>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, fa); \
+        break
+    switch (SF * 8 + SE) {
+        HD_FUSED(1, 1); HD_FUSED(1, 2); HD_FUSED(1, 3); HD_FUSED(1, 4);
+        HD_FUSED(2, 1); HD_FUSED(2, 2); HD_FUSED(2, 3); HD_FUSED(2, 4);
+        HD_FUSED(3, 1); HD_FUSED(3, 2); HD_FUSED(3, 3); HD_FUSED(3, 4);
+        HD_FUSED(4, 1); HD_FUSED(4, 2); HD_FUSED(4, 3); HD_FUSED(4, 4);
+    default:
+        hipdsp_set_error("n_sections %d / %d not in 1..%d", SF, SE, MAXS);
+        return HIPDSP_ERR_UNSUPPORTED;
+    }
+#undef HD_FUSED
+    rc = hd_launch_status("sos_fused_kernel");
+    if (rc != HIPDSP_OK) return rc;
+    }
+    if (phase == 1) return HIPDSP_OK;
+    if (ctx->mid_event) HD_CHECK_HIP(hipEventRecord(ctx->mid_event, ctx->stream));
+    // backward pass over the reversed scratch -> env (trim the padding, clamp)
+    SeqArgs a;
+    memset(&a, 0, sizeof(a));
+    a.T = frames; a.N = N; a.skip = 0; a.edge = edge;
+    a.rectify = rectify; a.gain = (float)gain; a.clamp = clamp;
+    a.in = (const float *)work; a.in_pitch = wpitch; a.out = env; a.out_pitch = env_pitch;
+    return launch_scan<MODE_ENV_BWD>(ctx, eplan, eplan->dev, SE, a, channels, eplan->host->warm);
 }
 
 int hipdsp_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const float *x, int64_t x_pitch,

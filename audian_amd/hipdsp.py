@@ -284,6 +284,14 @@ def envelope(ctx, plan, x, x_pitch, y, y_pitch, channels, frames, skip=0, rectif
                               float(gain), int(bool(clamp))))
 
 
+def sosfilt_envelope(ctx, fplan, eplan, x, x_pitch, yf, yf_pitch, env, env_pitch, channels, frames,
+                     rectify=True, gain=np.pi/2, clamp=True, phase=0):
+    check(lib.hipdsp_sosfilt_envelope(ctx.handle, fplan.handle, eplan.handle, _p(x), int(x_pitch),
+                                      _p(yf), int(yf_pitch), _p(env), int(env_pitch), int(channels),
+                                      int(frames), int(bool(rectify)), float(gain), int(bool(clamp)),
+                                      int(phase)))
+
+
 def spectrogram(ctx, x, x_pitch, channels, frames, nfft, hop, fs, out, frames_out, db_out=None,
                 out_pitch=0):
     check(lib.hipdsp_spectrogram(ctx.handle, _p(x), int(x_pitch), int(channels), int(frames),

@@ -55,6 +55,9 @@ def parse():
                          "multi-rank path on a one-GPU box")
     ap.add_argument('--same-device', action='store_true',
                     help='rehearsal: every rank uses GPU 0 (needs --backend gloo)')
+    ap.add_argument('--no-fuse', action='store_true',
+                    help='four launches (band-pass, spectrogram, envelope forward, backward) instead '
+                         'of fusing the envelope forward pass into the band-pass kernel')
     ap.add_argument('--force-dist', action='store_true',
                     help='rehearsal: take the multi-rank code path even with one rank')
     return ap.parse_args()
@@ -204,11 +207,19 @@ def main():
     events = [[ctx.event() for _ in range(n_ev)] for _ in range(args.steps)]
     mids = [ctx.event() for _ in range(args.steps)]
 
+    fused = not args.no_fuse
+
     def step(i):
         ev = events[i] if i >= 0 else None
         if ev:
             ctx.record(ev[0])
-        hipdsp.sosfilt(ctx, plan, dx, T, df, T, C, T, 0)
+        if fused:
+            # band-pass + envelope forward in one pass over x (filtered trace written once,
+            # not re-read); the backward pass follows after the spectrogram
+            hipdsp.sosfilt_envelope(ctx, plan, eplan, dx, T, df, T, de, T, C, T, rectify=True,
+                                    gain=np.pi/2, clamp=True, phase=1)
+        else:
+            hipdsp.sosfilt(ctx, plan, dx, T, df, T, C, T, 0)
         if ev:
             ctx.record(ev[1])
         hipdsp.spectrogram(ctx, df, T, C, T, args.nfft, args.hop, args.rate, ds, nd)
@@ -225,7 +236,14 @@ def main():
                 allgather_tiles(tile_buf.cpu(), world*C, out=merged)
         if ev:
             ctx.set_mid_event(mids[i])
-        hipdsp.envelope(ctx, eplan, df, T, de, T, C, T, 0, rectify=True, gain=np.pi/2, clamp=True)
+        if fused:
+            if ev:
+                ctx.record(mids[i])
+            ctx.set_mid_event(None)
+            hipdsp.sosfilt_envelope(ctx, plan, eplan, dx, T, df, T, de, T, C, T, rectify=True,
+                                    gain=np.pi/2, clamp=True, phase=2)
+        else:
+            hipdsp.envelope(ctx, eplan, df, T, de, T, C, T, 0, rectify=True, gain=np.pi/2, clamp=True)
         if ev:
             ctx.set_mid_event(None)
             ctx.record(ev[3])
@@ -255,8 +273,12 @@ def main():
         dt = float(tt.item())
 
     # per-kernel averages from the HIP events recorded inside the timed region
-    names = ['sos_scan<S=%d,filt>' % len(sos), 'spectrogram', 'sos_scan<S=%d,env_fwd>' % len(esos),
-             'sos_scan<S=%d,env_bwd>' % len(esos), 'allgather_tile_exposed']
+    if fused:
+        names = ['sos_fused<S=%d+%d,filt+env_fwd>' % (len(sos), len(esos)), 'spectrogram', 'tile_copy+gather_issue',
+                 'sos_scan<S=%d,env_bwd>' % len(esos), 'allgather_tile_exposed']
+    else:
+        names = ['sos_scan<S=%d,filt>' % len(sos), 'spectrogram', 'sos_scan<S=%d,env_fwd>' % len(esos),
+                 'sos_scan<S=%d,env_bwd>' % len(esos), 'allgather_tile_exposed']
     ms = dict.fromkeys(names, 0.0)
     for i in range(args.steps):
         e = events[i]
@@ -267,12 +289,19 @@ def main():
         ms[names[4]] += ctx.elapsed_ms(e[3], e[4])
     for k in ms:
         ms[k] /= args.steps
-    alg_bytes = {                       # algorithmic HBM bytes per launch
-        names[0]: 8.0*C*T,
-        names[1]: 4.0*C*T + 4.0*C*nd*F,
-        names[2]: 8.0*C*(T + 2*edge),
-        names[3]: 8.0*C*T + 4.0*C*2*edge,
-    }
+    if fused:
+        alg_bytes = {                   # algorithmic HBM bytes per launch
+            names[0]: 12.0*C*T + 4.0*C*2*edge,         # x read, filtered + forward scratch written
+            names[1]: 4.0*C*T + 4.0*C*nd*F,
+            names[3]: 8.0*C*T + 4.0*C*2*edge,
+        }
+    else:
+        alg_bytes = {
+            names[0]: 8.0*C*T,
+            names[1]: 4.0*C*T + 4.0*C*nd*F,
+            names[2]: 8.0*C*(T + 2*edge),
+            names[3]: 8.0*C*T + 4.0*C*2*edge,
+        }
     dom = max(alg_bytes, key=lambda k: ms[k])
     achieved = alg_bytes[dom]/(ms[dom]*1e-3)/1e9
     # HBM bytes per launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE x 2
@@ -285,7 +314,7 @@ def main():
             traffic = pmc['kernels'][dom]['hbm_bytes']
     kernels = {k: {'ms': round(ms[k], 4),
                    'GBps': round(alg_bytes[k]/(ms[k]*1e-3)/1e9, 1) if k in alg_bytes and ms[k] > 0 else None}
-               for k in names if k != 'allgather_tile_exposed' or multi}
+               for k in names if k in alg_bytes or multi}
 
     parity = None
     cpu = None
@@ -317,6 +346,7 @@ def main():
                                (f', all-gather of the {args.tile_seconds:g} s spectrogram tile'
                                 if world > 1 else ''),
                 'iir_warmup_samples': {'bandpass': warm_f, 'envelope': warm_e},
+                'envelope_forward': 'fused into the band-pass kernel' if fused else 'own launch',
             },
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

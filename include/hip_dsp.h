@@ -178,6 +178,23 @@ int hipdsp_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const float *x,
                     int64_t x_pitch, float *y, int64_t y_pitch, int64_t channels,
                     int64_t frames, int64_t skip, int rectify, double gain, int clamp);
 
+/* Batch form of the two calls above for a whole slab (the envelope is taken of the SAME
+ * frames the filter produces, skip = 0):
+ *   yf  = sosfilt(fplan, x)                          (BufferedFilter.process)
+ *   env = sosfiltfilt(eplan, gain*|yf|) [clamped]    (BufferedEnvelope.process on yf)
+ * The envelope's forward pass is fused into the band-pass kernel, so the filtered trace is
+ * not re-read: 12 + 8 instead of 8 + 16 bytes per sample.  Results equal the two separate
+ * calls up to float64 rounding of the IIR state.
+ * phase: 0 = both passes; 1 = fused forward only (yf complete, forward result parked in the
+ * context scratch); 2 = backward only (env from that scratch) -- so that other work on yf
+ * (the spectrogram) can be enqueued in between; no call that uses the context scratch
+ * (envelope, nfft > 8192, mean_spectrum_db) may come between phase 1 and phase 2. */
+int hipdsp_sosfilt_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan,
+                            const hipdsp_sosplan *eplan, const float *x, int64_t x_pitch,
+                            float *yf, int64_t yf_pitch, float *env, int64_t env_pitch,
+                            int64_t channels, int64_t frames, int rectify, double gain, int clamp,
+                            int phase);
+
 /* BufferedSpectrogram.process (bufferedspectrogram.py:45-59) ==
  * scipy.signal.spectrogram(x, fs, 'hann', nperseg=nfft, noverlap=nfft-hop,
  * detrend='constant', scaling='density', mode='psd'):

@@ -335,3 +335,44 @@ def test_spectrogram_large_nfft_four_step(oracle, nfft, hop, nframes):
     assert np.max(np.abs(db[fin] - 10*np.log10(got[fin]))) < 1e-3
     with pytest.raises(NotImplementedError):
         gh.gpu_spectrogram(x, rate, 1 << 20, 1 << 19, 1)
+
+
+@pytest.mark.parametrize('T', [10, 33, 2047, 2048, 2049, 2040, 4095, 70000, 1500000])
+def test_fused_filter_envelope_equals_separate_calls(oracle, T):
+    """hipdsp_sosfilt_envelope (forward pass fused into the band-pass kernel) against the two
+    separate calls and against the oracle, incl. tile borders inside the odd extension."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rate, C = 96000.0, 3
+    rng = np.random.default_rng(T)
+    x = synth(rng, T, C, rate)
+    c = gh.ctx()
+    dx = gh.to_planar(c, x)
+    cases = [((300.0, 3000.0), 2, 20.0, 0.0, 2), ((300.0, 3000.0), 1, 500.0, 0.0, 2), ((100.0, 20000.0), 2, 800.0, 50.0, 2)]
+    if T > 4000:
+        cases.append(((300.0, 3000.0), 4, 500.0, 0.0, 3))
+    for band, order, env, ehp, eorder in cases:
+        sos = butter_sos(order, band, 'bandpass', rate)
+        esos = butter_sos(eorder, (ehp, env), 'bandpass', rate) if ehp > 0 else butter_sos(eorder, env, 'lowpass', rate)
+        if T <= oracle.sosfiltfilt_edge(esos):
+            continue
+        fplan, eplan = hipdsp.SosPlan(c, sos), hipdsp.SosPlan(c, esos)
+        yf = hipdsp.DeviceArray(c, (C, T), np.float32)
+        ye = hipdsp.DeviceArray(c, (C, T), np.float32)
+        hipdsp.sosfilt_envelope(c, fplan, eplan, dx, T, yf, T, ye, T, C, T, clamp=ehp == 0)
+        f1 = hipdsp.DeviceArray(c, (C, T), np.float32)
+        e1 = hipdsp.DeviceArray(c, (C, T), np.float32)
+        hipdsp.sosfilt(c, fplan, dx, T, f1, T, C, T, 0)
+        hipdsp.envelope(c, eplan, f1, T, e1, T, C, T, 0, clamp=ehp == 0)
+        gf, ge, sf, se = yf.to_host(), ye.to_host(), f1.to_host(), e1.to_host()
+        want_f = oracle.sosfilt(sos, x.astype(np.float64))
+        want_e = np.zeros_like(want_f)
+        oracle.envelope_process(esos, sf.T.astype(np.float64), want_e, 0, highpass_cutoff=ehp)
+        for ch in range(C):
+            assert rel_err(gf[ch], sf[ch]) < 1e-6, (T, order, ch)
+            assert rel_err(ge[ch], se[ch]) < 2e-6, (T, env, ch)
+            assert rel_err(gf[ch], want_f[:, ch]) < TOL
+            assert rel_err(ge[ch], want_e[:, ch]) < TOL
+    with pytest.raises(ValueError):
+        plan = hipdsp.SosPlan(c, butter_sos(2, 20.0, 'lowpass', rate))
+        hipdsp.sosfilt_envelope(c, plan, plan, dx, T, dx, T, dx, T, C, 9)

@@ -16,7 +16,7 @@ os.makedirs(os.path.dirname(dst) or '.', exist_ok=True)
 
 
 def short(name):
-    for key, tag in (('sos_scan_kernel<2, 0>', 'sos_scan<S=2,filt>'), ('sos_scan_kernel<1, 1>', 'sos_scan<S=1,env_fwd>'),
+    for key, tag in (('sos_fused_kernel<2, 1>', 'sos_fused<S=2+1,filt+env_fwd>'), ('sos_scan_kernel<2, 0>', 'sos_scan<S=2,filt>'), ('sos_scan_kernel<1, 1>', 'sos_scan<S=1,env_fwd>'),
                      ('sos_scan_kernel<1, 2>', 'sos_scan<S=1,env_bwd>'), ('spec_fast_kernel', 'spectrogram'),
                      ('spec2_kernel', 'spectrogram'), ('spec_generic', 'spectrogram_generic'), ('synth', 'synth')):
         if key in name:
