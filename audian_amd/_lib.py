@@ -22,6 +22,16 @@ class HipDspError(RuntimeError):
         self.status = status
 
 
+if not os.path.exists(LIB_PATH) and os.path.exists('/opt/rocm/bin/hipcc') and \
+   os.environ.get('AUDIAN_AMD_NO_AUTOBUILD') != '1':
+    # a source checkout without the built extension: build it (hipcc, gfx950) rather than fail;
+    # there is still no CPU path -- without hipcc or on a build error the import raises below
+    import subprocess as _sp
+    try:
+        _sp.check_call(['make', '-C', os.path.join(_HERE, 'csrc'), '-j4', '-s'])
+    except Exception:
+        pass
+
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f'{LIB_PATH} is missing: build the HIP extension first '
