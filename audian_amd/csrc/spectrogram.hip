@@ -147,6 +147,27 @@ template <> __device__ __forceinline__ void dft<16>(float2 *v)
 
 __device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
 
+// Sum over the 64 lanes of a wave, result in every lane: DPP adds inside the VALU (quad
+// permutes, row mirrors, row broadcasts) instead of six dependent trips through the LDS
+// crossbar (ds_bpermute), whose latency sat in front of every frame.
+__device__ __forceinline__ float wave_sum(float v)
+{
+    auto step = [](float x, auto ctrl, auto row_mask) {
+        const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value,
+                                                  decltype(row_mask)::value, 0xf, false);
+        return x + __int_as_float(t);
+    };
+    using I = std::integral_constant<int, 0>;
+    (void)sizeof(I);
+    v = step(v, std::integral_constant<int, 0xB1>(), std::integral_constant<int, 0xf>());    // quad_perm [1,0,3,2]
+    v = step(v, std::integral_constant<int, 0x4E>(), std::integral_constant<int, 0xf>());    // quad_perm [2,3,0,1]
+    v = step(v, std::integral_constant<int, 0x141>(), std::integral_constant<int, 0xf>());   // row_half_mirror
+    v = step(v, std::integral_constant<int, 0x140>(), std::integral_constant<int, 0xf>());   // row_mirror
+    v = step(v, std::integral_constant<int, 0x142>(), std::integral_constant<int, 0xa>());   // row_bcast:15 -> rows 1, 3
+    v = step(v, std::integral_constant<int, 0x143>(), std::integral_constant<int, 0xc>());   // row_bcast:31 -> rows 2, 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // 8-byte global load the compiler does not track (the caller counts vmcnt by hand)
@@ -307,8 +328,12 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? 3 : 1) * WAVES / 4) voi
                 v[u * R1 + t] = make_float2(r.x, r.y);
                 s += r.x + r.y;
             }
+        if (LPF == 64) {
+            s = wave_sum(s);
+        } else {
 #pragma unroll
-        for (int d = LPF / 2; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+            for (int d = LPF / 2; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        }
         const float mean = s * (1.0f / (float)NFFT);
 #pragma unroll
         for (int u = 0; u < PPL / R1; u++)
@@ -351,12 +376,13 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? 3 : 1) * WAVES / 4) voi
                 const float2 z0 = v[(m0 % NB3) * R3 + m0 / NB3];
                 zm = (l == 0) ? z0 : zm;
             }
-            const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-            const float2 od2 = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
+            // E = (zk + conj zm)/2, O = -i (zk - conj zm)/2; the halves go into the scale
+            const float2 e = make_float2(zk.x + zm.x, zk.y - zm.y);
+            const float2 od2 = make_float2(zk.y + zm.y, zm.x - zk.x);
             const float2 t = cmul(od2, twn[k]);
             const float2 a = cadd(e, t), b = csub(e, t);
-            float pk = 2.f * scale * (a.x * a.x + a.y * a.y);
-            float pm = 2.f * scale * (b.x * b.x + b.y * b.y);
+            float pk = 0.5f * scale * (a.x * a.x + a.y * a.y);
+            float pm = 0.5f * scale * (b.x * b.x + b.y * b.y);
             if (m == 0) {
                 // bin 0 pairs with itself: DC = re + im, Nyquist = re - im, not doubled
                 const float dc0 = zk.x + zk.y, ny = zk.x - zk.y;

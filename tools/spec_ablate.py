@@ -26,8 +26,11 @@ def run(nfft, hop, **opts):
     print(f'nfft {nfft} hop {hop} {opts}: {ms:.3f} ms  {gb/ms*1e3:.0f} GB/s', flush=True)
     ds.free()
 
-run(2048, 1024, spec_stagger=0)
-for shift in (0, 3):
-    for unit in (2, 4, 8, 16):
-        run(2048, 1024, spec_stagger=(shift << 8) | unit)
-run(2048, 1024, spec_stagger=0)
+run(2048, 1024)
+run(2048, 1024)
+run(2048, 1024)
+run(1024, 512)
+run(1024, 256)
+run(4096, 2048)
+run(256, 128)
+run(512, 256)
