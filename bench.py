@@ -45,8 +45,11 @@ def parse():
     ap.add_argument('--lp', type=float, default=3000.0)
     ap.add_argument('--order', type=int, default=2)
     ap.add_argument('--env', type=float, default=20.0)
-    ap.add_argument('--tile-seconds', type=float, default=80.0,
-                    help='N>1: length of the spectrogram tile that is all-gathered')
+    ap.add_argument('--tile-seconds', type=float, default=61.0,
+                    help='N>1: length of the spectrogram tile that is all-gathered: the resident '
+                         'buffer of the spectrogram trace, buffer_time 60 s + 11 s + 10 s of raw '
+                         'pre/post-roll minus the 10 s trimmed by the filter and the 10 s trimmed by '
+                         'the spectrogram in align_buffer (data.py:17,168; buffereddata.py:75-88)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-seconds', type=float, default=60.0)
     ap.add_argument('--max-segments', type=int, default=0)
@@ -184,9 +187,12 @@ def main():
         tspec = torch.empty((C, nd, F), dtype=torch.float32, device='cuda')
         ds = hipdsp.DeviceArray(ctx, (C, nd, F), np.float32, ptr=tspec.data_ptr(), owner=tspec)
         tile_frames = n_tile_frames(nd, args.rate, args.hop, args.tile_seconds)
-        tile_buf = torch.empty((C, tile_frames, F), dtype=torch.float32, device='cuda')
-        merged = torch.empty((world*C, tile_frames, F), dtype=torch.float32,
-                             device='cuda' if args.backend == 'nccl' else 'cpu')
+        # two tiles in flight: the gather of step i runs under the kernels of step i + 1
+        tile_buf = [torch.empty((C, tile_frames, F), dtype=torch.float32, device='cuda') for _ in range(2)]
+        merged = [torch.empty((world*C, tile_frames, F), dtype=torch.float32,
+                              device='cuda' if args.backend == 'nccl' else 'cpu') for _ in range(2)]
+        works = [None, None]
+        counter = [0]
     else:
         ds = hipdsp.DeviceArray(ctx, (C, nd, F), np.float32)
     ctx.reserve(4*C*((T + 2*edge + 3)//4*4))
@@ -225,15 +231,20 @@ def main():
         hipdsp.spectrogram(ctx, df, T, C, T, args.nfft, args.hop, args.rate, ds, nd)
         if ev:
             ctx.record(ev[2])
-        work = None
         if multi:
-            # merged spectrogram tile of the visible window on every rank: one RCCL
-            # all-gather over xGMI, issued now so that it overlaps the envelope kernels
-            tile_buf.copy_(tspec[:, :tile_frames, :])
+            # merged spectrogram tile of the resident window on every rank: one RCCL all-gather
+            # over xGMI per step, double-buffered so that it overlaps the envelope backward
+            # pass of this step and the kernels of the next one
+            b = counter[0] % 2
+            counter[0] += 1
+            if works[b] is not None:
+                works[b].wait()              # tile b is about to be overwritten
+                works[b] = None
+            tile_buf[b].copy_(tspec[:, :tile_frames, :])
             if args.backend == 'nccl':
-                _, work = allgather_tiles(tile_buf, world*C, out=merged, async_op=True)
+                _, works[b] = allgather_tiles(tile_buf[b], world*C, out=merged[b], async_op=True)
             else:
-                allgather_tiles(tile_buf.cpu(), world*C, out=merged)
+                allgather_tiles(tile_buf[b].cpu(), world*C, out=merged[b])
         if ev:
             ctx.set_mid_event(mids[i])
         if fused:
@@ -247,12 +258,15 @@ def main():
         if ev:
             ctx.set_mid_event(None)
             ctx.record(ev[3])
-        if work is not None:
-            work.wait()                      # compute stream waits for the gather
         if ev:
             ctx.record(ev[4])
 
     def fence():
+        if multi:
+            for b in range(2):
+                if works[b] is not None:
+                    works[b].wait()          # every gather issued so far is part of the job
+                    works[b] = None
         ctx.synchronize()
         if multi:
             torch.cuda.synchronize()
@@ -274,11 +288,11 @@ def main():
 
     # per-kernel averages from the HIP events recorded inside the timed region
     if fused:
-        names = ['sos_fused<S=%d+%d,filt+env_fwd>' % (len(sos), len(esos)), 'spectrogram', 'tile_copy+gather_issue',
-                 'sos_scan<S=%d,env_bwd>' % len(esos), 'allgather_tile_exposed']
+        names = ['sos_fused<S=%d+%d,filt+env_fwd>' % (len(sos), len(esos)), 'spectrogram', 'tile_copy+gather_wait',
+                 'sos_scan<S=%d,env_bwd>' % len(esos), 'unused']
     else:
         names = ['sos_scan<S=%d,filt>' % len(sos), 'spectrogram', 'sos_scan<S=%d,env_fwd>' % len(esos),
-                 'sos_scan<S=%d,env_bwd>' % len(esos), 'allgather_tile_exposed']
+                 'sos_scan<S=%d,env_bwd>' % len(esos), 'unused']
     ms = dict.fromkeys(names, 0.0)
     for i in range(args.steps):
         e = events[i]
@@ -314,7 +328,7 @@ def main():
             traffic = pmc['kernels'][dom]['hbm_bytes']
     kernels = {k: {'ms': round(ms[k], 4),
                    'GBps': round(alg_bytes[k]/(ms[k]*1e-3)/1e9, 1) if k in alg_bytes and ms[k] > 0 else None}
-               for k in names if k in alg_bytes or multi}
+               for k in names if k in alg_bytes or (multi and k == 'tile_copy+gather_wait')}
 
     parity = None
     cpu = None
@@ -343,8 +357,8 @@ def main():
                             f'+ envelope {args.env:g} Hz',
                 'channels_per_gpu': C, 'frames': T, 'spectrogram_frames': nd,
                 'parallelism': f'channel shard x{world}' +
-                               (f', all-gather of the {args.tile_seconds:g} s spectrogram tile'
-                                if world > 1 else ''),
+                               (f', pipelined all-gather of the {args.tile_seconds:g} s spectrogram tile '
+                                f'({4*C*tile_frames*F/1e9:.2f} GB per rank)' if multi else ''),
                 'iir_warmup_samples': {'bandpass': warm_f, 'envelope': warm_e},
                 'envelope_forward': 'fused into the band-pass kernel' if fused else 'own launch',
             },
