@@ -64,9 +64,89 @@ def _subtract(ranges, a, b):
     return out
 
 
+class _LazyBuffer(object):
+    """What ``trace.buffer`` returns while parts of the host copy are stale: it looks like the
+    (frames, channels[, F]) float64 array, but only copies back from the device mirror the
+    frame range an access touches (``len()`` and ``shape`` touch nothing).  Anything it does
+    not know (``.T``, ufuncs on the whole array, ...) synchronises everything and falls
+    through to the real ndarray."""
+
+    def __init__(self, trace):
+        object.__setattr__(self, '_t', trace)
+
+    def __len__(self):
+        return len(self._t._hostbuf)
+
+    @property
+    def shape(self):
+        return self._t._hostbuf.shape
+
+    @property
+    def ndim(self):
+        return self._t._hostbuf.ndim
+
+    @property
+    def dtype(self):
+        return self._t._hostbuf.dtype
+
+    @property
+    def size(self):
+        return self._t._hostbuf.size
+
+    def _frames_of(self, key):
+        first = key[0] if isinstance(key, tuple) else key
+        n = len(self._t._hostbuf)
+        if isinstance(first, slice):
+            a, b, step = first.indices(n)
+            return (a, b) if step > 0 else (0, n)
+        if isinstance(first, (int, np.integer)):
+            i = int(first) + (n if first < 0 else 0)
+            return i, i + 1
+        return 0, n
+
+    def __getitem__(self, key):
+        a, b = self._frames_of(key)
+        self._t._flush_range(a, b)
+        return self._t._hostbuf[key]
+
+    def __setitem__(self, key, value):
+        a, b = self._frames_of(key)
+        self._t._flush_range(a, b)
+        self._t._hostbuf[key] = value
+        self._t._dev_valid = _subtract(self._t._dev_valid, a, b)
+
+    def __array__(self, dtype=None, copy=None):
+        self._t._flush()
+        return np.asarray(self._t._hostbuf, dtype=dtype)
+
+    def __getattr__(self, name):
+        self._t._flush()
+        return getattr(self._t._hostbuf, name)
+
+    def __iter__(self):
+        self._t._flush()
+        return iter(self._t._hostbuf)
+
+
+def _delegate(name):
+    def method(self, *args):
+        self._t._flush()
+        return getattr(self._t._hostbuf, name)(*args)
+    method.__name__ = name
+    return method
+
+
+for _name in ('__eq__', '__ne__', '__lt__', '__le__', '__gt__', '__ge__', '__add__', '__radd__',
+              '__sub__', '__rsub__', '__mul__', '__rmul__', '__truediv__', '__rtruediv__',
+              '__pow__', '__neg__', '__abs__', '__matmul__'):
+    setattr(_LazyBuffer, _name, _delegate(_name))
+_LazyBuffer.__hash__ = None
+
+
 class BufferedData(BufferedArray):
 
     _hostbuf = None
+    _raw_cache = None
     _dev = None
     _dev_valid = ()
     _stale = ()
@@ -97,8 +177,10 @@ class BufferedData(BufferedArray):
     # ---- host buffer with lazy read-back ---------------------------------------
     @property
     def buffer(self):
+        # the plain ndarray when the host copy is current, else a proxy that reads back only
+        # what is accessed (the plot code asks for len(buffer) and per-channel slices)
         if self._stale:
-            self._flush()
+            return _LazyBuffer(self)
         return self._hostbuf
 
     @buffer.setter
@@ -166,6 +248,24 @@ class BufferedData(BufferedArray):
                 self._hostbuf[a:b] = tmp.to_host()
             tmp.free()
 
+    def _flush_range(self, a, b):
+        """Read back only the stale parts of frames [a, b)."""
+        if not self._stale or b <= a:
+            return
+        need = []
+        for r0, r1 in self._stale:
+            lo, hi = max(r0, a), min(r1, b)
+            if hi > lo:
+                need.append([lo, hi])
+        if not need:
+            return
+        rest = list(self._stale)
+        for lo, hi in need:
+            rest = _subtract(rest, lo, hi)
+        self._stale = need
+        self._flush()
+        self._stale = rest
+
     def _adopt_buffer(self, new, offset, old_offset, old_nframes, keep0, keep1):
         """move_buffer recycled the host buffer: recycle the mirror the same way."""
         from . import hipdsp
@@ -206,17 +306,36 @@ class BufferedData(BufferedArray):
         if call is not None and n > 0 and hasattr(src, 'pcm_slab'):
             # the loader can hand over the file's own integers: upload those (2-4 bytes per
             # sample instead of 8) and convert on the device
+            # (an interactive cut-off sweep recomputes from the SAME raw slab: keep its device copy)
+            pkey = ('pcm', id(src), src.offset + call.soffset, n)
+            if self._raw_cache is not None and self._raw_cache[0] == pkey:
+                return self._raw_cache[1], n, None
             raw = src.pcm_slab(src.offset + call.soffset, n)
             up = hipdsp.DeviceArray.from_host(self.ctx, raw)
             planar = hipdsp.DeviceArray(self.ctx, (max(1, src.channels), n), np.float32)
             hipdsp.pcm_unpack(self.ctx, up, src.sample_bytes, n, src.channels, src.scale, planar, n)
-            return planar, n, up
+            self.ctx.synchronize()
+            self._raw_cache = (pkey, planar)
+            return planar, n, None
+        key = None
+        if call is not None and n > 0 and not isinstance(src, BufferedData):
+            # same for float slabs, keyed by the slab's identity, position and a fingerprint of a
+            # strided subsample (a loader may rewrite its buffer in place)
+            sample = source[::max(1, n//4096)]
+            key = (id(src), src.offset, self._source_len(), call.soffset, n,
+                   hash(np.ascontiguousarray(sample).tobytes()))
+            if self._raw_cache is not None and self._raw_cache[0] == key:
+                return self._raw_cache[1], n, None
         dtype = np.float32 if source.dtype == np.float32 else np.float64
         host = np.ascontiguousarray(source.reshape(n, -1), dtype=dtype)
         up = hipdsp.DeviceArray.from_host(self.ctx, host)
         planar = hipdsp.DeviceArray(self.ctx, (max(1, host.shape[1]), max(1, n)), np.float32)
         if n > 0:
             hipdsp.pack(self.ctx, up, planar, n, n, host.shape[1], src_dtype=dtype)
+        if key is not None:
+            self.ctx.synchronize()
+            self._raw_cache = (key, planar)
+            return planar, n, None
         return planar, max(1, n), up
 
     def _device_dest(self, dest, call):

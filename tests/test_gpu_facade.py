@@ -216,11 +216,25 @@ def test_chain_stays_on_the_device(oracle, monkeypatch):
     f = g['filtered']
     f.highpass_cutoff, f.lowpass_cutoff = 400.0, 4000.0
     f.update()                                  # recompute_all through the whole graph
-    assert counts == {'pack': 1, 'unpack': 0, 'unpack_spectrum': 0}
-    _ = g['spectrogram'].buffer                 # the display reads one trace
-    assert counts == {'pack': 1, 'unpack': 0, 'unpack_spectrum': 1}
+    # the raw slab has not changed since update_times: even its upload is skipped
+    assert counts == {'pack': 0, 'unpack': 0, 'unpack_spectrum': 0}
+    s = g['spectrogram']
+    assert len(s.buffer) == len(s._hostbuf) and s.buffer.shape == s._hostbuf.shape   # no read-back
+    assert counts['unpack_spectrum'] == 0
+    part = s.buffer[3:7, 1, :]                  # the display reads a few frames of one channel
+    assert counts['unpack_spectrum'] == 1 and s._stale == [[0, 3], [7, len(s._hostbuf)]]
+    assert part.shape == (4, s.shape[2])
+    _ = np.asarray(s.buffer)                    # ... or everything
+    assert s._stale == [] and isinstance(s.buffer, np.ndarray)
     _ = g['envelope'][g['envelope'].offset:g['envelope'].offset + 10, 0]
     assert counts['unpack'] == 1
+    # a loader that rewrites its buffer in place is noticed (fingerprint of the slab)
+    g.data.buffer[::97, :] *= 0.5
+    f.update()
+    assert counts['pack'] == 1
+    g.data.buffer[::97, :] *= 2.0
+    f.update()
+    assert counts['pack'] == 2
     o = build(oracle_twins(oracle), x, rate, 4.0, 1.0, nfft=512)
     o.update_times(2.0, 4.0)
     of = o['filtered']

@@ -1,0 +1,48 @@
+"""BASELINE configs[4] through the drop-in facade (not the C ABI): time DataBrowser.update_filter's
+work -- BufferedFilter.update() -> recompute_all() through spectrogram and envelope -- under a
+cut-off sweep, reading nothing back (no display).  Not a test."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from audian_amd.bufferedfilter import BufferedFilter
+from audian_amd.bufferedenvelope import BufferedEnvelope
+from audian_amd.bufferedspectrogram import BufferedSpectrogram
+from audian_amd.tracegraph import TraceGraph
+
+
+class Item:
+    def isVisible(self):
+        return True
+
+
+rate, C, seconds = 192000.0, 16, 100.0
+rng = np.random.default_rng(1)
+x = rng.uniform(-1, 1, size=(int(rate*seconds), C)).astype(np.float32)
+g = TraceGraph(60.0, 20.0)
+for t in (BufferedFilter(), BufferedSpectrogram(nfft=2048), BufferedEnvelope(envelope_cutoff=500.0)):
+    g.add_trace(t)
+g.setup_traces()
+g.open(x, rate)
+for t in g.traces:
+    t.plot_items = [Item() for _ in range(t.channels)]
+g.set_need_update()
+g.update_times(0.0, 10.0)
+f = g['filtered']
+print('resident frames', len(g.data.buffer), len(f.buffer), len(g['spectrogram'].buffer), len(g['envelope'].buffer), flush=True)
+n = 30
+t0 = time.perf_counter()
+for i in range(n):
+    f.highpass_cutoff = 100.0 + 60*i
+    f.lowpass_cutoff = 20000.0 - 500*i
+    f.update()
+f.ctx.synchronize()
+dt = (time.perf_counter() - t0)/n
+print(f'facade update_filter: {dt*1e3:.2f} ms per recompute ({1/dt:.1f} FPS), no read-back', flush=True)
+t0 = time.perf_counter()
+for i in range(5):
+    f.highpass_cutoff = 200.0 + 60*i
+    f.update()
+    img = g['spectrogram'].decibel_image(0)
+    mm = f.minmax_decimate(f.offset, f.offset + len(f.buffer), len(f.buffer)//2000, channel=0)
+dt = (time.perf_counter() - t0)/5
+print(f'  + dB image of one channel + 2000 px min/max trace: {dt*1e3:.2f} ms', flush=True)
