@@ -618,6 +618,69 @@ __global__ __launch_bounds__(64 * WAVES) void spec2_kernel(
     }
 }
 
+// ---- direct path: any nfft that is not a power of two ---------------------------------
+// The reference clamps nfft to len(source)//2 (bufferedspectrogram.py:88-90), which on a short
+// recording yields a non power of two.  Rare and small, so a plain O(nfft^2) DFT does: one
+// thread per bin, the detrended, windowed frame staged through LDS in chunks, twiddles from
+// sincospif on the exact fraction (k*n mod nfft)/nfft.
+__global__ __launch_bounds__(256) void spec_direct_kernel(
+    const float *__restrict__ x, long long x_pitch, long long n_valid, long long frames_out,
+    long long out_pitch, int nfft, int hop, float scale, float *__restrict__ out,
+    float *__restrict__ db_out)
+{
+    constexpr int CHUNK = 2048;
+    __shared__ float xs[CHUNK];
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const long long frame = blockIdx.y;
+    const long long ch = blockIdx.z;
+    const int F = nfft / 2 + 1;
+    const int k = blockIdx.x * 256 + tid;
+    float *o = out + ch * out_pitch + frame * (long long)F;
+    float *od = db_out ? db_out + ch * out_pitch + frame * (long long)F : nullptr;
+    if (frame >= n_valid) {
+        if (k < F) { o[k] = 0.f; if (od) od[k] = -INFINITY; }
+        return;
+    }
+    const float *seg = x + ch * x_pitch + frame * (long long)hop;
+    double s = 0.0;
+    for (int i = tid; i < nfft; i += 256) s += (double)seg[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float mean = (float)((red[0] + red[1] + red[2] + red[3]) / (double)nfft);
+    float re = 0.f, im = 0.f;
+    long long idx = 0;                       // (k * n) mod nfft, advanced incrementally
+    for (int base = 0; base < nfft; base += CHUNK) {
+        const int len = nfft - base < CHUNK ? nfft - base : CHUNK;
+        __syncthreads();
+        for (int i = tid; i < len; i += 256) {
+            const int n = base + i;
+            const float w = 0.5f - 0.5f * cospif(2.0f * (float)n / (float)nfft);
+            xs[i] = (seg[n] - mean) * w;
+        }
+        __syncthreads();
+        if (k < F) {
+            for (int i = 0; i < len; i++) {
+                float sn, cs;
+                sincospif(-2.0f * (float)idx / (float)nfft, &sn, &cs);
+                re = fmaf(xs[i], cs, re);
+                im = fmaf(xs[i], sn, im);
+                idx += k;
+                if (idx >= nfft) idx -= nfft;
+            }
+        }
+    }
+    if (k < F) {
+        float p = (re * re + im * im) * scale;
+        const bool edge_bin = (k == 0) || ((nfft % 2 == 0) && k == F - 1);
+        if (!edge_bin) p *= 2.f;
+        o[k] = p;
+        if (od) od[k] = to_db(p);
+    }
+}
+
 // ---- large path: nfft = 2^14 ... 2^19 (the rest of the reference's nfft combo box,
 // src/audian/databrowser.py:516) -----------------------------------------------------
 // A frame no longer fits into LDS, so the half-length complex FFT (M = nfft/2 = N1*N2) runs
@@ -992,8 +1055,10 @@ extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pit
     HD_REQUIRE(nfft >= 8, "nfft %d < 8", nfft);
     HD_REQUIRE(hop >= 1 && hop <= nfft, "hop %d not in [1, nfft=%d]", hop, nfft);
     HD_REQUIRE(fs > 0, "fs must be positive");
-    if ((nfft & (nfft - 1)) != 0 || nfft > (1 << 19)) {
-        hipdsp_set_error("nfft %d: only powers of two in [8, 524288] are implemented", nfft);
+    const bool pow2 = (nfft & (nfft - 1)) == 0;
+    if ((pow2 && nfft > (1 << 19)) || (!pow2 && nfft > (1 << 17))) {
+        hipdsp_set_error("nfft %d: powers of two up to 524288 and other sizes up to 131072 are implemented",
+                         nfft);
         return HIPDSP_ERR_UNSUPPORTED;
     }
     if (channels == 0 || frames_out == 0) return HIPDSP_OK;
@@ -1016,6 +1081,14 @@ extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pit
         wss += w * w;
     }
     float scale = (float)(1.0 / (fs * wss));
+    if (!pow2) {
+        HD_REQUIRE(frames_out <= 65535, "too many frames for the direct DFT path");
+        hipLaunchKernelGGL(spec_direct_kernel, dim3((unsigned)((nfft / 2 + 1 + 255) / 256), (unsigned)frames_out,
+                                                    (unsigned)channels), dim3(256), 0, ctx->stream, x,
+                           (long long)x_pitch, n_valid, (long long)frames_out, (long long)out_pitch, nfft, hop,
+                           scale, out, db_out);
+        return hd_launch_status("spec_direct_kernel");
+    }
     if (!ctx->force_generic_fft && nfft >= 256 && nfft <= 4096) {
         // spec_kernel: 0 = default choice per size, 2 = two-stage kernel, 3 = three-stage kernel
         const int want = ctx->spec_kernel;

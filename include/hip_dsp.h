@@ -205,9 +205,10 @@ int hipdsp_sosfilt_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan,
  * nsource < nfft).  out is (channels, frames_out, nfft/2 + 1) float32 with out_pitch
  * elements between consecutive channels (0 = compact, frames_out*(nfft/2 + 1)).
  * If db_out != NULL it additionally receives decibel(out) (fused epilogue,
- * specitem.py:36) in the same layout.  nfft must be a power of two in [8, 524288] (the
- * reference's nfft selector, databrowser.py:516); sizes above 8192 run a four-step FFT over
- * the context scratch. */
+ * specitem.py:36) in the same layout.  nfft: any power of two in [8, 524288] (the reference's
+ * nfft selector, databrowser.py:516; above 8192 a four-step FFT over the context scratch)
+ * and, for the values the reference's clamp to len(source)//2 can produce, any other size up
+ * to 131072 (direct DFT, O(nfft^2), meant for the rare short recording). */
 int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, int64_t channels,
                        int64_t frames, int nfft, int hop, double fs, float *out,
                        float *db_out, int64_t frames_out, int64_t out_pitch);

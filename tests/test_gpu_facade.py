@@ -289,9 +289,17 @@ def test_process_as_plain_function_on_host_arrays(oracle):
     assert np.all(dest[-1] == 0)
     for k in range(nd - 1):
         assert rel_err(dest[k], want[k]) < TOL
-    s.nfft, s.hop = 100, 50
+    s.update(nfft=100, overlap_frac=0.5)                 # not a power of two: direct DFT path
+    assert (s.nfft, s.hop, s.shape[2]) == (100, 50, 51)
+    dest = np.zeros((10, 2, 51))
+    s.process(x[:10*50 + 1], dest, 0)
+    want = np.zeros_like(dest)
+    oracle.spectrogram_process(x[:10*50 + 1], want, rate, 100, 50)
+    for k in range(9):
+        assert rel_err(dest[k], want[k]) < TOL
+    s.nfft, s.hop, s.shape = 1 << 20, 1 << 19, (1, 2, (1 << 19) + 1)
     with pytest.raises(NotImplementedError):
-        s.process(x, np.zeros((10, 2, 51)), 0)
+        s.process(x, np.zeros((1, 2, (1 << 19) + 1)), 0)
 
 
 def test_wav_recording_through_pcm_ingest(oracle, tmp_path, monkeypatch):
