@@ -94,10 +94,25 @@ def cpu_baseline(args, sos, esos):
     t0 = time.perf_counter()
     run()
     dt = time.perf_counter() - t0
-    return {'value': C*T/dt/1e6, 'unit': 'Msamples/s', 'cores': 1, 'kind': 'port',
-            'host_cores': os.cpu_count(),
-            'sample': f'{C} ch x {args.cpu_sample_seconds:g} s x {args.rate/1000:g} kHz float64, '
-                      f'same chain, {dt:.1f} s wall; {impl}'}
+    out = {'value': C*T/dt/1e6, 'unit': 'Msamples/s', 'cores': 1, 'kind': 'port',
+           'host_cores': os.cpu_count(),
+           'sample': f'{C} ch x {args.cpu_sample_seconds:g} s x {args.rate/1000:g} kHz float64, '
+                     f'same chain, {dt:.1f} s wall; {impl}'}
+    # for fairness also an all-cores figure: channels split over 16 worker processes (the
+    # box's CPU share for one GPU), in a separate process tree that never touches the GPU
+    try:
+        import subprocess
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'scipy_path.py'), str(C),
+                            str(args.cpu_sample_seconds), str(args.rate), str(args.nfft), str(args.hop),
+                            str(args.hp), str(args.lp), str(args.order), str(args.env), '16'],
+                           capture_output=True, text=True, timeout=180)
+        if r.returncode == 0:
+            allc = json.loads(r.stdout.strip().split('\n')[-1])
+            out['all_cores'] = {'value': allc['value'], 'unit': 'Msamples/s', 'cores': allc['cores'],
+                                'sample': 'same sample, channels split over worker processes'}
+    except Exception:
+        pass
+    return out
 
 
 def parity_subset(args, hipdsp, ctx, dx, df, ds, de, T, nd, sos, esos):

@@ -57,3 +57,42 @@ def chain(x, rate, sos, esos, nfft, hop):
     env = np.zeros((T, C))
     envelope_process(esos, filt, env)
     return filt, spec, env
+
+
+def _worker(job):
+    """One process = one block of channels through the reference's chain (own synthetic slab)."""
+    import time
+    c0, c1, C, T, rate, nfft, hop, hp, lp, order, env = job
+    rng = np.random.default_rng(1234 + 2 + c0)
+    t = np.arange(T)/rate
+    x = rng.uniform(-1.0, 1.0, size=(T, c1 - c0))
+    for c in range(c0, c1):
+        x[:, c - c0] = 0.5*x[:, c - c0] + 0.5*np.sin(2*np.pi*1000.0*(1 + c/C)*t)
+    sos = signal.butter(order, (hp, lp), 'bandpass', fs=rate, output='sos')
+    esos = signal.butter(2, env, 'lowpass', fs=rate, output='sos')
+    t0 = time.perf_counter()
+    chain(x, rate, sos, esos, nfft, hop)
+    return time.perf_counter() - t0
+
+
+if __name__ == '__main__':
+    # all-cores variant of the CPU baseline (SURVEY 8d): channels split over processes.
+    # Runs as its own process tree so that nothing here ever touches the GPU.
+    import json
+    import multiprocessing as mp
+    import sys
+    import time
+    C, seconds, rate, nfft, hop, hp, lp, order, env, nproc = [float(v) for v in sys.argv[1:11]]
+    C, nfft, hop, order, nproc = int(C), int(nfft), int(hop), int(order), int(nproc)
+    T = int(seconds*rate)
+    nproc = max(1, min(nproc, C))
+    bounds = [round(i*C/nproc) for i in range(nproc + 1)]
+    jobs = [(bounds[i], bounds[i + 1], C, T, rate, nfft, hop, hp, lp, order, env)
+            for i in range(nproc) if bounds[i + 1] > bounds[i]]
+    t0 = time.perf_counter()
+    with mp.get_context('fork').Pool(len(jobs)) as pool:
+        inner = pool.map(_worker, jobs)
+    wall = time.perf_counter() - t0
+    # throughput over the slowest worker's chain time (generation of the input excluded)
+    print(json.dumps({'value': C*T/max(inner)/1e6, 'cores': len(jobs), 'wall_s': wall,
+                      'chain_s_max': max(inner)}))
