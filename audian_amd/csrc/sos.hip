@@ -729,6 +729,23 @@ int hipdsp_sosplan_set(hipdsp_ctx *ctx, hipdsp_sosplan *plan, const double *host
     return hipdsp_sosplan_upload(ctx, plan);
 }
 
+int hipdsp_sos_plan_host(const double *host_sos, int n_sections, int64_t *warmup, int *edge, double *zi)
+{
+    HD_REQUIRE(host_sos != nullptr, "host_sos is NULL");
+    if (n_sections < 1 || n_sections > MAXS) {
+        hipdsp_set_error("n_sections %d not in 1..%d", n_sections, MAXS);
+        return HIPDSP_ERR_UNSUPPORTED;
+    }
+    SosPlanDev tmp;
+    int rc = fill_plan(&tmp, host_sos, n_sections);
+    if (rc != HIPDSP_OK) return rc;
+    if (warmup) *warmup = tmp.warm;
+    if (edge) *edge = tmp.edge;
+    if (zi)
+        for (int k = 0; k < 2 * n_sections; k++) zi[k] = tmp.zi[k];
+    return HIPDSP_OK;
+}
+
 int hipdsp_sosplan_info(hipdsp_ctx *ctx, hipdsp_sosplan *plan, int64_t *warmup, int *edge)
 {
     HD_REQUIRE(ctx != nullptr && plan != nullptr, "NULL argument");

@@ -152,6 +152,11 @@ int hipdsp_sosplan_set(hipdsp_ctx *ctx, hipdsp_sosplan *plan, const double *host
 int hipdsp_sosplan_set_host(hipdsp_ctx *ctx, hipdsp_sosplan *plan, const double *host_sos,
                             int n_sections);
 int hipdsp_sosplan_upload(hipdsp_ctx *ctx, hipdsp_sosplan *plan);
+/* The host half of a plan without any device: warm-up length (smallest multiple of the
+ * 2048-sample tile with ||A^warm||_inf < 2^-60; 2^50 tiles when the filter does not decay),
+ * scipy's sosfiltfilt pad length and sosfilt_zi (2*n_sections values); any output may be NULL. */
+int hipdsp_sos_plan_host(const double *host_sos, int n_sections, int64_t *warmup, int *edge,
+                         double *zi);
 /* Introspection (tests): warm-up length in samples, sosfiltfilt pad length. */
 int hipdsp_sosplan_info(hipdsp_ctx *ctx, hipdsp_sosplan *plan, int64_t *warmup, int *edge);
 

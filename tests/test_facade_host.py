@@ -292,3 +292,43 @@ def test_wav_loader_scales_like_audioio(tmp_path, nbytes):
     raw = w.pcm_slab(10, 4)
     assert raw.dtype == np.uint8 and len(raw) == 4*3*nbytes
     w.close()
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+def test_random_scroll_sequences_keep_buffers_consistent(seed):
+    """Any sequence of window moves (forwards, backwards, jumps, EOF) leaves every derived
+    trace's buffer equal to a from-scratch evaluation of its range (stateless stub traces at
+    rate 1 and rate 1/8, pre/post-roll trimming as in align_buffer)."""
+    rng = np.random.default_rng(seed)
+    frames, rate = 60000, 100.0
+    g = TraceGraph(buffer_time=20.0, back_time=5.0)
+    a = Doubler('a', 'data', tbefore=3)
+    b = Doubler('b', 'a', tafter=2)
+    s = Doubler('s', 'a', step=8, tafter=4)
+    for t in (s, b, a):
+        g.add_trace(t)
+    g.setup_traces()
+    g.open(ramp(frames, 3), rate)
+    for t in g.traces:
+        t.plot_items = [Item(), None, None]
+    g.set_need_update()
+    t0 = 0.0
+    ref = ramp(frames, 3)
+    for _ in range(40):
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            t0 = max(0.0, t0 + rng.uniform(0.5, 8.0))
+        elif kind == 1:
+            t0 = max(0.0, t0 - rng.uniform(0.5, 8.0))
+        elif kind == 2:
+            t0 = rng.uniform(0.0, frames/rate - 1.0)
+        else:
+            t0 = frames/rate - rng.uniform(0.5, 5.0)
+        t1 = min(frames/rate, t0 + rng.uniform(0.5, 10.0))
+        g.update_times(t0, t1)
+        d = g.data
+        assert np.array_equal(d.buffer, ref[d.offset:d.offset + len(d.buffer)])
+        assert np.array_equal(a.buffer, 2*ref[a.offset:a.offset + len(a.buffer)])
+        assert np.array_equal(b.buffer, 4*ref[b.offset:b.offset + len(b.buffer)])
+        want = 4*ref[::8][s.offset:s.offset + len(s.buffer)]
+        assert np.array_equal(s.buffer, want)

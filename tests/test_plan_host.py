@@ -1,0 +1,74 @@
+"""Host half of the IIR plan (no GPU): warm-up length, pad length and steady-state initial
+conditions computed by libhip_dsp against brute-force NumPy and the oracle."""
+
+import ctypes
+
+import numpy as np
+import pytest
+
+from audian_amd import _lib
+from audian_amd.design import butter_sos
+
+TILE = 2048
+
+
+def plan_host(sos):
+    sos = np.ascontiguousarray(sos, dtype=np.float64)
+    warm = ctypes.c_int64()
+    edge = ctypes.c_int()
+    zi = np.zeros(2*len(sos))
+    _lib.check(_lib.lib.hipdsp_sos_plan_host(ctypes.c_void_p(sos.ctypes.data), len(sos), ctypes.byref(warm),
+                                             ctypes.byref(edge), ctypes.c_void_p(zi.ctypes.data)))
+    return int(warm.value), int(edge.value), zi
+
+
+def transition_matrix(sos):
+    """State-transition matrix of the DF-II-transposed cascade, column by column."""
+    S = len(sos)
+    A = np.zeros((2*S, 2*S))
+    for c in range(2*S):
+        z = np.zeros(2*S)
+        z[c] = 1.0
+        cur = 0.0
+        for s in range(S):
+            b0, b1, b2, _, a1, a2 = sos[s]
+            y = b0*cur + z[2*s]
+            z[2*s] = b1*cur - a1*y + z[2*s + 1]
+            z[2*s + 1] = b2*cur - a2*y
+            cur = y
+        A[:, c] = z
+    return A
+
+
+@pytest.mark.parametrize('btype,order,wn,rate', [
+    ('bandpass', 2, (300.0, 3000.0), 96000.0), ('bandpass', 4, (300.0, 3000.0), 48000.0),
+    ('lowpass', 2, 20.0, 96000.0), ('lowpass', 2, 500.0, 48000.0), ('highpass', 3, 100.0, 192000.0),
+    ('bandpass', 2, (5.0, 3000.0), 96000.0), ('lowpass', 1, 4000.0, 48000.0)])
+def test_warmup_is_the_smallest_tile_multiple_below_tolerance(oracle, btype, order, wn, rate):
+    sos = butter_sos(order, wn, btype, rate)
+    warm, edge, zi = plan_host(sos)
+    assert warm % TILE == 0 and warm >= TILE
+    A = transition_matrix(sos)
+    tol = 2.0**-60
+    norm = lambda M: np.max(np.sum(np.abs(M), axis=1))
+    assert norm(np.linalg.matrix_power(A, warm)) < tol
+    if warm > TILE:
+        assert norm(np.linalg.matrix_power(A, warm - TILE)) >= tol*0.5     # not wastefully long
+    assert edge == oracle.sosfiltfilt_edge(sos)
+    assert np.allclose(zi.reshape(-1, 2), oracle.sosfilt_zi(sos), rtol=1e-12, atol=1e-15)
+
+
+def test_non_decaying_filter_never_segments():
+    # a pure integrator section (pole on the unit circle) keeps its history for ever
+    sos = np.array([[1.0, 0.0, 0.0, 1.0, -1.0, 0.0]])
+    warm, edge, _ = plan_host(sos)
+    assert warm >= 2**40
+
+
+def test_plan_rejects_bad_tables():
+    with pytest.raises(ValueError):
+        plan_host(np.array([[1.0, 0.0, 0.0, 2.0, 0.0, 0.0]]))            # a0 != 1
+    with pytest.raises(NotImplementedError):
+        plan_host(np.tile(np.array([[1.0, 0.0, 0.0, 1.0, 0.0, 0.0]]), (5, 1)))   # > 4 sections
+    with pytest.raises(ValueError):
+        plan_host(np.array([[np.nan, 0.0, 0.0, 1.0, 0.0, 0.0]]))
