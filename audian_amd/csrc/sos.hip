@@ -40,23 +40,16 @@ struct SosPlanDev {
     int edge;                       // sosfiltfilt pad length
 };
 
-enum { MODE_FILT = 0, MODE_ENV_FWD = 1, MODE_ENV_BWD = 2 };
-
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte aligned float4
 
 struct SeqArgs {
-    const float *in;        // channel 0 of the physical input
-    float *out;             // channel 0 of the physical output
+    const float *in;        // channel 0 of the input
+    float *out;             // channel 0 of the output
     long long in_pitch, out_pitch;
-    long long T;            // frames of the user's trace
-    long long N;            // logical sequence length (T, or T + 2*edge)
+    long long N;            // frames
     long long seg_len;      // multiple of TILE
     int n_seg;
-    long long skip;         // nbefore
-    int edge;
-    int rectify;
-    float gain;
-    int clamp;
+    long long skip;         // nbefore: the first `skip` outputs are dropped
 };
 
 __device__ __forceinline__ long long opaque_zero()
@@ -67,103 +60,50 @@ __device__ __forceinline__ long long opaque_zero()
 }
 
 __device__ __forceinline__ int lds_slot(int row, int q) { return row * 8 + (q ^ ((row >> 1) & 7)); }
+__device__ __forceinline__ int lds_float_index(int s) { return lds_slot(s >> 5, (s & 31) >> 2) * 4 + (s & 3); }
 
-// One logical sample (slow path: sequence borders, odd extension).
-template <int MODE>
-__device__ __forceinline__ float load_one(const SeqArgs &a, const float *in, long long i)
+// samples p..p+3 of a row of `n` frames, zeros past the end
+__device__ __forceinline__ float4 load_four(const float *in, long long p, long long n)
 {
-    if (i < 0 || i >= a.N) return 0.f;
-    if (MODE == MODE_FILT) return in[i];
-    if (MODE == MODE_ENV_BWD) return in[a.N - 1 - i];
-    // MODE_ENV_FWD: odd extension of r(j) = gain*|x[j]| (scipy odd_ext)
-    long long j = i - a.edge;
-    auto r = [&](long long k) { float v = in[k]; return a.rectify ? a.gain * fabsf(v) : v; };
-    if (j < 0) return 2.f * r(0) - r(-j);
-    if (j >= a.T) return 2.f * r(a.T - 1) - r(2 * a.T - 2 - j);
-    return r(j);
-}
-
-template <int MODE>
-__device__ __forceinline__ float4 load_four(const SeqArgs &a, const float *in, long long p)
-{
-    float4 v;
-    bool fast;
-    if (MODE == MODE_FILT) fast = (p >= 0 && p + 4 <= a.N);
-    else if (MODE == MODE_ENV_BWD) fast = (p >= 0 && p + 4 <= a.N);
-    else fast = (p >= a.edge && p + 4 <= a.edge + a.T);
-    if (fast) {
-        if (MODE == MODE_FILT) {
-            f4u t = *reinterpret_cast<const f4u *>(in + p);
-            v = make_float4(t.x, t.y, t.z, t.w);
-        } else if (MODE == MODE_ENV_BWD) {
-            f4u t = *reinterpret_cast<const f4u *>(in + (a.N - 4 - p));
-            v = make_float4(t.w, t.z, t.y, t.x);
-        } else {
-            f4u t = *reinterpret_cast<const f4u *>(in + (p - a.edge));
-            if (a.rectify)
-                v = make_float4(a.gain * fabsf(t.x), a.gain * fabsf(t.y), a.gain * fabsf(t.z),
-                                a.gain * fabsf(t.w));
-            else
-                v = make_float4(t.x, t.y, t.z, t.w);
-        }
-    } else {
-        v.x = load_one<MODE>(a, in, p);
-        v.y = load_one<MODE>(a, in, p + 1);
-        v.z = load_one<MODE>(a, in, p + 2);
-        v.w = load_one<MODE>(a, in, p + 3);
+    if (p + 4 <= n) {
+        const f4u t = *reinterpret_cast<const f4u *>(in + p);
+        return make_float4(t.x, t.y, t.z, t.w);
     }
+    float4 v;
+    v.x = p < n ? in[p] : 0.f;
+    v.y = p + 1 < n ? in[p + 1] : 0.f;
+    v.z = p + 2 < n ? in[p + 2] : 0.f;
+    v.w = p + 3 < n ? in[p + 3] : 0.f;
     return v;
 }
 
-// Store logical samples p..p+3 restricted to [lo, hi) (the wave's own segment).
-template <int MODE>
-__device__ __forceinline__ void store_four(const SeqArgs &a, float *out, long long p, float4 v,
-                                           long long lo, long long hi)
+// store samples p..p+3 restricted to [lo, hi) at out[p - shift]
+__device__ __forceinline__ void store_four(float *out, long long p, float4 v, long long lo, long long hi,
+                                           long long shift)
 {
-    if (MODE == MODE_ENV_BWD && a.clamp) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-    }
-    // logical range that maps onto the physical output
-    long long olo, ohi, phys;      // phys index of logical p (for BWD: of logical p+3)
-    if (MODE == MODE_FILT) { olo = a.skip; ohi = a.N; }
-    else if (MODE == MODE_ENV_FWD) { olo = 0; ohi = a.N; }
-    else { olo = a.edge; ohi = a.N - a.edge - a.skip; }   // t = N-1-i-edge in [skip, T)
-    if (olo < lo) olo = lo;
-    if (ohi > hi) ohi = hi;
-    if (p >= olo && p + 4 <= ohi) {
-        f4u t;
-        if (MODE == MODE_ENV_BWD) {
-            phys = a.N - 1 - (p + 3) - a.edge - a.skip;
-            t.x = v.w; t.y = v.z; t.z = v.y; t.w = v.x;
-        } else {
-            phys = (MODE == MODE_FILT) ? p - a.skip : p;
-            t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
-        }
-        *reinterpret_cast<f4u *>(out + phys) = t;
+    if (p >= lo && p + 4 <= hi) {
+        f4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+        *reinterpret_cast<f4u *>(out + (p - shift)) = t;
     } else {
-        float e[4] = {v.x, v.y, v.z, v.w};
+        const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            long long i = p + k;
-            if (i >= olo && i < ohi) {
-                if (MODE == MODE_FILT) out[i - a.skip] = e[k];
-                else if (MODE == MODE_ENV_FWD) out[i] = e[k];
-                else out[a.N - 1 - i - a.edge - a.skip] = e[k];
-            }
-        }
+        for (int k = 0; k < 4; k++)
+            if (p + k >= lo && p + k < hi) out[p + k - shift] = e[k];
     }
 }
 
-template <int S, int MODE>
+// The plan tables (coefficients, G, M: up to ~3 KB) are wave-uniform and must come through
+// scalar loads (s_load -> SGPR operands of v_fma_f64).  Hoisting them out of the tile loop would
+// need ~500 SGPRs and spill through v_writelane; a "memory" clobber would demote them to
+// per-lane vector loads.  So every use goes through PLAN_OF(): the same pointer plus an opaque,
+// always-zero scalar that the compiler must assume changes each time, which pins the s_load
+// next to its use.
+#define PLAN_OF(ptr) (reinterpret_cast<const SosPlanDev *>(reinterpret_cast<const char *>(ptr) + opaque_zero()))
+
+// ---- sosfilt: BufferedFilter.process ------------------------------------------------------
+template <int S>
 __global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *__restrict__ P0, SeqArgs a)
 {
-    // The plan tables (coefficients, G, M: up to ~3 KB) are wave-uniform and must come
-    // through scalar loads (s_load -> SGPR operands of v_fma_f64).  Hoisting them out of
-    // the tile loop would need ~500 SGPRs and spill through v_writelane; a "memory"
-    // clobber would demote them to per-lane vector loads.  So every use goes through
-    // PLAN(): the same pointer plus an opaque, always-zero scalar that the compiler must
-    // assume changes each time, which pins the s_load next to its use.
-#define PLAN() (reinterpret_cast<const SosPlanDev *>(reinterpret_cast<const char *>(P0) + opaque_zero()))
     constexpr int D = 2 * S;
     __shared__ float4 lds[64 * 8];
     const int lane = threadIdx.x;
@@ -176,32 +116,24 @@ __global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *__restri
     long long hi = lo + a.seg_len;
     if (hi > a.N) hi = a.N;
     long long start = lo - P0->warm;
-    const bool true_init = start <= 0;
-    if (start < 0) start = 0;
+    if (start < 0) start = 0;                   // zero state at sample 0 is the true state
+    const long long olo = lo > a.skip ? lo : a.skip;
 
     double carry[D];
 #pragma unroll
     for (int r = 0; r < D; r++) carry[r] = 0.0;
-    if (MODE != MODE_FILT && true_init) {
-        // scipy sosfiltfilt: zi * x_ext[0] (forward) / zi * y_fwd[-1] (backward)
-        double v0 = (double)load_one<MODE>(a, in, 0);
-#pragma unroll
-        for (int r = 0; r < D; r++) carry[r] = P0->zi[r] * v0;
-    }
 
     for (long long tile = start; tile < hi; tile += TILE) {
         // ---- HBM -> LDS (coalesced 16 B per lane), LDS -> registers (row per lane)
         // (A register prefetch of the next tile with a hand-counted vmcnt was measured and
         // bought nothing: the kernel already runs at the device's read+write copy rate.)
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            long long p = tile + 256 * k + 4 * lane;
-            lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = load_four<MODE>(a, in, p);
-        }
+        for (int k = 0; k < 8; k++)
+            lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = load_four(in, tile + 256 * k + 4 * lane, a.N);
         __syncthreads();
 
 #define CASC_S S
-#define CASC_PLAN() PLAN()
+#define CASC_PLAN() PLAN_OF(P0)
 #define CASC_CARRY carry
 #define CASC_IN(v) (v)
 #include "sos_cascade.inc"
@@ -210,46 +142,46 @@ __global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *__restri
 #undef CASC_CARRY
 #undef CASC_IN
         __syncthreads();
-        if (tile + TILE > lo) {      // warm-up tiles produce no output
+        if (tile + TILE > olo) {      // warm-up tiles produce no output
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                long long p = tile + 256 * k + 4 * lane;
-                float4 v = lds[lds_slot(8 * k + (lane >> 3), lane & 7)];
-                store_four<MODE>(a, out, p, v, lo, hi);
-            }
+            for (int k = 0; k < 8; k++)
+                store_four(out, tile + 256 * k + 4 * lane, lds[lds_slot(8 * k + (lane >> 3), lane & 7)], olo, hi,
+                           a.skip);
         }
         __syncthreads();
     }
 }
 
-// ---- fused band-pass + envelope forward pass ----------------------------------------
-// Batch chains (whole slab: filter -> envelope of the SAME slab) re-read the filtered trace
-// only to rectify it and run the envelope's forward pass.  This kernel does both cascades
-// on the tile while it is in LDS: read x once, write the filtered trace and the forward
-// scratch (12 B per sample instead of 8 + 8).  The backward pass stays the plain
-// MODE_ENV_BWD launch.  Sequence handling of scipy's sosfiltfilt in sample coordinates:
-//   * left odd extension: `edge` serial steps before tile 0 from zi * ext[0] (wave-uniform);
-//   * right odd extension: the samples T .. T+edge-1 of the last tile(s) are replaced by the
-//     extension values, so the cascade itself produces the padded outputs;
-//   * scratch index = sample index + edge, exactly what the backward kernel expects.
-struct FusedArgs {
+// ---- envelope without a forward scratch: state checkpoints + recomputation ----------------
+// sosfiltfilt's forward output is only ever consumed by its own backward pass.  Instead of
+// writing it to HBM and reading it back (8 B per sample), the forward sweep keeps only the
+// cascade state that ENTERS each 2048-sample tile (2*SE doubles per tile, < 0.01 B/sample),
+// which needs phase 1 and the scan but no phase 3; the backward sweep walks the tiles from the
+// end, re-runs the forward cascade on a tile from its checkpoint (bit-identical to what the
+// forward sweep would have emitted), and filters the result backwards while it is in LDS.
+//   forward sweep   sos_ckpt_kernel<SF, SE>: SF > 0 also runs the band-pass and writes the
+//                   filtered trace (the batch chain, 8 B/sample); SF == 0 reads the trace to
+//                   rectify as it is (BufferedEnvelope.process alone, 4 B/sample)
+//   backward sweep  env_bwd_kernel<SE>: 8 B/sample.
+// Tiles are aligned in SAMPLE coordinates p in [0, T + edge) for both sweeps (right odd
+// extension at p >= T; the left one is `edge` serial steps before tile 0).  The backward sweep
+// starts in the middle of the top tile (p = T+edge-1) from zi * w[T+edge-1]: the rest of that
+// tile is filled with the same value, for which zi * value is the cascade's steady state.
+struct CkptArgs {
     const float *in;
-    float *yf, *w;
-    long long in_pitch, yf_pitch, w_pitch;
+    float *yf;
+    double *ckpt;
+    long long in_pitch, yf_pitch, ckpt_pitch;
     long long T, seg_len;
     int n_seg, edge, rectify;
     float gain;
 };
 
-__device__ __forceinline__ int lds_float_index(int s) { return lds_slot(s >> 5, (s & 31) >> 2) * 4 + (s & 3); }
-
 template <int SF, int SE>
-__global__ __launch_bounds__(64) void sos_fused_kernel(const SosPlanDev *__restrict__ PF0,
-                                                       const SosPlanDev *__restrict__ PE0, FusedArgs a)
+__global__ __launch_bounds__(64) void sos_ckpt_kernel(const SosPlanDev *__restrict__ PF0,
+                                                      const SosPlanDev *__restrict__ PE0, CkptArgs a)
 {
-#define PLANF() (reinterpret_cast<const SosPlanDev *>(reinterpret_cast<const char *>(PF0) + opaque_zero()))
-#define PLANE() (reinterpret_cast<const SosPlanDev *>(reinterpret_cast<const char *>(PE0) + opaque_zero()))
-    constexpr int DF = 2 * SF, DE = 2 * SE;
+    constexpr int DF = SF > 0 ? 2 * SF : 1, DE = 2 * SE;
     __shared__ float4 lds[64 * 8];
     __shared__ float rprev[64];            // rectified samples of the previous tile's last two rows
     float *ldsf = reinterpret_cast<float *>(lds);
@@ -257,8 +189,8 @@ __global__ __launch_bounds__(64) void sos_fused_kernel(const SosPlanDev *__restr
     const int seg = blockIdx.x % a.n_seg;
     const long long ch = blockIdx.x / a.n_seg;
     const float *in = a.in + ch * a.in_pitch;
-    float *yf = a.yf + ch * a.yf_pitch;
-    float *w = a.w + ch * a.w_pitch;
+    float *yf = SF > 0 ? a.yf + ch * a.yf_pitch : nullptr;
+    double *ckpt = a.ckpt + ch * a.ckpt_pitch;
     const long long T = a.T;
     const int edge = a.edge;
 
@@ -269,7 +201,8 @@ __global__ __launch_bounds__(64) void sos_fused_kernel(const SosPlanDev *__restr
     long long env_start = lo - PE0->warm;
     const bool env_true = env_start <= 0;
     if (env_start < 0) env_start = 0;
-    long long start = env_start - PF0->warm;
+    long long start = env_start;
+    if (SF > 0) start -= PF0->warm;
     if (start < 0) start = 0;               // zero state at sample 0 is the filter's true state
     const long long loop_end = last_seg ? T + edge : hi;   // the right extension may need a tile more
 
@@ -281,26 +214,13 @@ __global__ __launch_bounds__(64) void sos_fused_kernel(const SosPlanDev *__restr
     rprev[lane] = 0.f;
 
     for (long long tile = start; tile < loop_end; tile += TILE) {
-        // ---- x tile -> LDS
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const long long p = tile + 256 * k + 4 * lane;
-            float4 v;
-            if (p + 4 <= T) {
-                f4u t = *reinterpret_cast<const f4u *>(in + p);
-                v = make_float4(t.x, t.y, t.z, t.w);
-            } else {
-                v.x = p < T ? in[p] : 0.f;
-                v.y = p + 1 < T ? in[p + 1] : 0.f;
-                v.z = p + 2 < T ? in[p + 2] : 0.f;
-                v.w = p + 3 < T ? in[p + 3] : 0.f;
-            }
-            lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = v;
-        }
+        for (int k = 0; k < 8; k++)
+            lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = load_four(in, tile + 256 * k + 4 * lane, T);
         __syncthreads();
-        // ---- band-pass cascade: rows now hold the filtered samples
+        if constexpr (SF > 0) {
 #define CASC_S SF
-#define CASC_PLAN() PLANF()
+#define CASC_PLAN() PLAN_OF(PF0)
 #define CASC_CARRY cf_
 #define CASC_IN(v) (v)
 #include "sos_cascade.inc"
@@ -308,25 +228,14 @@ __global__ __launch_bounds__(64) void sos_fused_kernel(const SosPlanDev *__restr
 #undef CASC_PLAN
 #undef CASC_CARRY
 #undef CASC_IN
-        __syncthreads();
-        if (tile + TILE > lo && tile < hi) {
+            __syncthreads();
+            if (tile + TILE > lo && tile < hi) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const long long p = tile + 256 * k + 4 * lane;
-                const float4 v = lds[lds_slot(8 * k + (lane >> 3), lane & 7)];
-                if (p >= lo && p + 4 <= hi) {
-                    f4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
-                    *reinterpret_cast<f4u *>(yf + p) = t;
-                } else {
-                    const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        if (p + q >= lo && p + q < hi) yf[p + q] = e[q];
-                }
+                for (int k = 0; k < 8; k++)
+                    store_four(yf, tile + 256 * k + 4 * lane, lds[lds_slot(8 * k + (lane >> 3), lane & 7)], lo, hi, 0);
             }
         }
         if (tile < env_start) { __syncthreads(); continue; }    // band-pass warm-up only
-
         // ---- envelope input in place: r = gain*|y|, then the odd extension past T
         if (a.rectify) {
 #pragma unroll
@@ -354,8 +263,8 @@ __global__ __launch_bounds__(64) void sos_fused_kernel(const SosPlanDev *__restr
         }
         if (env_true && tile == 0) {
             // left odd extension: ext[i] = 2 r(0) - r(edge - i), i < edge, from zi * ext[0];
-            // wave-uniform serial steps, lane 0 stores the padded outputs
-            const SosPlanDev *P = PLANE();
+            // wave-uniform serial steps
+            const SosPlanDev *P = PLAN_OF(PE0);
             const float r0 = ldsf[lds_float_index(0)];
             const double x0 = (double)(2.f * r0 - ldsf[lds_float_index(edge)]);
 #pragma unroll
@@ -369,9 +278,13 @@ __global__ __launch_bounds__(64) void sos_fused_kernel(const SosPlanDev *__restr
                     ce_[2 * s2 + 1] = fma(-P->coef[s2][4], y, P->coef[s2][2] * cur);
                     cur = y;
                 }
-                if (lane == 0) w[i] = (float)cur;
             }
         }
+        if (tile >= lo && lane == 0) {
+#pragma unroll
+            for (int r = 0; r < DE; r++) ckpt[(tile / TILE) * DE + r] = ce_[r];
+        }
+        if (tile + TILE >= loop_end) break;
         // keep the last two rows for an extension that reaches back over the tile border
         {
             const float4 keep0 = lds[lds_slot(62 + ((lane >> 3) & 1), lane & 7)];
@@ -381,41 +294,129 @@ __global__ __launch_bounds__(64) void sos_fused_kernel(const SosPlanDev *__restr
                 rprev[4 * lane + 2] = keep0.z; rprev[4 * lane + 3] = keep0.w;
             }
         }
-        // ---- envelope forward cascade
+        // ---- envelope forward: phase 1 and the scan only, the state moves on to the next tile
 #define CASC_S SE
-#define CASC_PLAN() PLANE()
+#define CASC_PLAN() PLAN_OF(PE0)
 #define CASC_CARRY ce_
 #define CASC_IN(v) (v)
+#define CASC_NO_OUTPUT
 #include "sos_cascade.inc"
+#undef CASC_NO_OUTPUT
 #undef CASC_S
 #undef CASC_PLAN
 #undef CASC_CARRY
 #undef CASC_IN
         __syncthreads();
-        {
-            // scratch index = sample + edge; this wave owns samples [lo, hi) (+ the extension)
-            const long long wlo = lo, whi = last_seg ? T + edge : hi;
-            if (tile + TILE > wlo) {
+    }
+}
+
+struct BwdArgs {
+    const float *in;         // the trace the envelope is taken of (before rectification)
+    float *out;
+    const double *ckpt;
+    long long in_pitch, out_pitch, ckpt_pitch;
+    long long T, skip;
+    long long n_tiles;       // ceil((T + edge) / TILE)
+    long long seg_tiles, warm_tiles;
+    int n_seg, edge, rectify, clamp;
+    float gain;
+};
+
+template <int SE>
+__global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restrict__ P0, BwdArgs a)
+{
+    constexpr int DE = 2 * SE;
+    __shared__ float4 lds[64 * 8];
+    float *ldsf = reinterpret_cast<float *>(lds);
+    const int lane = threadIdx.x;
+    const int seg = blockIdx.x % a.n_seg;
+    const long long ch = blockIdx.x / a.n_seg;
+    const float *in = a.in + ch * a.in_pitch;
+    float *out = a.out + ch * a.out_pitch;
+    const double *ckpt = a.ckpt + ch * a.ckpt_pitch;
+    const long long T = a.T;
+    const int edge = a.edge;
+
+    // reversed tile index rt = n_tiles-1 - (p / TILE): the wave owns rt in [rt_lo, rt_hi)
+    const long long rt_lo = (long long)seg * a.seg_tiles;
+    long long rt_hi = rt_lo + a.seg_tiles;
+    if (rt_hi > a.n_tiles) rt_hi = a.n_tiles;
+    long long rt_start = rt_lo - a.warm_tiles;
+    if (rt_start < 0) rt_start = 0;
+
+    double cb_[DE];
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const long long p = tile + 256 * k + 4 * lane;
-                    const float4 v = lds[lds_slot(8 * k + (lane >> 3), lane & 7)];
-                    if (p >= wlo && p + 4 <= whi) {
-                        f4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
-                        *reinterpret_cast<f4u *>(w + p + edge) = t;
-                    } else {
-                        const float e[4] = {v.x, v.y, v.z, v.w};
+    for (int r = 0; r < DE; r++) cb_[r] = 0.0;
+
+    for (long long rt = rt_start; rt < rt_hi; rt++) {
+        const long long tidx = a.n_tiles - 1 - rt;
+        const long long tile = tidx * TILE;
+        if (tile + TILE <= a.skip) break;          // nothing below `skip` is kept
+        // ---- trace tile -> LDS, rectified
 #pragma unroll
-                        for (int q = 0; q < 4; q++)
-                            if (p + q >= wlo && p + q < whi) w[p + q + edge] = e[q];
-                    }
+        for (int k = 0; k < 8; k++) {
+            float4 v = load_four(in, tile + 256 * k + 4 * lane, T);
+            if (a.rectify)
+                v = make_float4(a.gain * fabsf(v.x), a.gain * fabsf(v.y), a.gain * fabsf(v.z), a.gain * fabsf(v.w));
+            lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = v;
+        }
+        __syncthreads();
+        if (tile + TILE > T) {
+            // right odd extension ext[T + i] = 2 r(T-1) - r(T-2-i), i < edge, straight from HBM
+            if (lane < edge) {
+                const long long pj = T + lane;
+                if (pj >= tile && pj < tile + TILE) {
+                    float ra = in[T - 1], rb = in[T - 2 - lane];
+                    if (a.rectify) { ra = a.gain * fabsf(ra); rb = a.gain * fabsf(rb); }
+                    ldsf[lds_float_index((int)(pj - tile))] = 2.f * ra - rb;
                 }
+            }
+            __syncthreads();
+        }
+        // ---- forward cascade again, from the state that entered this tile
+        double cfw_[DE];
+#pragma unroll
+        for (int r = 0; r < DE; r++) cfw_[r] = ckpt[tidx * DE + r];
+#define CASC_S SE
+#define CASC_PLAN() PLAN_OF(P0)
+#define CASC_CARRY cfw_
+#define CASC_IN(v) (v)
+#include "sos_cascade.inc"
+#undef CASC_CARRY
+        __syncthreads();
+        if (rt == 0) {
+            // scipy: backward pass starts from zi * y_fwd[-1]; pad the rest of the tile with it
+            const int last = (int)(T + edge - 1 - tile);
+            const float v0 = ldsf[lds_float_index(last)];
+            __syncthreads();
+            for (int s2 = last + 1 + lane; s2 < TILE; s2 += 64) ldsf[lds_float_index(s2)] = v0;
+            const SosPlanDev *P = PLAN_OF(P0);
+#pragma unroll
+            for (int r = 0; r < DE; r++) cb_[r] = P->zi[r] * (double)v0;
+            __syncthreads();
+        }
+        // ---- backward cascade over the forward outputs, last sample first
+#define CASC_CARRY cb_
+#define CASC_REVERSED
+#include "sos_cascade.inc"
+#undef CASC_REVERSED
+#undef CASC_S
+#undef CASC_PLAN
+#undef CASC_CARRY
+#undef CASC_IN
+        __syncthreads();
+        if (rt >= rt_lo) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                float4 v = lds[lds_slot(8 * k + (lane >> 3), lane & 7)];
+                if (a.clamp) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                store_four(out, tile + 256 * k + 4 * lane, v, a.skip, T, a.skip);
             }
         }
         __syncthreads();
     }
-#undef PLANF
-#undef PLANE
 }
 
 // pass-through / zero fill for the sos-is-None branches
@@ -621,9 +622,7 @@ void plan_segments(const hipdsp_ctx *ctx, long long N, long long channels, long 
     *n_seg = (int)best_n;
 }
 
-template <int MODE>
-int launch_scan(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const SosPlanDev *dev, int S, SeqArgs a,
-                long long channels, long long warm)
+int launch_scan(hipdsp_ctx *ctx, const SosPlanDev *dev, int S, SeqArgs a, long long channels, long long warm)
 {
     plan_segments(ctx, a.N, channels, warm, &a.seg_len, &a.n_seg);
     long long blocks = channels * a.n_seg;
@@ -633,16 +632,87 @@ int launch_scan(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const SosPlanDev *d
     }
     dim3 grid((unsigned)blocks), block(64);
     switch (S) {
-    case 1: hipLaunchKernelGGL((sos_scan_kernel<1, MODE>), grid, block, 0, ctx->stream, dev, a); break;
-    case 2: hipLaunchKernelGGL((sos_scan_kernel<2, MODE>), grid, block, 0, ctx->stream, dev, a); break;
-    case 3: hipLaunchKernelGGL((sos_scan_kernel<3, MODE>), grid, block, 0, ctx->stream, dev, a); break;
-    case 4: hipLaunchKernelGGL((sos_scan_kernel<4, MODE>), grid, block, 0, ctx->stream, dev, a); break;
+    case 1: hipLaunchKernelGGL((sos_scan_kernel<1>), grid, block, 0, ctx->stream, dev, a); break;
+    case 2: hipLaunchKernelGGL((sos_scan_kernel<2>), grid, block, 0, ctx->stream, dev, a); break;
+    case 3: hipLaunchKernelGGL((sos_scan_kernel<3>), grid, block, 0, ctx->stream, dev, a); break;
+    case 4: hipLaunchKernelGGL((sos_scan_kernel<4>), grid, block, 0, ctx->stream, dev, a); break;
     default:
         hipdsp_set_error("n_sections %d not in 1..%d", S, MAXS);
         return HIPDSP_ERR_UNSUPPORTED;
     }
-    (void)plan;
     return hd_launch_status("sos_scan_kernel");
+}
+
+// Envelope by checkpoints: forward sweep (optionally with the band-pass in front), then the
+// recomputing backward sweep.  `fplan` NULL: `x` is the trace to rectify.
+int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *edev, int SF, int SE, long long warmF,
+                    long long warmE, int edge, const float *x, long long x_pitch, float *yf,
+                    long long yf_pitch, float *env, long long env_pitch, long long channels,
+                    long long frames, long long skip, int rectify, double gain, int clamp, int phase)
+{
+    const long long n_tiles = (frames + edge + TILE - 1) / TILE;
+    const long long ckpt_pitch = n_tiles * 2 * SE;
+    void *work = nullptr;
+    int rc = hipdsp_scratch(ctx, sizeof(double) * (size_t)ckpt_pitch * (size_t)channels, &work);
+    if (rc != HIPDSP_OK) return rc;
+    if (phase != 2) {
+        CkptArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.in = x; fa.yf = yf; fa.ckpt = (double *)work;
+        fa.in_pitch = x_pitch; fa.yf_pitch = yf_pitch; fa.ckpt_pitch = ckpt_pitch;
+        fa.T = frames; fa.edge = edge; fa.rectify = rectify; fa.gain = (float)gain;
+        long long warm = warmF + warmE;
+        if (warmF >= (1LL << 40) || warmE >= (1LL << 40)) warm = 1LL << 50;
+        plan_segments(ctx, frames, channels, warm, &fa.seg_len, &fa.n_seg);
+        long long blocks = channels * fa.n_seg;
+        HD_REQUIRE(blocks <= 0x7fffffffLL, "grid too large");
+        dim3 grid((unsigned)blocks), block(64);
+#define HD_CKPT(A, B)                                                                              \
+    case (A) * 8 + (B):                                                                            \
+        hipLaunchKernelGGL((sos_ckpt_kernel<A, B>), grid, block, 0, ctx->stream, fdev, edev, fa);  \
+        break
+        switch (SF * 8 + SE) {
+            HD_CKPT(0, 1); HD_CKPT(0, 2); HD_CKPT(0, 3); HD_CKPT(0, 4);
+            HD_CKPT(1, 1); HD_CKPT(1, 2); HD_CKPT(1, 3); HD_CKPT(1, 4);
+            HD_CKPT(2, 1); HD_CKPT(2, 2); HD_CKPT(2, 3); HD_CKPT(2, 4);
+            HD_CKPT(3, 1); HD_CKPT(3, 2); HD_CKPT(3, 3); HD_CKPT(3, 4);
+            HD_CKPT(4, 1); HD_CKPT(4, 2); HD_CKPT(4, 3); HD_CKPT(4, 4);
+        default:
+            hipdsp_set_error("n_sections %d / %d not in 0..%d / 1..%d", SF, SE, MAXS, MAXS);
+            return HIPDSP_ERR_UNSUPPORTED;
+        }
+#undef HD_CKPT
+        rc = hd_launch_status("sos_ckpt_kernel");
+        if (rc != HIPDSP_OK) return rc;
+    }
+    if (phase == 1) return HIPDSP_OK;
+    if (ctx->mid_event) HD_CHECK_HIP(hipEventRecord(ctx->mid_event, ctx->stream));
+    if (frames - skip == 0) return HIPDSP_OK;
+    BwdArgs b;
+    memset(&b, 0, sizeof(b));
+    b.in = SF > 0 ? yf : x; b.in_pitch = SF > 0 ? yf_pitch : x_pitch;
+    b.out = env; b.out_pitch = env_pitch;
+    b.ckpt = (const double *)work; b.ckpt_pitch = ckpt_pitch;
+    b.T = frames; b.skip = skip; b.n_tiles = n_tiles; b.edge = edge;
+    b.rectify = rectify; b.clamp = clamp; b.gain = (float)gain;
+    const long long used_tiles = n_tiles - skip / TILE;      // tiles below `skip` are never visited
+    long long seg_len = 0;
+    plan_segments(ctx, used_tiles * TILE, channels, warmE, &seg_len, &b.n_seg);
+    b.seg_tiles = seg_len / TILE;
+    b.warm_tiles = warmE / TILE;
+    long long blocks = channels * b.n_seg;
+    HD_REQUIRE(blocks <= 0x7fffffffLL, "grid too large");
+    dim3 grid((unsigned)blocks), block(64);
+    switch (SE) {
+    case 1: hipLaunchKernelGGL((env_bwd_kernel<1>), grid, block, 0, ctx->stream, edev, b); break;
+    case 2: hipLaunchKernelGGL((env_bwd_kernel<2>), grid, block, 0, ctx->stream, edev, b); break;
+    case 3: hipLaunchKernelGGL((env_bwd_kernel<3>), grid, block, 0, ctx->stream, edev, b); break;
+    case 4: hipLaunchKernelGGL((env_bwd_kernel<4>), grid, block, 0, ctx->stream, edev, b); break;
+    default:
+        hipdsp_set_error("n_sections %d not in 1..%d", SE, MAXS);
+        return HIPDSP_ERR_UNSUPPORTED;
+    }
+    return hd_launch_status("env_bwd_kernel");
 }
 
 }  // namespace
@@ -776,9 +846,8 @@ int hipdsp_sosfilt(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const float *x, 
     SeqArgs a;
     memset(&a, 0, sizeof(a));
     a.in = x; a.out = y; a.in_pitch = x_pitch; a.out_pitch = y_pitch;
-    a.T = frames; a.N = frames; a.skip = skip; a.edge = 0; a.rectify = 0; a.gain = 1.f; a.clamp = 0;
-    return launch_scan<MODE_FILT>(ctx, plan, plan->dev, plan->host->n_sections, a, channels,
-                                  plan->host->warm);
+    a.N = frames; a.skip = skip;
+    return launch_scan(ctx, plan->dev, plan->host->n_sections, a, channels, plan->host->warm);
 }
 
 int hipdsp_sosfilt_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hipdsp_sosplan *eplan,
@@ -799,50 +868,9 @@ int hipdsp_sosfilt_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const 
     if (channels == 0) return HIPDSP_OK;
     HD_REQUIRE(x != nullptr && yf != nullptr && env != nullptr, "NULL data pointer");
     HD_REQUIRE(x_pitch >= frames && yf_pitch >= frames && env_pitch >= frames, "pitch smaller than row length");
-    const long long N = frames + 2LL * edge;
-    const long long wpitch = (N + 3) / 4 * 4;
-    void *work = nullptr;
-    int rc = hipdsp_scratch(ctx, sizeof(float) * (size_t)wpitch * (size_t)channels, &work);
-    if (rc != HIPDSP_OK) return rc;
-    FusedArgs fa;
-    memset(&fa, 0, sizeof(fa));
-    fa.in = x; fa.yf = yf; fa.w = (float *)work;
-    fa.in_pitch = x_pitch; fa.yf_pitch = yf_pitch; fa.w_pitch = wpitch;
-    fa.T = frames; fa.edge = edge; fa.rectify = rectify; fa.gain = (float)gain;
-    long long warm = fplan->host->warm + eplan->host->warm;
-    if (fplan->host->warm >= (1LL << 40) || eplan->host->warm >= (1LL << 40)) warm = 1LL << 50;
-    plan_segments(ctx, frames, channels, warm, &fa.seg_len, &fa.n_seg);
-    long long blocks = channels * fa.n_seg;
-    HD_REQUIRE(blocks <= 0x7fffffffLL, "grid too large");
-    dim3 grid((unsigned)blocks), block(64);
-    const int SF = fplan->host->n_sections, SE = eplan->host->n_sections;
-    if (phase != 2) {
-#define HD_FUSED(A, B)                                                                                  \
-    case (A) * 8 + (B):                                                                                 \
-        hipLaunchKernelGGL((sos_fused_kernel<A, B>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, fa); \
-        break
-    switch (SF * 8 + SE) {
-        HD_FUSED(1, 1); HD_FUSED(1, 2); HD_FUSED(1, 3); HD_FUSED(1, 4);
-        HD_FUSED(2, 1); HD_FUSED(2, 2); HD_FUSED(2, 3); HD_FUSED(2, 4);
-        HD_FUSED(3, 1); HD_FUSED(3, 2); HD_FUSED(3, 3); HD_FUSED(3, 4);
-        HD_FUSED(4, 1); HD_FUSED(4, 2); HD_FUSED(4, 3); HD_FUSED(4, 4);
-    default:
-        hipdsp_set_error("n_sections %d / %d not in 1..%d", SF, SE, MAXS);
-        return HIPDSP_ERR_UNSUPPORTED;
-    }
-#undef HD_FUSED
-    rc = hd_launch_status("sos_fused_kernel");
-    if (rc != HIPDSP_OK) return rc;
-    }
-    if (phase == 1) return HIPDSP_OK;
-    if (ctx->mid_event) HD_CHECK_HIP(hipEventRecord(ctx->mid_event, ctx->stream));
-    // backward pass over the reversed scratch -> env (trim the padding, clamp)
-    SeqArgs a;
-    memset(&a, 0, sizeof(a));
-    a.T = frames; a.N = N; a.skip = 0; a.edge = edge;
-    a.rectify = rectify; a.gain = (float)gain; a.clamp = clamp;
-    a.in = (const float *)work; a.in_pitch = wpitch; a.out = env; a.out_pitch = env_pitch;
-    return launch_scan<MODE_ENV_BWD>(ctx, eplan, eplan->dev, SE, a, channels, eplan->host->warm);
+    return launch_env_ckpt(ctx, fplan->dev, eplan->dev, fplan->host->n_sections, eplan->host->n_sections,
+                           fplan->host->warm, eplan->host->warm, edge, x, x_pitch, yf, yf_pitch, env, env_pitch,
+                           channels, frames, 0, rectify, gain, clamp, phase);
 }
 
 int hipdsp_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const float *x, int64_t x_pitch,
@@ -873,26 +901,8 @@ int hipdsp_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const float *x,
     if (channels == 0) return HIPDSP_OK;
     HD_REQUIRE(x != nullptr && y != nullptr, "NULL data pointer");
     HD_REQUIRE(x_pitch >= frames && y_pitch >= frames - skip, "pitch smaller than row length");
-    const long long N = frames + 2LL * edge;
-    const long long wpitch = (N + 3) / 4 * 4;
-    void *work = nullptr;
-    int rc = hipdsp_scratch(ctx, sizeof(float) * (size_t)wpitch * (size_t)channels, &work);
-    if (rc != HIPDSP_OK) return rc;
-    SeqArgs a;
-    memset(&a, 0, sizeof(a));
-    a.T = frames; a.N = N; a.skip = skip; a.edge = edge;
-    a.rectify = rectify; a.gain = (float)gain; a.clamp = clamp;
-    // forward pass over the odd-extended, rectified input -> scratch
-    a.in = x; a.in_pitch = x_pitch; a.out = (float *)work; a.out_pitch = wpitch;
-    rc = launch_scan<MODE_ENV_FWD>(ctx, plan, plan->dev, plan->host->n_sections, a, channels,
-                                   plan->host->warm);
-    if (rc != HIPDSP_OK) return rc;
-    if (ctx->mid_event) HD_CHECK_HIP(hipEventRecord(ctx->mid_event, ctx->stream));
-    if (frames - skip == 0) return HIPDSP_OK;
-    // backward pass over the reversed scratch -> y (trim edge, skip, clamp)
-    a.in = (const float *)work; a.in_pitch = wpitch; a.out = y; a.out_pitch = y_pitch;
-    return launch_scan<MODE_ENV_BWD>(ctx, plan, plan->dev, plan->host->n_sections, a, channels,
-                                     plan->host->warm);
+    return launch_env_ckpt(ctx, nullptr, plan->dev, 0, plan->host->n_sections, 0, plan->host->warm, edge, x,
+                           x_pitch, nullptr, 0, y, y_pitch, channels, frames, skip, rectify, gain, clamp, 0);
 }
 
 }  // extern "C"

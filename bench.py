@@ -210,7 +210,7 @@ def main():
         counter = [0]
     else:
         ds = hipdsp.DeviceArray(ctx, (C, nd, F), np.float32)
-    ctx.reserve(4*C*((T + 2*edge + 3)//4*4))
+    ctx.reserve(8*C*((T + edge + 2047)//2048)*2*len(esos))      # envelope state checkpoints
     hipdsp.synth(ctx, dx, T, C, T, args.rate, 1234 + 2, c0=rank*C, c_total=world*C)
     ctx.synchronize()
 
@@ -235,8 +235,9 @@ def main():
         if ev:
             ctx.record(ev[0])
         if fused:
-            # band-pass + envelope forward in one pass over x (filtered trace written once,
-            # not re-read); the backward pass follows after the spectrogram
+            # band-pass + envelope forward sweep in one pass over x: writes the filtered trace and
+            # the envelope state entering every 2048-sample tile; the backward sweep (which
+            # recomputes the forward output tile by tile) follows after the spectrogram
             hipdsp.sosfilt_envelope(ctx, plan, eplan, dx, T, df, T, de, T, C, T, rectify=True,
                                     gain=np.pi/2, clamp=True, phase=1)
         else:
@@ -303,11 +304,11 @@ def main():
 
     # per-kernel averages from the HIP events recorded inside the timed region
     if fused:
-        names = ['sos_fused<S=%d+%d,filt+env_fwd>' % (len(sos), len(esos)), 'spectrogram', 'tile_copy+gather_wait',
-                 'sos_scan<S=%d,env_bwd>' % len(esos), 'unused']
+        names = ['sos_ckpt<S=%d+%d,filt+env_state>' % (len(sos), len(esos)), 'spectrogram', 'tile_copy+gather_wait',
+                 'env_bwd<S=%d>' % len(esos), 'unused']
     else:
-        names = ['sos_scan<S=%d,filt>' % len(sos), 'spectrogram', 'sos_scan<S=%d,env_fwd>' % len(esos),
-                 'sos_scan<S=%d,env_bwd>' % len(esos), 'unused']
+        names = ['sos_scan<S=%d,filt>' % len(sos), 'spectrogram', 'sos_ckpt<S=0+%d,env_state>' % len(esos),
+                 'env_bwd<S=%d>' % len(esos), 'unused']
     ms = dict.fromkeys(names, 0.0)
     for i in range(args.steps):
         e = events[i]
@@ -318,18 +319,19 @@ def main():
         ms[names[4]] += ctx.elapsed_ms(e[3], e[4])
     for k in ms:
         ms[k] /= args.steps
+    ckpt_bytes = 8.0*C*((T + edge + 2047)//2048)*2*len(esos)
     if fused:
         alg_bytes = {                   # algorithmic HBM bytes per launch
-            names[0]: 12.0*C*T + 4.0*C*2*edge,         # x read, filtered + forward scratch written
+            names[0]: 8.0*C*T + ckpt_bytes,            # x read, filtered trace + tile states written
             names[1]: 4.0*C*T + 4.0*C*nd*F,
-            names[3]: 8.0*C*T + 4.0*C*2*edge,
+            names[3]: 8.0*C*T + ckpt_bytes,            # filtered trace + tile states read, envelope written
         }
     else:
         alg_bytes = {
             names[0]: 8.0*C*T,
             names[1]: 4.0*C*T + 4.0*C*nd*F,
-            names[2]: 8.0*C*(T + 2*edge),
-            names[3]: 8.0*C*T + 4.0*C*2*edge,
+            names[2]: 4.0*C*T + ckpt_bytes,
+            names[3]: 8.0*C*T + ckpt_bytes,
         }
     dom = max(alg_bytes, key=lambda k: ms[k])
     achieved = alg_bytes[dom]/(ms[dom]*1e-3)/1e9
@@ -375,7 +377,7 @@ def main():
                                (f', pipelined all-gather of the {args.tile_seconds:g} s spectrogram tile '
                                 f'({4*C*tile_frames*F/1e9:.2f} GB per rank)' if multi else ''),
                 'iir_warmup_samples': {'bandpass': warm_f, 'envelope': warm_e},
-                'envelope_forward': 'fused into the band-pass kernel' if fused else 'own launch',
+                'envelope_forward': ('state checkpoints, ' + ('fused into the band-pass kernel' if fused else 'own launch')),
             },
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -130,6 +130,26 @@ def test_envelope_long_vs_oracle(oracle, env, order, hp, rate, T):
     assert rel_err(got, want[7:]) < TOL
 
 
+@pytest.mark.parametrize('T', [2050, 70000, 300000])
+def test_envelope_skip_values_vs_oracle(oracle, T):
+    """nbefore (skip) below, at and above tile borders: the backward sweep stops at the tile that
+    holds `skip`, the forward state sweep still covers the whole slab."""
+    from audian_amd.design import butter_sos
+    rate = 48000.0
+    rng = np.random.default_rng(T)
+    sos = butter_sos(2, 500.0, 'lowpass', rate)
+    x = synth(rng, T, 2, rate)
+    want = np.zeros((T, 2))
+    oracle.envelope_process(sos, x.astype(np.float64), want, 0)
+    for skip in (0, 1, 2047, 2048, 2049, 5000, 65536, T - 1, T):
+        if skip > T:
+            continue
+        got = gh.gpu_envelope(sos, x, skip=skip)
+        assert got.shape[0] == T - skip
+        if skip < T:
+            assert rel_err(got, want[skip:]) < TOL, skip
+
+
 def test_spectrogram_golden():
     g = load_golden('spectrogram')
     for k in range(int(g['count'])):

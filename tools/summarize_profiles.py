@@ -8,6 +8,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -16,9 +17,18 @@ os.makedirs(os.path.dirname(dst) or '.', exist_ok=True)
 
 
 def short(name):
-    for key, tag in (('sos_fused_kernel<2, 1>', 'sos_fused<S=2+1,filt+env_fwd>'), ('sos_scan_kernel<2, 0>', 'sos_scan<S=2,filt>'), ('sos_scan_kernel<1, 1>', 'sos_scan<S=1,env_fwd>'),
-                     ('sos_scan_kernel<1, 2>', 'sos_scan<S=1,env_bwd>'), ('spec_fast_kernel', 'spectrogram'),
-                     ('spec2_kernel', 'spectrogram'), ('spec_generic', 'spectrogram_generic'), ('synth', 'synth')):
+    """Kernel names as bench.py prints them."""
+    m = re.search(r'sos_ckpt_kernel<(\d), (\d)>', name)
+    if m:
+        return ('sos_ckpt<S=%s+%s,filt+env_state>' if m.group(1) != '0' else 'sos_ckpt<S=%s+%s,env_state>') % m.groups()
+    m = re.search(r'env_bwd_kernel<(\d)>', name)
+    if m:
+        return 'env_bwd<S=%s>' % m.group(1)
+    m = re.search(r'sos_scan_kernel<(\d)>', name)
+    if m:
+        return 'sos_scan<S=%s,filt>' % m.group(1)
+    for key, tag in (('spec_fast_kernel', 'spectrogram'), ('spec2_kernel', 'spectrogram'),
+                     ('spec_generic', 'spectrogram_generic'), ('synth', 'synth')):
         if key in name:
             return tag
     return name[:60]
