@@ -90,6 +90,7 @@ _SIGNATURES = {
     'hipdsp_event_create': ([_vp, _pp], _int),
     'hipdsp_event_destroy': ([_vp, _vp], _int),
     'hipdsp_event_record': ([_vp, _vp], _int),
+    'hipdsp_event_wait': ([_vp, _vp], _int),
     'hipdsp_event_elapsed_ms': ([_vp, _vp, _vp, ctypes.POINTER(ctypes.c_float)], _int),
     'hipdsp_pack_f64': ([_vp, _vp, _vp, _i64, _i64, _i64], _int),
     'hipdsp_pack_f32': ([_vp, _vp, _vp, _i64, _i64, _i64], _int),

@@ -276,6 +276,13 @@ int hipdsp_event_record(hipdsp_ctx *ctx, void *event)
     return HIPDSP_OK;
 }
 
+int hipdsp_event_wait(hipdsp_ctx *ctx, void *event)
+{
+    HD_REQUIRE(ctx != nullptr && event != nullptr, "NULL argument");
+    HD_CHECK_HIP(hipStreamWaitEvent(ctx->stream, (hipEvent_t)event, 0));
+    return HIPDSP_OK;
+}
+
 int hipdsp_event_elapsed_ms(hipdsp_ctx *ctx, void *start, void *stop, float *ms)
 {
     HD_REQUIRE(ctx != nullptr && start && stop && ms, "NULL argument");

@@ -74,6 +74,10 @@ class Context:
     def record(self, ev):
         check(lib.hipdsp_event_record(self._h, ev))
 
+    def wait_event(self, ev):
+        """Later work on this context's stream waits for `ev` (recorded on any stream)."""
+        check(lib.hipdsp_event_wait(self._h, ev))
+
     def elapsed_ms(self, start, stop):
         ms = ctypes.c_float()
         check(lib.hipdsp_event_elapsed_ms(self._h, start, stop, ctypes.byref(ms)))

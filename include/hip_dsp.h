@@ -108,6 +108,9 @@ int hipdsp_memcpy2d_d2d(hipdsp_ctx *ctx, void *dst, size_t dst_pitch, const void
 int hipdsp_event_create(hipdsp_ctx *ctx, void **event);
 int hipdsp_event_destroy(hipdsp_ctx *ctx, void *event);
 int hipdsp_event_record(hipdsp_ctx *ctx, void *event);
+/* Work queued on the context's stream after this call waits for `event` (recorded on any stream
+ * of the device): orders two contexts that run on streams of their own. */
+int hipdsp_event_wait(hipdsp_ctx *ctx, void *event);
 int hipdsp_event_elapsed_ms(hipdsp_ctx *ctx, void *start, void *stop, float *ms);
 
 /* Profiling hook: when set (non-NULL), hipdsp_envelope records this event between
