@@ -170,6 +170,54 @@ __device__ __forceinline__ float wave_sum(float v)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// Packed-fp32 complex helpers (v_pk_*_f32 computes two lanes per instruction; op_sel picks the
+// low/high dword of a source pair for the low lane, op_sel_hi for the high lane, neg_lo/neg_hi
+// negate a source per lane).  hipcc's SLP vectoriser finds the packed form inside the small
+// in-register DFTs but not across the twiddle tables and the split step of the big kernel.
+__device__ __forceinline__ v2f as_v2f(float2 a) { v2f r = {a.x, a.y}; return r; }
+__device__ __forceinline__ float2 as_f2(v2f a) { return make_float2(a.x, a.y); }
+// a * b: same roundings as cmul() (product, then fma)
+__device__ __forceinline__ v2f pk_cmul(v2f a, v2f b)
+{
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(b));  // (-ay by, ay bx)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));   // (ax bx + t.x, ax by + t.y)
+    return r;
+}
+// (-i a) * b = (ay bx + ax by, ay by - ax bx)
+__device__ __forceinline__ v2f pk_cmul_negi(v2f a, v2f b)
+{
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(t) : "v"(a), "v"(b));               // (ay bx, ay by)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+__device__ __forceinline__ v2f pk_add_conj(v2f a, v2f b)      // a + conj(b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_sub_conj(v2f a, v2f b)      // a - conj(b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// (a.x + b.x, a.x - b.x) and (a.y + b.y, a.y - b.y)
+__device__ __forceinline__ v2f pk_sumdiff_x(v2f a, v2f b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_sumdiff_y(v2f a, v2f b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // 8-byte global load the compiler does not track (the caller counts vmcnt by hand)
 __device__ __forceinline__ v2f asm_load8(const float *p, int imm)
 {
@@ -188,13 +236,23 @@ __device__ __forceinline__ void stockham_stage(float2 *v, float2 *fb, const floa
 {
     constexpr int PPL = M / LPF;
     constexpr int NB = PPL / R;          // butterflies per lane
+    // Padded frame-buffer indices as (per-lane part) + (compile-time part): pad16(a + c) =
+    // pad16(a) + c + c/16 whenever c is a multiple of 16, so the constant goes into the DS
+    // instruction's offset field instead of a shift and two adds per access.
+    constexpr bool SPLIT_LOAD = LPF % 16 == 0 && (M / R) % 16 == 0;
+    constexpr bool STORE_R16 = NS == 1 && R == 16;                       // index = 17 j + t
+    constexpr bool STORE_NS16 = NS % 16 == 0 && LPF % NS == 0;           // k, j/NS split by lane
     // all loads of the stage come before any store: the exchange is in place and one
     // butterfly's outputs land on another butterfly's inputs
     if (LOAD) {
+        const int pl = pad16(l);
 #pragma unroll
         for (int u = 0; u < NB; u++)
 #pragma unroll
-            for (int t = 0; t < R; t++) v[u * R + t] = fb[pad16(l + LPF * u + t * (M / R))];
+            for (int t = 0; t < R; t++) {
+                const int c = LPF * u + t * (M / R);
+                v[u * R + t] = fb[SPLIT_LOAD ? pl + c + c / 16 : pad16(l + c)];
+            }
     }
 #pragma unroll
     for (int u = 0; u < NB; u++) {
@@ -203,28 +261,37 @@ __device__ __forceinline__ void stockham_stage(float2 *v, float2 *fb, const floa
         if (NS > 1) {
             const int k = j % NS;
             if (POWERS) {            // table holds W^k only; W^(k t) by repeated multiplication
-                const float2 w1 = tw[k];
-                float2 w = w1;
+                const v2f w1 = as_v2f(tw[k]);
+                v2f w = w1;
 #pragma unroll
                 for (int t = 1; t < R; t++) {
-                    b[t] = cmul(b[t], w);
-                    if (t + 1 < R) w = cmul(w, w1);
+                    b[t] = as_f2(pk_cmul(as_v2f(b[t]), w));
+                    if (t + 1 < R) w = pk_cmul(w, w1);
                 }
             } else {
 #pragma unroll
-                for (int t = 1; t < R; t++) b[t] = cmul(b[t], tw[(t - 1) * NS + k]);
+                for (int t = 1; t < R; t++) b[t] = as_f2(pk_cmul(as_v2f(b[t]), as_v2f(tw[(t - 1) * NS + k])));
             }
         }
         dft<R>(b);
     }
     if (STORE) {
+        int sl = 0;                      // per-lane part of the store index
+        if (STORE_R16) sl = 17 * l;
+        else if (STORE_NS16) sl = (l / NS) * (NS * R + NS * R / 16) + pad16(l % NS);
 #pragma unroll
         for (int u = 0; u < NB; u++) {
             const int j = l + LPF * u;
             const int k = j % NS;
             const int base = (j / NS) * NS * R + k;
 #pragma unroll
-            for (int t = 0; t < R; t++) fb[pad16(base + t * NS)] = v[u * R + t];
+            for (int t = 0; t < R; t++) {
+                int idx;
+                if (STORE_R16) idx = sl + 17 * LPF * u + t;
+                else if (STORE_NS16) idx = sl + u * (LPF / NS) * (NS * R + NS * R / 16) + t * (NS + NS / 16);
+                else idx = pad16(base + t * NS);
+                fb[idx] = v[u * R + t];
+            }
         }
     }
 }
@@ -318,7 +385,7 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? 3 : 1) * WAVES / 4) voi
         float *o = oc + frame * (long long)F;
         float *od = DB ? dc + frame * (long long)F : nullptr;
         float2 v[PPL];
-        float s = 0.f;
+        v2f acc = {0.f, 0.f};                             // even and odd samples side by side (v_pk_add_f32)
 #pragma unroll
         for (int u = 0; u < PPL / R1; u++)
 #pragma unroll
@@ -326,8 +393,9 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? 3 : 1) * WAVES / 4) voi
                 v2f &r = t < R1H ? lo[u * R1H + t] : hi[u * R1H + t - R1H];
                 asm volatile("" : "+v"(r));               // not before the counted wait
                 v[u * R1 + t] = make_float2(r.x, r.y);
-                s += r.x + r.y;
+                acc += r;
             }
+        float s = acc.x + acc.y;
         if (LPF == 64) {
             s = wave_sum(s);
         } else {
@@ -335,13 +403,14 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? 3 : 1) * WAVES / 4) voi
             for (int d = LPF / 2; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
         }
         const float mean = s * (1.0f / (float)NFFT);
+        const v2f mean2 = {mean, mean};
 #pragma unroll
         for (int u = 0; u < PPL / R1; u++)
 #pragma unroll
             for (int t = 0; t < R1; t++) {
-                const float2 w = win[l + LPF * u + t * (M / R1)];
+                const v2f w = as_v2f(win[l + LPF * u + t * (M / R1)]);
                 float2 &e = v[u * R1 + t];
-                e = make_float2((e.x - mean) * w.x, (e.y - mean) * w.y);
+                e = as_f2((as_v2f(e) - mean2) * w);
             }
         stockham_stage<R1, 1, M, LPF, false, true>(v, fb, tw2, l);
         stockham_stage<R2, R1, M, LPF, true, true>(v, fb, tw2, l);
@@ -362,6 +431,7 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? 3 : 1) * WAVES / 4) voi
         // with ds_bpermute instead of a third trip through LDS memory.
         constexpr int NB3 = PPL / R3;
         float pk_last = 0.f;
+        const v2f hscale2 = {0.5f * scale, 0.5f * scale};
 #pragma unroll
         for (int m = 0; m < PPL / 2; m++) {
             const int k = l + LPF * m;
@@ -376,13 +446,13 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? 3 : 1) * WAVES / 4) voi
                 const float2 z0 = v[(m0 % NB3) * R3 + m0 / NB3];
                 zm = (l == 0) ? z0 : zm;
             }
-            // E = (zk + conj zm)/2, O = -i (zk - conj zm)/2; the halves go into the scale
-            const float2 e = make_float2(zk.x + zm.x, zk.y - zm.y);
-            const float2 od2 = make_float2(zk.y + zm.y, zm.x - zk.x);
-            const float2 t = cmul(od2, twn[k]);
-            const float2 a = cadd(e, t), b = csub(e, t);
-            float pk = 0.5f * scale * (a.x * a.x + a.y * a.y);
-            float pm = 0.5f * scale * (b.x * b.x + b.y * b.y);
+            // E = (zk + conj zm)/2, O = -i (zk - conj zm)/2; the halves go into the scale.
+            // X[k] = E + W^k O, X[M-k] = conj(E - W^k O): real parts in `re`, imaginary in `im`
+            const v2f e = pk_add_conj(as_v2f(zk), as_v2f(zm));
+            const v2f t = pk_cmul_negi(pk_sub_conj(as_v2f(zk), as_v2f(zm)), as_v2f(twn[k]));
+            const v2f re = pk_sumdiff_x(e, t), im = pk_sumdiff_y(e, t);
+            const v2f pw = (re * re + im * im) * hscale2;
+            float pk = pw.x, pm = pw.y;
             if (m == 0) {
                 // bin 0 pairs with itself: DC = re + im, Nyquist = re - im, not doubled
                 const float dc0 = zk.x + zk.y, ny = zk.x - zk.y;
