@@ -190,8 +190,7 @@ def main():
     ctx = hipdsp.Context(local_rank, stream)
     if args.max_segments:
         ctx.set_max_segments(args.max_segments)
-    # The spectrogram (VALU-bound) and the envelope backward sweep (HBM/latency-bound) both only
-    # read the filtered trace: they run next to each other on two streams, ordered by events.
+    # The spectrogram and the envelope backward sweep both only read the filtered trace: they run next to each other on two streams, ordered by events.
     overlap = not args.no_overlap
     sctx, sstream = ctx, None
     if overlap:
