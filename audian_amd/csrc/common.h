@@ -21,6 +21,7 @@ struct hipdsp_ctx {
     int force_generic_fft; // tests: use the generic radix-2 kernel for every nfft
     void *fft_tables2[20]; // same for the two-stage kernel: tw2 | twn | window
     int sos_waves_per_cu;  // experiments: resident waves per CU the IIR planner aims for
+    int sos_prefetch;      // experiments: register prefetch of the next tile in the envelope sweeps
     int spec_no_half;      // experiments/tests: do not reuse the overlapped half frame
     int spec_fpw, spec_kernel;   // experiments (tools/), 0 = defaults
 };

@@ -52,6 +52,7 @@ int hipdsp_ctx_create(int device, void *stream, hipdsp_ctx **out)
     ctx->spec_fpw = ctx->spec_kernel = 0;
     ctx->sos_waves_per_cu = 0;
     ctx->spec_no_half = 0;
+    ctx->sos_prefetch = 1;
     for (int i = 0; i < 20; i++) ctx->fft_tables2[i] = nullptr;
     *out = ctx;
     return HIPDSP_OK;
@@ -98,6 +99,7 @@ int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value)
     if (strcmp(name, "force_generic_fft") == 0) { ctx->force_generic_fft = value != 0; return HIPDSP_OK; }
     if (strcmp(name, "spec_fpw") == 0) { ctx->spec_fpw = (int)value; return HIPDSP_OK; }
     if (strcmp(name, "sos_waves_per_cu") == 0) { ctx->sos_waves_per_cu = (int)value; return HIPDSP_OK; }
+    if (strcmp(name, "sos_prefetch") == 0) { ctx->sos_prefetch = value != 0; return HIPDSP_OK; }
     if (strcmp(name, "spec_no_half") == 0) { ctx->spec_no_half = value != 0; return HIPDSP_OK; }
     if (strcmp(name, "spec_kernel") == 0) { ctx->spec_kernel = (int)value; return HIPDSP_OK; }
     hipdsp_set_error("unknown option '%s'", name);

@@ -177,7 +177,24 @@ struct CkptArgs {
     float gain;
 };
 
-template <int SF, int SE>
+// 16-byte global load the compiler does not track: the caller counts vmcnt by hand, so that the
+// wait for a prefetched tile does not also wait for the stores issued after it.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v4f asm_load16(const void *p)
+{
+    v4f r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ float asm_load4(const float *p)
+{
+    float r;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+
+template <int SF, int SE, bool PREFETCH>
 __global__ __launch_bounds__(64) void sos_ckpt_kernel(const SosPlanDev *__restrict__ PF0,
                                                       const SosPlanDev *__restrict__ PE0, CkptArgs a)
 {
@@ -213,11 +230,56 @@ __global__ __launch_bounds__(64) void sos_ckpt_kernel(const SosPlanDev *__restri
     for (int r = 0; r < DE; r++) ce_[r] = 0.0;
     rprev[lane] = 0.f;
 
-    for (long long tile = start; tile < loop_end; tile += TILE) {
+    // Prefetch (see env_bwd_kernel for the rules): the next tile is requested as soon as this one
+    // is in LDS; with a band-pass in front (SF > 0) the wait sits right behind the 8 vector stores
+    // of the filtered tile (`vmcnt(7)`), otherwise at the end of the iteration.  The fetch is
+    // unconditional (a tile that cannot be prefetched fetches the highest full tile instead).
+    v4f nx[8];
+    bool pre = false;
+    const long long top_full = (T / TILE - 1) * TILE;            // host guarantees >= 0
+    auto fetch = [&](long long t0) {
 #pragma unroll
-        for (int k = 0; k < 8; k++)
-            lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = load_four(in, tile + 256 * k + 4 * lane, T);
+        for (int k = 0; k < 8; k++) nx[k] = asm_load16(in + t0 + 256 * k + 4 * lane);
+    };
+    if (PREFETCH) {
+        pre = start < loop_end && start + TILE <= T;
+        fetch(pre ? start : top_full);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    for (long long tile = start; tile < loop_end; tile += TILE) {
+        if (PREFETCH && pre) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                asm volatile("" : "+v"(nx[k]));
+                lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = make_float4(nx[k].x, nx[k].y, nx[k].z, nx[k].w);
+            }
+        } else if (PREFETCH) {
+            // a tile that reaches past T: untracked loads from clamped addresses, zeros past T
+#pragma unroll 1
+            for (int k = 0; k < 8; k++) {
+                const long long p = tile + 256 * k + 4 * lane;
+                v4f t;
+                t.x = asm_load4(in + (p < T ? p : T - 1));
+                t.y = asm_load4(in + (p + 1 < T ? p + 1 : T - 1));
+                t.z = asm_load4(in + (p + 2 < T ? p + 2 : T - 1));
+                t.w = asm_load4(in + (p + 3 < T ? p + 3 : T - 1));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("" : "+v"(t));
+                lds[lds_slot(8 * k + (lane >> 3), lane & 7)] =
+                    make_float4(p < T ? t.x : 0.f, p + 1 < T ? t.y : 0.f, p + 2 < T ? t.z : 0.f, p + 3 < T ? t.w : 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = load_four(in, tile + 256 * k + 4 * lane, T);
+        }
         __syncthreads();
+        if (PREFETCH) {
+            const long long next = tile + TILE;
+            pre = next < loop_end && next + TILE <= T;
+            fetch(pre ? next : top_full);
+        }
         if constexpr (SF > 0) {
 #define CASC_S SF
 #define CASC_PLAN() PLAN_OF(PF0)
@@ -230,12 +292,30 @@ __global__ __launch_bounds__(64) void sos_ckpt_kernel(const SosPlanDev *__restri
 #undef CASC_IN
             __syncthreads();
             if (tile + TILE > lo && tile < hi) {
+                if (tile >= lo && tile + TILE <= hi) {
+                    // interior tile: exactly 8 vector stores, then the counted wait
 #pragma unroll
-                for (int k = 0; k < 8; k++)
-                    store_four(yf, tile + 256 * k + 4 * lane, lds[lds_slot(8 * k + (lane >> 3), lane & 7)], lo, hi, 0);
+                    for (int k = 0; k < 8; k++) {
+                        const float4 v = lds[lds_slot(8 * k + (lane >> 3), lane & 7)];
+                        f4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+                        *reinterpret_cast<f4u *>(yf + tile + 256 * k + 4 * lane) = t;
+                    }
+                    if (PREFETCH) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        store_four(yf, tile + 256 * k + 4 * lane, lds[lds_slot(8 * k + (lane >> 3), lane & 7)], lo, hi, 0);
+                    if (PREFETCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            } else if (PREFETCH) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // warm-up tile: no stores to count
             }
         }
-        if (tile < env_start) { __syncthreads(); continue; }    // band-pass warm-up only
+        if (tile < env_start) {                                  // band-pass warm-up only
+            if (PREFETCH && SF == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            continue;
+        }
         // ---- envelope input in place: r = gain*|y|, then the odd extension past T
         if (a.rectify) {
 #pragma unroll
@@ -284,7 +364,10 @@ __global__ __launch_bounds__(64) void sos_ckpt_kernel(const SosPlanDev *__restri
 #pragma unroll
             for (int r = 0; r < DE; r++) ckpt[(tile / TILE) * DE + r] = ce_[r];
         }
-        if (tile + TILE >= loop_end) break;
+        if (tile + TILE >= loop_end) {
+            if (PREFETCH && SF == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            break;
+        }
         // keep the last two rows for an extension that reaches back over the tile border
         {
             const float4 keep0 = lds[lds_slot(62 + ((lane >> 3) & 1), lane & 7)];
@@ -306,6 +389,7 @@ __global__ __launch_bounds__(64) void sos_ckpt_kernel(const SosPlanDev *__restri
 #undef CASC_PLAN
 #undef CASC_CARRY
 #undef CASC_IN
+        if (PREFETCH && SF == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 }
@@ -322,7 +406,7 @@ struct BwdArgs {
     float gain;
 };
 
-template <int SE>
+template <int SE, bool PREFETCH>
 __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restrict__ P0, BwdArgs a)
 {
     constexpr int DE = 2 * SE;
@@ -348,20 +432,115 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
 #pragma unroll
     for (int r = 0; r < DE; r++) cb_[r] = 0.0;
 
+    // Prefetch: the next tile (one below) and its checkpoint are requested right after this
+    // tile went into LDS, i.e. before this tile's arithmetic and stores.  The loads are inline
+    // asm (hipcc does not track them), and the wait for them sits at the END of the iteration
+    // behind the 8 vector stores: `s_waitcnt vmcnt(7)` lets those stores stay in flight while
+    // every older load has landed.  Iterations without exactly those stores wait vmcnt(0).
+    // (The waits sit inside the branches, not behind a flag, so that the ISA check can follow them.)
+    // Every load inside the loop is such an asm load: a load hipcc tracks would make it insert
+    // its own vmcnt(0), which drains the prefetch as well.
+    v4f nx[8], nck[SE];
+    bool pre = false;
+    auto fetch = [&](long long tidx) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) nx[k] = asm_load16(in + tidx * TILE + 256 * k + 4 * lane);
+#pragma unroll
+        for (int i = 0; i < SE; i++) nck[i] = asm_load16(ckpt + tidx * DE + 2 * i);
+    };
+    // The fetch itself is unconditional (a tile that cannot be prefetched fetches the highest full
+    // tile instead and drops it): a conditional asm load would make `nx` a phi of two register
+    // sets, and the copies hipcc inserts for it read the registers while the loads are in flight.
+    const long long top_full = T / TILE - 1;                     // host guarantees >= 0
+    auto prefetchable = [&](long long tidx) { return tidx >= 0 && tidx <= top_full && tidx * TILE + TILE > a.skip; };
+    if (PREFETCH) {
+        const long long t0 = a.n_tiles - 1 - rt_start;
+        pre = rt_start < rt_hi && prefetchable(t0);
+        fetch(pre ? t0 : top_full);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the first tile has nothing to hide behind
+    }
+
     for (long long rt = rt_start; rt < rt_hi; rt++) {
         const long long tidx = a.n_tiles - 1 - rt;
         const long long tile = tidx * TILE;
         if (tile + TILE <= a.skip) break;          // nothing below `skip` is kept
+        double cfw_[DE];
         // ---- trace tile -> LDS, rectified
+        if (PREFETCH && pre) {
+            // (the wait for this tile's prefetch sits at the end of the previous iteration, behind
+            // the stores it is counted against)
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            float4 v = load_four(in, tile + 256 * k + 4 * lane, T);
-            if (a.rectify)
-                v = make_float4(a.gain * fabsf(v.x), a.gain * fabsf(v.y), a.gain * fabsf(v.z), a.gain * fabsf(v.w));
-            lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = v;
+            for (int k = 0; k < 8; k++) {
+                asm volatile("" : "+v"(nx[k]));
+                float4 v = make_float4(nx[k].x, nx[k].y, nx[k].z, nx[k].w);
+                if (a.rectify)
+                    v = make_float4(a.gain * fabsf(v.x), a.gain * fabsf(v.y), a.gain * fabsf(v.z), a.gain * fabsf(v.w));
+                lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < SE; i++) {
+                asm volatile("" : "+v"(nck[i]));
+                const v2d d = __builtin_bit_cast(v2d, nck[i]);
+                cfw_[2 * i] = d.x; cfw_[2 * i + 1] = d.y;
+            }
+            __syncthreads();
+        } else if (PREFETCH) {
+            // a tile that touches T (the top one or two of a channel).  Every load of this loop is
+            // an untracked asm load: hipcc's own vmcnt(0) for a tracked one would also drain the
+            // prefetch issued further down.  Clamped addresses are always valid; samples past T
+            // become zero.
+#pragma unroll 1
+            for (int k = 0; k < 8; k++) {
+                const long long p = tile + 256 * k + 4 * lane;
+                v4f t;
+                t.x = asm_load4(in + (p < T ? p : T - 1));
+                t.y = asm_load4(in + (p + 1 < T ? p + 1 : T - 1));
+                t.z = asm_load4(in + (p + 2 < T ? p + 2 : T - 1));
+                t.w = asm_load4(in + (p + 3 < T ? p + 3 : T - 1));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("" : "+v"(t));
+                float4 v = make_float4(p < T ? t.x : 0.f, p + 1 < T ? t.y : 0.f, p + 2 < T ? t.z : 0.f,
+                                       p + 3 < T ? t.w : 0.f);
+                if (a.rectify)
+                    v = make_float4(a.gain * fabsf(v.x), a.gain * fabsf(v.y), a.gain * fabsf(v.z), a.gain * fabsf(v.w));
+                lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = v;
+            }
+            v4f ck[SE];
+#pragma unroll
+            for (int i = 0; i < SE; i++) ck[i] = asm_load16(ckpt + tidx * DE + 2 * i);
+            float ra = asm_load4(in + (T - 1));
+            float rb = asm_load4(in + (lane < edge ? T - 2 - lane : 0));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < SE; i++) {
+                asm volatile("" : "+v"(ck[i]));
+                const v2d d = __builtin_bit_cast(v2d, ck[i]);
+                cfw_[2 * i] = d.x; cfw_[2 * i + 1] = d.y;
+            }
+            asm volatile("" : "+v"(ra));
+            asm volatile("" : "+v"(rb));
+            __syncthreads();
+            // right odd extension ext[T + i] = 2 r(T-1) - r(T-2-i), i < edge
+            if (lane < edge) {
+                const long long pj = T + lane;
+                if (pj >= tile && pj < tile + TILE) {
+                    if (a.rectify) { ra = a.gain * fabsf(ra); rb = a.gain * fabsf(rb); }
+                    ldsf[lds_float_index((int)(pj - tile))] = 2.f * ra - rb;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                float4 v = load_four(in, tile + 256 * k + 4 * lane, T);
+                if (a.rectify)
+                    v = make_float4(a.gain * fabsf(v.x), a.gain * fabsf(v.y), a.gain * fabsf(v.z), a.gain * fabsf(v.w));
+                lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = v;
+            }
+#pragma unroll
+            for (int r = 0; r < DE; r++) cfw_[r] = ckpt[tidx * DE + r];
         }
         __syncthreads();
-        if (tile + TILE > T) {
+        if (!PREFETCH && tile + TILE > T) {
             // right odd extension ext[T + i] = 2 r(T-1) - r(T-2-i), i < edge, straight from HBM
             if (lane < edge) {
                 const long long pj = T + lane;
@@ -373,10 +552,12 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
             }
             __syncthreads();
         }
+        if (PREFETCH) __syncthreads();
+        if (PREFETCH) {
+            pre = rt + 1 < rt_hi && prefetchable(tidx - 1);
+            fetch(pre ? tidx - 1 : top_full);
+        }
         // ---- forward cascade again, from the state that entered this tile
-        double cfw_[DE];
-#pragma unroll
-        for (int r = 0; r < DE; r++) cfw_[r] = ckpt[tidx * DE + r];
 #define CASC_S SE
 #define CASC_PLAN() PLAN_OF(P0)
 #define CASC_CARRY cfw_
@@ -406,14 +587,34 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
 #undef CASC_IN
         __syncthreads();
         if (rt >= rt_lo) {
+            if (tile >= a.skip && tile + TILE <= T) {
+                // interior tile: exactly 8 vector stores
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                float4 v = lds[lds_slot(8 * k + (lane >> 3), lane & 7)];
-                if (a.clamp) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                for (int k = 0; k < 8; k++) {
+                    float4 v = lds[lds_slot(8 * k + (lane >> 3), lane & 7)];
+                    if (a.clamp) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    f4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+                    *reinterpret_cast<f4u *>(out + (tile + 256 * k + 4 * lane - a.skip)) = t;
                 }
-                store_four(out, tile + 256 * k + 4 * lane, v, a.skip, T, a.skip);
+                // the prefetch issued above is older than these 8 stores: all but 7 operations done
+                // means every load has landed (one less than 8, so a merged store could not make
+                // the wait too weak; tools/check_prefetch_isa.py re-checks the ISA)
+                if (PREFETCH) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    float4 v = lds[lds_slot(8 * k + (lane >> 3), lane & 7)];
+                    if (a.clamp) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    store_four(out, tile + 256 * k + 4 * lane, v, a.skip, T, a.skip);
+                }
+                if (PREFETCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+        } else if (PREFETCH) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // warm-up tile: no stores to count
         }
         __syncthreads();
     }
@@ -667,9 +868,13 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
         long long blocks = channels * fa.n_seg;
         HD_REQUIRE(blocks <= 0x7fffffffLL, "grid too large");
         dim3 grid((unsigned)blocks), block(64);
-#define HD_CKPT(A, B)                                                                              \
-    case (A) * 8 + (B):                                                                            \
-        hipLaunchKernelGGL((sos_ckpt_kernel<A, B>), grid, block, 0, ctx->stream, fdev, edev, fa);  \
+        const bool pf = ctx->sos_prefetch && frames >= 4 * TILE;
+#define HD_CKPT(A, B)                                                                                       \
+    case (A) * 8 + (B):                                                                                     \
+        if (pf && (A) <= 2 && (B) <= 2)                                                                     \
+            hipLaunchKernelGGL((sos_ckpt_kernel<A, B, ((A) <= 2 && (B) <= 2)>), grid, block, 0, ctx->stream, fdev, edev, fa); \
+        else                                                                                                \
+            hipLaunchKernelGGL((sos_ckpt_kernel<A, B, false>), grid, block, 0, ctx->stream, fdev, edev, fa); \
         break
         switch (SF * 8 + SE) {
             HD_CKPT(0, 1); HD_CKPT(0, 2); HD_CKPT(0, 3); HD_CKPT(0, 4);
@@ -704,10 +909,16 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
     HD_REQUIRE(blocks <= 0x7fffffffLL, "grid too large");
     dim3 grid((unsigned)blocks), block(64);
     switch (SE) {
-    case 1: hipLaunchKernelGGL((env_bwd_kernel<1>), grid, block, 0, ctx->stream, edev, b); break;
-    case 2: hipLaunchKernelGGL((env_bwd_kernel<2>), grid, block, 0, ctx->stream, edev, b); break;
-    case 3: hipLaunchKernelGGL((env_bwd_kernel<3>), grid, block, 0, ctx->stream, edev, b); break;
-    case 4: hipLaunchKernelGGL((env_bwd_kernel<4>), grid, block, 0, ctx->stream, edev, b); break;
+    case 1:
+        if (ctx->sos_prefetch && frames >= 4 * TILE) hipLaunchKernelGGL((env_bwd_kernel<1, true>), grid, block, 0, ctx->stream, edev, b);
+        else hipLaunchKernelGGL((env_bwd_kernel<1, false>), grid, block, 0, ctx->stream, edev, b);
+        break;
+    case 2:
+        if (ctx->sos_prefetch && frames >= 4 * TILE) hipLaunchKernelGGL((env_bwd_kernel<2, true>), grid, block, 0, ctx->stream, edev, b);
+        else hipLaunchKernelGGL((env_bwd_kernel<2, false>), grid, block, 0, ctx->stream, edev, b);
+        break;
+    case 3: hipLaunchKernelGGL((env_bwd_kernel<3, false>), grid, block, 0, ctx->stream, edev, b); break;
+    case 4: hipLaunchKernelGGL((env_bwd_kernel<4, false>), grid, block, 0, ctx->stream, edev, b); break;
     default:
         hipdsp_set_error("n_sections %d not in 1..%d", SE, MAXS);
         return HIPDSP_ERR_UNSUPPORTED;

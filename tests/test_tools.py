@@ -1,4 +1,5 @@
-"""The ISA hazard checker that guards the hand-counted prefetch must catch a hazard."""
+"""The ISA checker that guards the hand-counted prefetches (tools/check_prefetch_isa.py) must
+accept the patterns the kernels rely on and catch the ways they can break."""
 
 import os
 import subprocess
@@ -6,20 +7,22 @@ import sys
 
 from conftest import ROOT
 
-GOOD = '''
-_Zkernel:
-.LBB0_1:
-	s_waitcnt vmcnt(2)
+
+def asm(*lines):
+    return '\t;;#ASMSTART\n' + ''.join('\t%s\n' % l for l in lines) + '\t;;#ASMEND\n'
+
+
+LOADS = asm('global_load_dwordx2 v[0:1], v[20:21], off') + asm('global_load_dwordx2 v[2:3], v[20:21], off offset:512') + \
+    asm('global_load_dwordx2 v[4:5], v[20:21], off offset:1024') + asm('global_load_dwordx2 v[6:7], v[20:21], off offset:1536')
+
+GOOD = '_Zkernel:\n' + LOADS + asm('s_waitcnt vmcnt(0)') + '''.LBB0_1:
 	v_add_f32_e32 v9, v0, v1
-	global_load_dwordx2 v[0:1], v[20:21], off
-	global_load_dwordx2 v[2:3], v[20:21], off offset:512
-	global_load_dwordx2 v[4:5], v[20:21], off offset:1024
-	global_load_dwordx2 v[6:7], v[20:21], off offset:1536
-	v_mul_f32_e32 v10, v11, v12
+''' + LOADS + '''	v_mul_f32_e32 v10, v11, v12
 	global_store_dword v[30:31], v10, off
 	global_store_dword v[30:31], v11, off
-	s_cbranch_scc0 .LBB0_1
+''' + asm('s_waitcnt vmcnt(2)') + '''	s_cbranch_scc0 .LBB0_1
 	s_endpgm
+.Lfunc_end0:
 '''
 
 
@@ -32,12 +35,74 @@ def run(text, tmp_path):
 
 def test_checker_passes_clean_loop_and_flags_early_use(tmp_path):
     r = run(GOOD, tmp_path)
-    assert r.returncode == 0 and '0 hazard' in r.stdout, r.stdout
-    # reading a destination register before the counted wait
+    assert r.returncode == 0 and '0 hazard' in r.stdout and '8 of them' in r.stdout, r.stdout
+    # reading a destination register while the load is in flight
     bad = GOOD.replace('\tv_mul_f32_e32 v10, v11, v12\n', '\tv_mul_f32_e32 v10, v2, v12\n')
     r = run(bad, tmp_path)
     assert r.returncode == 1 and 'HAZARD' in r.stdout
-    # a wait that does not cover the loads (only one younger store would be allowed to remain)
+    # a wait that does not cover the loads (three operations may remain, only two are younger)
     bad = GOOD.replace('s_waitcnt vmcnt(2)', 's_waitcnt vmcnt(3)')
     r = run(bad, tmp_path)
     assert r.returncode == 1 and 'HAZARD' in r.stdout
+    # one store less than counted (a merged store, say)
+    bad = GOOD.replace('\tglobal_store_dword v[30:31], v11, off\n', '')
+    r = run(bad, tmp_path)
+    assert r.returncode == 1 and 'HAZARD' in r.stdout
+
+
+def test_checker_sees_register_copies_on_the_back_edge(tmp_path):
+    # what hipcc does for a conditionally assigned prefetch buffer: a phi copy before the wait
+    bad = GOOD.replace(asm('s_waitcnt vmcnt(2)'), '\tv_mov_b32_e32 v40, v4\n' + asm('s_waitcnt vmcnt(2)'))
+    r = run(bad, tmp_path)
+    assert r.returncode == 1 and 'v_mov_b32_e32 v40, v4' in r.stdout
+    # the same copy after the wait is fine
+    ok = GOOD.replace(asm('s_waitcnt vmcnt(2)'), asm('s_waitcnt vmcnt(2)') + '\tv_mov_b32_e32 v40, v4\n')
+    assert run(ok, tmp_path).returncode == 0
+
+
+def test_checker_follows_all_paths_and_uniform_flags(tmp_path):
+    # a branch around the stores whose own wait is vmcnt(0): fine on both paths
+    two_way = '_Zkernel:\n' + LOADS + asm('s_waitcnt vmcnt(0)') + '''.LBB0_1:
+	v_add_f32_e32 v9, v0, v1
+''' + LOADS + '''	s_cbranch_scc1 .LBB0_2
+	global_store_dword v[30:31], v10, off
+	global_store_dword v[30:31], v11, off
+''' + asm('s_waitcnt vmcnt(2)') + '''	s_branch .LBB0_3
+.LBB0_2:
+''' + asm('s_waitcnt vmcnt(0)') + '''.LBB0_3:
+	s_cbranch_scc0 .LBB0_1
+	s_endpgm
+.Lfunc_end0:
+'''
+    assert run(two_way, tmp_path).returncode == 0
+    # the no-store path without its wait is a hazard even though the other path is clean
+    r = run(two_way.replace('.LBB0_2:\n' + asm('s_waitcnt vmcnt(0)'), '.LBB0_2:\n'), tmp_path)
+    assert r.returncode == 1
+    # hipcc's lowering of "wait unless the stores were issued": a 0 / -1 flag in an SGPR pair,
+    # tested through vcc -- the checker must not walk the combination the flag rules out
+    flagged = '_Zkernel:\n' + LOADS + asm('s_waitcnt vmcnt(0)') + '''.LBB0_1:
+	v_add_f32_e32 v9, v0, v1
+''' + LOADS + '''	s_mov_b64 s[16:17], -1
+	s_cbranch_scc1 .LBB0_2
+	global_store_dword v[30:31], v10, off
+	global_store_dword v[30:31], v11, off
+''' + asm('s_waitcnt vmcnt(2)') + '''	s_mov_b64 s[16:17], 0
+.LBB0_2:
+	s_andn2_b64 vcc, exec, s[16:17]
+	s_cbranch_vccnz .LBB0_3
+''' + asm('s_waitcnt vmcnt(0)') + '''.LBB0_3:
+	s_cbranch_scc0 .LBB0_1
+	s_endpgm
+.Lfunc_end0:
+'''
+    assert run(flagged, tmp_path).returncode == 0
+    # with the flag clobbered by something the checker cannot evaluate, it has to assume the worst
+    r = run(flagged.replace('\ts_mov_b64 s[16:17], -1\n', '\ts_mov_b64 s[16:17], -1\n\ts_and_b64 s[16:17], s[16:17], s[30:31]\n'), tmp_path)
+    assert r.returncode == 1
+
+
+def test_compiler_tracked_loads_only_take_a_queue_slot(tmp_path):
+    # a load outside an asm block is hipcc's business (it inserts its own waits); it still counts
+    # as a younger operation behind the prefetch
+    text = GOOD.replace('\tglobal_store_dword v[30:31], v11, off\n', '\tglobal_load_dword v50, v[30:31], off\n')
+    assert run(text, tmp_path).returncode == 0

@@ -28,10 +28,13 @@ def timed(f, n=5):
 
 
 waves = [int(w) for w in os.environ.get('WAVES', '12,16,20').split(',')]
-for w in waves:
-    ctx.set_option('sos_waves_per_cu', w)
-    fw = timed(lambda: hipdsp.sosfilt_envelope(ctx, fplan, eplan, dx, T, dy, T, de, T, C, T, phase=1))
-    bw = timed(lambda: hipdsp.sosfilt_envelope(ctx, fplan, eplan, dx, T, dy, T, de, T, C, T, phase=2))
-    en = timed(lambda: hipdsp.envelope(ctx, eplan, dx, T, de, T, C, T, 0))
-    print(f'waves/CU {w:2d}: band-pass + state sweep {fw:.3f} ms  backward sweep {bw:.3f} ms  '
-          f'sum {fw + bw:.3f} ms | envelope alone {en:.3f} ms', flush=True)
+for pf in [int(v) for v in os.environ.get('PREFETCH', '0').split(',')]:
+  ctx.set_option('sos_prefetch', pf)
+  print('prefetch', pf)
+  for w in waves:
+      ctx.set_option('sos_waves_per_cu', w)
+      fw = timed(lambda: hipdsp.sosfilt_envelope(ctx, fplan, eplan, dx, T, dy, T, de, T, C, T, phase=1))
+      bw = timed(lambda: hipdsp.sosfilt_envelope(ctx, fplan, eplan, dx, T, dy, T, de, T, C, T, phase=2))
+      en = timed(lambda: hipdsp.envelope(ctx, eplan, dx, T, de, T, C, T, 0))
+      print(f'waves/CU {w:2d}: band-pass + state sweep {fw:.3f} ms  backward sweep {bw:.3f} ms  '
+            f'sum {fw + bw:.3f} ms | envelope alone {en:.3f} ms', flush=True)
