@@ -219,11 +219,12 @@ __device__ __forceinline__ v2f pk_sumdiff_y(v2f a, v2f b)
 }
 
 // 8-byte global load the compiler does not track (the caller counts vmcnt by hand)
-__device__ __forceinline__ v2f asm_load8(const float *p, int imm)
+// The destination is a tied operand ("+v"): the load lands in the very registers that held the
+// previous frame's samples, so the value the loop carries never changes registers (a plain
+// "=v" output lets hipcc pick fresh ones and copy them on the back edge -- while in flight).
+__device__ __forceinline__ void asm_load8(v2f &r, const float *p, int imm)
 {
-    v2f r;
-    asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(r) : "v"(p), "n"(imm) : "memory");
-    return r;
+    asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "+v"(r) : "v"(p), "n"(imm) : "memory");
 }
 
 // One Stockham stage on the PPL register values of this lane.
@@ -349,9 +350,12 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? 3 : 1) * WAVES / 4) voi
     // IS the lower half of frame f+1 in the same lane (n' = n - M/2 <=> t' = t - R1/2), so
     // only the new half is fetched and the two register sets swap roles every frame: each
     // sample is requested once instead of twice (PMC: 22.1 GB -> 14.8 GB read per launch).
+    constexpr bool EARLY_PF = !DB;             // the dB epilogue needs the registers (it would spill)
     constexpr int HP = PPL / 2;                            // points per half
     constexpr int R1H = R1 / 2;
     v2f ra[HP], rb[HP];
+#pragma unroll
+    for (int i = 0; i < HP; i++) { ra[i] = (v2f){0.f, 0.f}; rb[i] = (v2f){0.f, 0.f}; }
     auto fetch_half = [&](long long frame, int upper, v2f *dst) {
         const float *seg = xc + frame * (long long)hop + 2 * l;
 #pragma unroll
@@ -361,8 +365,8 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? 3 : 1) * WAVES / 4) voi
                 constexpr int CH = 512;                    // float2 per 4096-byte window
                 const int n0 = LPF * u + t * (M / R1);     // compile-time after unrolling
                 const int n1 = n0 + R1H * (M / R1);
-                if (upper) dst[u * R1H + t] = asm_load8(seg + 2 * (n1 / CH) * CH, (n1 % CH) * 8);
-                else dst[u * R1H + t] = asm_load8(seg + 2 * (n0 / CH) * CH, (n0 % CH) * 8);
+                if (upper) asm_load8(dst[u * R1H + t], seg + 2 * (n1 / CH) * CH, (n1 % CH) * 8);
+                else asm_load8(dst[u * R1H + t], seg + 2 * (n0 / CH) * CH, (n0 % CH) * 8);
             }
     };
     // stores behind a prefetch in the steady-state loop; one less than issued, so the wait
@@ -412,10 +416,22 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? 3 : 1) * WAVES / 4) voi
                 float2 &e = v[u * R1 + t];
                 e = as_f2((as_v2f(e) - mean2) * w);
             }
+        // the raw registers are dead from here on: request the next frame now, so that the whole
+        // FFT of this one hides the latency
+        if (PF && EARLY_PF) {
+            const long long nf = frame + G;
+            const long long cf = nf < last_valid ? nf : last_valid;
+            if (HALF) {
+                fetch_half(cf, 1, lo);                    // hi stays: it is the next lower half
+            } else {
+                fetch_half(cf, 0, lo);
+                fetch_half(cf, 1, hi);
+            }
+        }
         stockham_stage<R1, 1, M, LPF, false, true>(v, fb, tw2, l);
         stockham_stage<R2, R1, M, LPF, true, true>(v, fb, tw2, l);
         stockham_stage<R3, R1 * R2, M, LPF, true, false, true>(v, fb, tw3, l);
-        if (PF) {
+        if (PF && !EARLY_PF) {
             const long long nf = frame + G;
             const long long cf = nf < last_valid ? nf : last_valid;
             if (HALF) {
