@@ -297,8 +297,10 @@ __device__ __forceinline__ void stockham_stage(float2 *v, float2 *fb, const floa
     }
 }
 
+// Three workgroups per CU (<= 168 VGPRs); the dB epilogue does not fit in that (it spilled 44
+// registers to scratch) and runs two per CU instead, which measured 15 % faster than spilling.
 template <int NFFT, int LPF, int R1, int R2, int R3, int WAVES, bool DB, bool HALF>
-__global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? 3 : 1) * WAVES / 4) void spec_fast_kernel(
+__global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? (DB ? 2 : 3) : 1) * WAVES / 4) void spec_fast_kernel(
     const float *__restrict__ x, long long x_pitch, long long n_valid, long long frames_out,
     long long out_pitch, int hop, float scale, const float *__restrict__ tables, float *__restrict__ out,
     float *__restrict__ db_out, int frames_per_wave)
