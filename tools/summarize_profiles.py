@@ -18,10 +18,10 @@ os.makedirs(os.path.dirname(dst) or '.', exist_ok=True)
 
 def short(name):
     """Kernel names as bench.py prints them."""
-    m = re.search(r'sos_ckpt_kernel<(\d), (\d)>', name)
+    m = re.search(r'sos_ckpt_kernel<(\d), (\d)(?:, \w+)?>', name)
     if m:
         return ('sos_ckpt<S=%s+%s,filt+env_state>' if m.group(1) != '0' else 'sos_ckpt<S=%s+%s,env_state>') % m.groups()
-    m = re.search(r'env_bwd_kernel<(\d)>', name)
+    m = re.search(r'env_bwd_kernel<(\d)(?:, \w+)?>', name)
     if m:
         return 'env_bwd<S=%s>' % m.group(1)
     m = re.search(r'sos_scan_kernel<(\d)>', name)
