@@ -68,3 +68,48 @@ def test_graph_replay_under_cutoff_sweep(oracle):
     ctx.graph_destroy(graph)
     ctx.set_stream(None)
     ctx.destroy_stream(stream)
+
+
+def test_two_streams_ordered_by_events(oracle):
+    """bench.py's step: the spectrogram on a second context/stream next to the envelope's backward
+    sweep, ordered by hipdsp_event_record / hipdsp_event_wait; results equal the one-stream chain."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rate, C, T, nfft, hop = 96000.0, 3, 96000*4, 2048, 1024
+    a = hipdsp.Context(0)
+    a.set_stream(a.create_stream())
+    b = hipdsp.Context(0, a.create_stream())
+    dx = hipdsp.DeviceArray(a, (C, T), np.float32)
+    hipdsp.synth(a, dx, T, C, T, rate, 5)
+    df = hipdsp.DeviceArray(a, (C, T), np.float32)
+    de = hipdsp.DeviceArray(a, (C, T), np.float32)
+    nd = (T + hop - 1)//hop
+    F = nfft//2 + 1
+    ds = hipdsp.DeviceArray(a, (C, nd, F), np.float32)
+    fplan = hipdsp.SosPlan(a, butter_sos(2, (300.0, 3000.0), 'bandpass', rate))
+    eplan = hipdsp.SosPlan(a, butter_sos(2, 20.0, 'lowpass', rate))
+    filtered, done = a.event(), a.event()
+    for _ in range(3):                      # repeated steps: the next forward sweep must wait for `done`
+        hipdsp.sosfilt_envelope(a, fplan, eplan, dx, T, df, T, de, T, C, T, phase=1)
+        a.record(filtered)
+        b.wait_event(filtered)
+        hipdsp.spectrogram(b, df, T, C, T, nfft, hop, rate, ds, nd)
+        b.record(done)
+        hipdsp.sosfilt_envelope(a, fplan, eplan, dx, T, df, T, de, T, C, T, phase=2)
+        a.wait_event(done)
+    a.synchronize()
+    b.synchronize()
+    got_s, got_e, got_f = ds.to_host(), de.to_host(), df.to_host()
+    # one stream, separate calls
+    c = hipdsp.Context(0)
+    f1 = hipdsp.DeviceArray(c, (C, T), np.float32)
+    e1 = hipdsp.DeviceArray(c, (C, T), np.float32)
+    s1 = hipdsp.DeviceArray(c, (C, nd, F), np.float32)
+    p1, p2 = hipdsp.SosPlan(c, butter_sos(2, (300.0, 3000.0), 'bandpass', rate)), hipdsp.SosPlan(c, butter_sos(2, 20.0, 'lowpass', rate))
+    hipdsp.sosfilt(c, p1, dx, T, f1, T, C, T, 0)
+    hipdsp.spectrogram(c, f1, T, C, T, nfft, hop, rate, s1, nd)
+    hipdsp.envelope(c, p2, f1, T, e1, T, C, T, 0)
+    assert np.array_equal(got_f, f1.to_host())
+    assert np.array_equal(got_s, s1.to_host())
+    for ch in range(C):
+        assert rel_err(got_e[ch], e1.to_host()[ch]) < 1e-6
