@@ -14,7 +14,7 @@ struct hipdsp_ctx {
     hipStream_t stream;
     int max_segments;      // 0 = auto
     int n_cus;
-    void *scratch;         // envelope forward-pass intermediate
+    void *scratch;         // envelope state checkpoints, four-step FFT work area
     size_t scratch_bytes;
     hipEvent_t mid_event;  // optional: recorded between envelope fwd and bwd
     void *fft_tables[20];  // per log2(nfft): window | TWM | TWN (device), built on first use

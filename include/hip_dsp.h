@@ -68,8 +68,9 @@ int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
  *   "spec_fpw"           consecutive frames per wave (0 = automatic)
  *   "spec_no_half"       non-zero: do not reuse the overlapped half frame at 50 % overlap */
 int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value);
-/* Pre-size the internal scratch (envelope forward pass) so that later calls do
- * not allocate; required before stream capture into a hipGraph. */
+/* Pre-size the internal scratch (envelope state checkpoints: 16 * n_sections bytes per
+ * 2048-sample tile and channel; four-step FFT work area) so that later calls do not
+ * allocate; required before stream capture into a hipGraph. */
 int hipdsp_ctx_reserve(hipdsp_ctx *ctx, size_t bytes);
 
 /* ---- streams and hipGraph capture (interactive recompute, BASELINE configs[4]) ---- */
@@ -190,12 +191,14 @@ int hipdsp_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const float *x,
  * frames the filter produces, skip = 0):
  *   yf  = sosfilt(fplan, x)                          (BufferedFilter.process)
  *   env = sosfiltfilt(eplan, gain*|yf|) [clamped]    (BufferedEnvelope.process on yf)
- * The envelope's forward pass is fused into the band-pass kernel, so the filtered trace is
- * not re-read: 12 + 8 instead of 8 + 16 bytes per sample.  Results equal the two separate
- * calls up to float64 rounding of the IIR state.
- * phase: 0 = both passes; 1 = fused forward only (yf complete, forward result parked in the
- * context scratch); 2 = backward only (env from that scratch) -- so that other work on yf
- * (the spectrogram) can be enqueued in between; no call that uses the context scratch
+ * One sweep over x writes yf and, instead of the forward output of sosfiltfilt, only the
+ * envelope cascade's state at every 2048-sample tile border (context scratch); the backward
+ * sweep re-reads yf, recomputes the forward output tile by tile from those states and filters
+ * it backwards: 8 + 8 bytes per sample instead of 8 + 16.  Results equal the two separate calls
+ * up to float64 rounding of the IIR state.
+ * phase: 0 = both sweeps; 1 = forward sweep only (yf complete, states parked in the context
+ * scratch); 2 = backward sweep only (env from yf and those states) -- so that other work on yf
+ * (the spectrogram) can be enqueued in between; no call that uses the scratch of THIS context
  * (envelope, nfft > 8192, mean_spectrum_db) may come between phase 1 and phase 2. */
 int hipdsp_sosfilt_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan,
                             const hipdsp_sosplan *eplan, const float *x, int64_t x_pitch,

@@ -375,7 +375,7 @@ def test_spectrogram_arbitrary_nfft_direct_dft(oracle, nfft, hop):
 
 @pytest.mark.parametrize('T', [10, 33, 2047, 2048, 2049, 2040, 4095, 70000, 1500000])
 def test_fused_filter_envelope_equals_separate_calls(oracle, T):
-    """hipdsp_sosfilt_envelope (forward pass fused into the band-pass kernel) against the two
+    """hipdsp_sosfilt_envelope (band-pass + envelope state sweep, then the backward sweep) against the two
     separate calls and against the oracle, incl. tile borders inside the odd extension."""
     from audian_amd import hipdsp
     from audian_amd.design import butter_sos
