@@ -63,6 +63,7 @@ int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
 /* Named tuning/testing options (results do not depend on them beyond rounding):
  *   "max_segments"       as hipdsp_ctx_set_max_segments
  *   "sos_waves_per_cu"   resident waves per CU the IIR segment planner aims for (16)
+ *   "sos_prefetch"       0: envelope sweeps without the register prefetch of the next tile (1)
  *   "force_generic_fft"  non-zero: every nfft takes the generic radix-2 spectrogram kernel
  *   "spec_kernel"        0 = default per size, 2 = two-stage, 3 = three-stage FFT kernel
  *   "spec_fpw"           consecutive frames per wave (0 = automatic)

@@ -128,6 +128,13 @@ def test_envelope_long_vs_oracle(oracle, env, order, hp, rate, T):
         assert rel_err(got[:, c], want[:, c]) < TOL
     got = gh.gpu_envelope(sos, x, skip=7, clamp=hp == 0)
     assert rel_err(got, want[7:]) < TOL
+    # the same sweeps without the register prefetch (the variant short slabs always take)
+    gh.ctx().set_option('sos_prefetch', 0)
+    try:
+        plain = gh.gpu_envelope(sos, x, clamp=hp == 0)
+    finally:
+        gh.ctx().set_option('sos_prefetch', 1)
+    assert np.array_equal(plain, gh.gpu_envelope(sos, x, clamp=hp == 0))
 
 
 @pytest.mark.parametrize('T', [2050, 70000, 300000])
