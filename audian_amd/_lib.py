@@ -109,6 +109,7 @@ _SIGNATURES = {
     'hipdsp_spectrogram': ([_vp, _vp, _i64, _i64, _i64, _int, _int, _dbl, _vp, _vp, _i64, _i64], _int),
     'hipdsp_decibel': ([_vp, _vp, _vp, _i64, _dbl, _dbl], _int),
     'hipdsp_decibel_image': ([_vp, _vp, _vp, _i64, _i64, _dbl, _dbl], _int),
+    'hipdsp_decibel_image_decimate': ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl], _int),
     'hipdsp_channel_mean': ([_vp, _vp, _i64, ctypes.POINTER(_int), _int, _i64, _i64, _dbl, _vp], _int),
     'hipdsp_stride_copy': ([_vp, _vp, _i64, _i64, _vp], _int),
     'hipdsp_max_nonneg': ([_vp, _vp, _i64, _vp], _int),

@@ -128,6 +128,32 @@ class BufferedSpectrogram(BufferedData):
             return img.to_host()
         return decibel(self.buffer[:, channel, :].T, ref_power, min_power).astype(np.float32)
 
+    def decimated_image(self, start, stop, step, channel, ref_power=1.0, min_power=1e-20):
+        """The dB image of frames [start, stop) (absolute frame indices inside the current buffer)
+        of one channel at screen resolution: every column is the maximum over `step` frames --
+        TraceItem.update_plot's np.maximum.reduceat (src/audian/traceitem.py:55-61) applied to the
+        spectrogram, the reference's open TODO (README.md:96) -- then decibel(...).T as
+        SpecItem.update_plot shows it (src/audian/specitem.py:36).  Device reduction when the
+        mirror is valid, so only (F, ceil((stop-start)/step)) float32 values cross PCIe."""
+        from . import hipdsp
+        from .buffereddata import _covers
+        a, b = int(start) - self.offset, int(stop) - self.offset
+        n = len(self._hostbuf)
+        F = self.nfft//2 + 1
+        if a < 0 or b > n or b < a or step < 1:
+            raise IndexError('range outside the loaded buffer')
+        ncols = (b - a + step - 1)//step
+        if ncols == 0:
+            return np.zeros((F, 0), dtype=np.float32)
+        if self._dev is not None and _covers(self._dev_valid, a, b):
+            img = hipdsp.DeviceArray(self.ctx, (F, ncols), np.float32)
+            hipdsp.decibel_image_decimate(self.ctx, self._dev.view(channel*n*F, (1,)), img, n, F, a, b, step,
+                                          ref_power, min_power)
+            return img.to_host()
+        seg = np.arange(0, b - a, step)
+        block = np.maximum.reduceat(self.buffer[a:b, channel, :], seg, axis=0)
+        return decibel(block, ref_power, min_power).T.astype(np.float32)
+
     def mean_power_db(self, i0, i1, channel, floor_db=-200.0):
         """Power spectrum of frames [i0, i1) (absolute frame indices) of one channel as
         SpectrogramPlot.update_plot shows it (src/audian/spectrogramplot.py:158-160):

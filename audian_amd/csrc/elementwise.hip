@@ -42,6 +42,42 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
     }
 }
 
+// Screen-resolution dB image of one channel: column c = max over the frames
+// [start + c*step, min(start + (c+1)*step, stop)) of the (frames, F) slab (np.maximum.reduceat, NaN
+// propagates), then dB, written transposed as (F, ncols).  32 bins x 32 columns per workgroup; a
+// row of 32 lanes reads 128 contiguous bytes per frame.
+__global__ __launch_bounds__(256) void db_image_decimate_kernel(const float *__restrict__ src,
+                                                                float *__restrict__ dst, long long start,
+                                                                long long stop, long long step, long long ncols,
+                                                                long long F, float inv_ref, float min_power)
+{
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 bins x 8 columns at a time
+    const long long f0 = (long long)blockIdx.x * 32, c0 = (long long)blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const long long c = c0 + ty + 8 * k, f = f0 + tx;
+        float v = 0.f;
+        if (c < ncols && f < F) {
+            const long long a = start + c * step;
+            const long long b = a + step < stop ? a + step : stop;
+            v = src[a * F + f];
+            for (long long r = a + 1; r < b; r++) {
+                const float w = src[r * F + f];
+                v = (w > v || w != w) ? w : v;                   // NaN wins, like np.maximum
+            }
+            v = (v <= min_power) ? -INFINITY : 10.0f * log10f(v * inv_ref);
+        }
+        tile[ty + 8 * k][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const long long f = f0 + ty + 8 * k, c = c0 + tx;
+        if (f < F && c < ncols) dst[f * ncols + c] = tile[tx][ty + 8 * k];
+    }
+}
+
 // (T, C) interleaved -> planar (C, pitch) float32
 template <typename SRC>
 __global__ __launch_bounds__(256) void pack_kernel(const SRC *__restrict__ src, float *__restrict__ dst,
@@ -324,6 +360,28 @@ int hipdsp_decibel_image(hipdsp_ctx *ctx, const float *spec_tf, float *image_ft,
     hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, ctx->stream, spec_tf, image_ft,
                        (long long)frames, (long long)nfreq, (float)(1.0 / ref_power), (float)min_power);
     return hd_launch_status("transpose_kernel");
+}
+
+int hipdsp_decibel_image_decimate(hipdsp_ctx *ctx, const float *spec_tf, float *image_fc, int64_t frames,
+                                  int64_t nfreq, int64_t start, int64_t stop, int64_t step, double ref_power,
+                                  double min_power)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    HD_REQUIRE(frames >= 0 && nfreq >= 0, "negative size");
+    HD_REQUIRE(step >= 1, "step must be >= 1");
+    HD_REQUIRE(start >= 0 && start <= stop && stop <= frames, "frame range [%lld, %lld) not inside [0, %lld)",
+               (long long)start, (long long)stop, (long long)frames);
+    HD_REQUIRE(ref_power > 0, "ref_power must be positive");
+    const long long ncols = (stop - start + step - 1) / step;
+    if (ncols == 0 || nfreq == 0) return HIPDSP_OK;
+    HD_REQUIRE(spec_tf != nullptr && image_fc != nullptr, "NULL data pointer");
+    HD_REQUIRE((ncols + 31) / 32 <= 65535, "too many columns for one image");
+    HD_CHECK_HIP(hipSetDevice(ctx->device));
+    dim3 grid((unsigned)((nfreq + 31) / 32), (unsigned)((ncols + 31) / 32));
+    hipLaunchKernelGGL(db_image_decimate_kernel, grid, dim3(256), 0, ctx->stream, spec_tf, image_fc,
+                       (long long)start, (long long)stop, (long long)step, ncols, (long long)nfreq,
+                       (float)(1.0 / ref_power), (float)min_power);
+    return hd_launch_status("db_image_decimate_kernel");
 }
 
 static int pack_check(hipdsp_ctx *ctx, const void *a, const void *b, int64_t pitch, int64_t frames,

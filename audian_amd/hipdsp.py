@@ -313,6 +313,13 @@ def decibel_image(ctx, spec_tf, image_ft, frames, nfreq, ref_power=1.0, min_powe
                                    float(ref_power), float(min_power)))
 
 
+def decibel_image_decimate(ctx, spec_tf, image_fc, frames, nfreq, start, stop, step, ref_power=1.0,
+                           min_power=1e-20):
+    check(lib.hipdsp_decibel_image_decimate(ctx.handle, _p(spec_tf), _p(image_fc), int(frames), int(nfreq),
+                                            int(start), int(stop), int(step), float(ref_power),
+                                            float(min_power)))
+
+
 def pack(ctx, src_tc, dst, dst_pitch, frames, channels, src_dtype=np.float64):
     fn = lib.hipdsp_pack_f64 if np.dtype(src_dtype) == np.float64 else lib.hipdsp_pack_f32
     check(fn(ctx.handle, _p(src_tc), _p(dst), int(dst_pitch), int(frames), int(channels)))

@@ -234,6 +234,15 @@ int hipdsp_decibel(hipdsp_ctx *ctx, const float *p, float *out, int64_t n, doubl
  * channel's (frames, nfreq) slab to a (nfreq, frames) dB image. */
 int hipdsp_decibel_image(hipdsp_ctx *ctx, const float *spec_tf, float *image_ft,
                          int64_t frames, int64_t nfreq, double ref_power, double min_power);
+/* The same image at screen resolution: column c = decibel(max over the frames
+ * [start + c*step, min(start + (c+1)*step, stop)) ), i.e. np.maximum.reduceat over the
+ * segments arange(0, stop - start, step) -- the min/max screen decimation TraceItem.update_plot
+ * applies to traces (traceitem.py:42-61), applied to the spectrogram image (the reference's
+ * README TODO "Implement downsampling of spectrograms", README.md:96).  image_fc is
+ * (nfreq, ceil((stop - start) / step)); NaN propagates like np.maximum. */
+int hipdsp_decibel_image_decimate(hipdsp_ctx *ctx, const float *spec_tf, float *image_fc,
+                                  int64_t frames, int64_t nfreq, int64_t start, int64_t stop,
+                                  int64_t step, double ref_power, double min_power);
 
 /* ---- next rows --------------------------------------------------- */
 

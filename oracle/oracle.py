@@ -259,6 +259,16 @@ def minmax_decimate(data, start, stop, step):
     return out
 
 
+def decimated_db_image(spec_tcf, start, stop, step, channel):
+    """Screen-resolution spectrogram image of one channel: TraceItem.update_plot's reduction
+    (np.maximum.reduceat over arange(0, stop - start, step), src/audian/traceitem.py:55-61) applied
+    to the frames of buffer[start:stop, channel, :], then SpecItem's decibel(...).T
+    (src/audian/specitem.py:36).  The reference itself only has this as a TODO (README.md:96)."""
+    seg = np.arange(0, stop - start, step)
+    block = np.asarray(spec_tcf)[start:stop, channel, :]
+    return decibel(np.maximum.reduceat(block, seg, axis=0)).T
+
+
 def mean_power_db(spec_tcf, i0, i1, channel, floor_db=-200.0):
     """SpectrogramPlot.update_plot's power spectrum (src/audian/spectrogramplot.py:158-160)."""
     power = np.mean(np.asarray(spec_tcf, dtype=np.float64)[i0:i1, channel, :], axis=0)

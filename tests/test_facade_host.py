@@ -257,6 +257,23 @@ def test_minmax_decimate_host_path():
         t.minmax_decimate(t.offset, t.offset + len(t.buffer) + 1, 4)
 
 
+def test_decimated_image_host_path(oracle):
+    """BufferedSpectrogram.decimated_image without a device mirror: the NumPy reduceat + decibel."""
+    from audian_amd.bufferedspectrogram import BufferedSpectrogram
+    s = BufferedSpectrogram.__new__(BufferedSpectrogram)
+    rng = np.random.default_rng(11)
+    s.nfft, s.offset = 16, 100
+    s._dev, s._dev_valid = None, []
+    s._hostbuf = 10.0**rng.uniform(-22, 1, size=(50, 2, 9))
+    s._stale = []
+    got = s.decimated_image(103, 147, 6, 1)
+    want = oracle.decimated_db_image(s._hostbuf, 3, 47, 6, 1)
+    assert got.shape == (9, 8) and np.allclose(got, want, rtol=1e-6)
+    assert s.decimated_image(110, 110, 3, 0).shape == (9, 0)
+    with pytest.raises(IndexError):
+        s.decimated_image(99, 120, 2, 0)
+
+
 def _write_wav(path, data_int, nbytes, rate):
     import wave
     w = wave.open(str(path), 'wb')

@@ -169,6 +169,14 @@ def test_scroll_update_and_recompute_match_oracle_twins(oracle):
         got = f.minmax_decimate(a, b, step, channel=1)
         want = oracle.minmax_decimate(f.buffer[:, 1], a - f.offset, b - f.offset, step)
         assert np.array_equal(got, want)
+    # ... and the same reduction on the spectrogram image (max over `step` frames, then dB)
+    for a, b, step in [(s.offset, s.offset + len(s.buffer), 1), (s.offset + 1, s.offset + len(s.buffer) - 2, 7),
+                       (s.offset + 3, s.offset + 4, 5)]:
+        got = s.decimated_image(a, b, step, 1)
+        want = oracle.decimated_db_image(s.buffer, a - s.offset, b - s.offset, step, 1)
+        fin = np.isfinite(want)
+        assert got.shape == want.shape and np.array_equal(np.isfinite(got), fin)
+        assert np.max(np.abs(got[fin] - want[fin])) < 1e-3
     # visible-window power spectrum from the device mirror
     for i0, i1 in [(s.offset, s.offset + 1), (s.offset + 2, s.offset + len(s.buffer))]:
         got = s.mean_power_db(i0, i1, 1)

@@ -334,6 +334,33 @@ def test_mean_spectrum_db(oracle):
             assert np.max(np.abs(got - want)) < 1e-3, (frames, F, i0, i1)
 
 
+@pytest.mark.parametrize('frames,F,start,stop,step', [(70, 129, 0, 70, 1), (1000, 1025, 3, 997, 28), (5000, 513, 100, 4999, 64),
+                                                      (33, 33, 32, 33, 4), (400, 2049, 0, 400, 400), (10, 5, 4, 4, 3)])
+def test_decimated_db_image(oracle, frames, F, start, stop, step):
+    """SURVEY 8f-1 for the spectrogram: max over `step` frames (np.maximum.reduceat), then the dB image."""
+    from audian_amd import hipdsp
+    rng = np.random.default_rng(frames + step)
+    c = gh.ctx()
+    spec = (10.0**rng.uniform(-24, 2, size=(frames, F))).astype(np.float32)
+    spec[frames//2, :] = 0.0
+    if stop - start > 2*step:
+        spec[start + step:start + 2*step, 1] = 0.0          # a whole segment at -inf
+    ncols = (stop - start + step - 1)//step
+    ds = hipdsp.DeviceArray.from_host(c, spec)
+    img = hipdsp.DeviceArray(c, (F, max(ncols, 1)), np.float32)
+    hipdsp.decibel_image_decimate(c, ds, img, frames, F, start, stop, step)
+    if ncols == 0:
+        return
+    got = img.to_host()[:, :ncols] if ncols else None
+    want = oracle.decimated_db_image(spec[:, None, :], start, stop, step, 0)
+    fin = np.isfinite(want)
+    assert got.shape == want.shape
+    assert np.array_equal(np.isfinite(got), fin)
+    assert np.max(np.abs(got[fin] - want[fin])) < 1e-4
+    with pytest.raises(ValueError):
+        hipdsp.decibel_image_decimate(c, ds, img, frames, F, 0, frames + 1, step)
+
+
 @pytest.mark.parametrize('nfft,hop,nframes', [(16384, 8192, 5), (32768, 4096, 4), (65536, 16384, 3),
                                               (262144, 131072, 3), (524288, 262144, 2)])
 def test_spectrogram_large_nfft_four_step(oracle, nfft, hop, nframes):
