@@ -153,26 +153,21 @@ class BufferedData(BufferedArray):
     _pending = None
     _ctx = None
 
-    def __init__(self, name, source_name, tbefore=0, tafter=0,
-                 panel='none', panel_type='trace',
+    def __init__(self, name, source_name, tbefore=0, tafter=0, panel='none', panel_type='trace',
                  color='#00ee00', lw_thin=1.1, lw_thick=2):
-        super().__init__(verbose=0)
-        self.name = name
-        self.source_name = source_name
-        # like the reference: own times start at 0 and only grow via expand_times()
-        self.tbefore = 0
-        self.tafter = 0
-        self.panel = panel
-        self.panel_type = panel_type
-        self.plot_items = []
-        self.color = color
-        self.lw_thin = lw_thin
-        self.lw_thick = lw_thick
-        self.source = None
-        self.source_tbefore = tbefore
-        self.source_tafter = tafter
-        self.dests = []
+        """Arguments as in audian (buffereddata.py:14-30).  `tbefore` / `tafter` are the margins
+        (seconds) this trace needs from its SOURCE; its own margins start at zero and only grow
+        through expand_times() when traces derived from it ask for more."""
+        BufferedArray.__init__(self, verbose=0)
+        self.name, self.source_name = name, source_name
+        self.source, self.dests = None, []
+        self.source_tbefore, self.source_tafter = tbefore, tafter
+        self.tbefore = self.tafter = 0
         self.need_update = False
+        # presentation attributes the plot code reads
+        self.panel, self.panel_type = panel, panel_type
+        self.color, self.lw_thin, self.lw_thick = color, lw_thin, lw_thick
+        self.plot_items = []
 
     # ---- host buffer with lazy read-back ---------------------------------------
     @property
@@ -396,41 +391,41 @@ class BufferedData(BufferedArray):
             res[:, 1::2] = np.maximum.reduceat(buf, seg, axis=0).T
         return res[channel] if channel is not None else res
 
-    # ---- the reference's surface ----------------------------------------------------
+    # ---- the reference's surface (src/audian/buffereddata.py), restated --------------
     def expand_times(self, tbefore, tafter):
-        self.tbefore += tbefore
-        self.tafter += tafter
-        return self.source_tbefore + tbefore, self.source_tafter + tafter
+        """Widen this trace's own margins by what a derived trace needs; returns what the source
+        then has to provide (buffereddata.py:33-36)."""
+        self.tbefore, self.tafter = self.tbefore + tbefore, self.tafter + tafter
+        return tbefore + self.source_tbefore, tafter + self.source_tafter
 
     def update_step(self, step=1, more_shape=None):
-        tbuffer = self.bufferframes/self.rate
-        if step < 1:
-            step = 1
-        self.rate = self.source.rate/step
-        self.frames = (self.source.frames + step - 1)//step
-        if more_shape is None:
-            self.shape = (self.frames, self.channels)
-        else:
-            self.shape = (self.frames, self.channels) + more_shape
-        self.ndim = len(self.shape)
-        self.size = self.frames*self.channels
-        if self.source.bufferframes == self.source.frames:
-            self.bufferframes = self.frames
-        else:
-            self.bufferframes = int(tbuffer*self.rate)
-        self.offset = (self.source.offset + step - 1)//step
+        """Frame bookkeeping for one frame of this trace per `step` source frames
+        (buffereddata.py:39-56): rate, frames, shape, offset round UP to whole frames; the buffer
+        keeps its length in seconds unless the source holds the whole recording."""
+        src = self.source
+        seconds = self.bufferframes/self.rate            # at the rate valid so far
+        step = max(step, 1)
+
+        def frames_of(n):
+            return -(-n//step)
+
+        self.rate = src.rate/step
+        self.frames = frames_of(src.frames)
+        self.shape = (self.frames, self.channels) + tuple(more_shape or ())
+        self.ndim, self.size = len(self.shape), self.frames*self.channels
+        whole_recording = src.bufferframes == src.frames
+        self.bufferframes = self.frames if whole_recording else int(seconds*self.rate)
+        self.offset = frames_of(src.offset)
         self.follow = 0
 
     def open(self, source, step=1, more_shape=None):
+        """Become a destination of `source`: inherit channels, rate, amplitude range and unit,
+        start with an empty buffer (buffereddata.py:59-72)."""
+        source.dests.append(self)
         self.source = source
-        self.source.dests.append(self)
-        self.ampl_min = source.ampl_min
-        self.ampl_max = source.ampl_max
-        self.unit = source.unit
-        self.bufferframes = 0
-        self.backframes = 0
-        self.channels = self.source.channels
-        self.rate = self.source.rate
+        for attr in ('ampl_min', 'ampl_max', 'unit', 'channels', 'rate'):
+            setattr(self, attr, getattr(source, attr))
+        self.bufferframes = self.backframes = 0
         self.buffer_changed = np.zeros(self.channels, dtype=bool)
         self.buffer = np.zeros((0, self.channels))
         self.plot_items = [None]*self.channels
@@ -440,48 +435,49 @@ class BufferedData(BufferedArray):
         src = self.source
         return len(src._hostbuf) if isinstance(src, BufferedData) else len(src.buffer)
 
+    def _source_buffer(self):
+        src = self.source
+        return src._hostbuf if isinstance(src, BufferedData) else src.buffer
+
     def align_buffer(self):
-        soffset = self.source.offset
-        snframes = self._source_len()
-        if soffset > 0:
-            n = floor(self.source_tbefore*self.source.rate)
-            soffset += n
-            snframes -= n
-        if self.source.offset + self._source_len() < self.source.frames:
-            n = floor(self.source_tafter*self.source.rate)
-            snframes -= n
-        offset = ceil(soffset*self.rate/self.source.rate)
-        nframes = floor((soffset + snframes)*self.rate/self.source.rate) - offset
-        self.move_buffer(offset, nframes)
+        """Put this buffer over what the source holds minus the margins the computation needs:
+        `source_tbefore` at the front unless the source starts at the beginning of the recording,
+        `source_tafter` at the back unless it reaches the end (buffereddata.py:75-88)."""
+        src = self.source
+        first, count = src.offset, self._source_len()
+        reaches_end = first + count >= src.frames
+        if first > 0:
+            margin = floor(self.source_tbefore*src.rate)
+            first, count = first + margin, count - margin
+        if not reaches_end:
+            count -= floor(self.source_tafter*src.rate)
+        offset = ceil(first*self.rate/src.rate)
+        self.move_buffer(offset, floor((first + count)*self.rate/src.rate) - offset)
         self.bufferframes = len(self._hostbuf)
 
     def load_buffer(self, offset, nframes, buffer):
+        """Fill `buffer` (frames [offset, offset + nframes) of this trace) from the source's
+        buffer through process() (buffereddata.py:91-109)."""
         if _TRACE:
             print(f'load {self.name} {offset/self.rate:.3f} - {(offset + nframes)/self.rate:.3f}')
-        # transform to rate of source buffer:
-        soffset = floor(offset*self.source.rate/self.rate)
-        snframes = ceil((offset + nframes)*self.source.rate/self.rate) - soffset
-        # the reference divides seconds by the rate here (buffereddata.py:96,99), so
-        # nbefore is 0 and nafter is 1 for any realistic rate; kept for parity.
-        nbefore = floor(self.source_tbefore/self.source.rate)
-        soffset -= nbefore
-        snframes += nbefore
-        nafter = ceil(self.source_tafter/self.source.rate)
-        snframes += nafter
-        soffset -= self.source.offset
-        if soffset < 0:
-            nbefore += soffset
-            snframes += soffset
-            soffset = 0
-        slen = self._source_len()
-        if soffset + snframes > slen:
-            snframes = slen - soffset
         src = self.source
-        sbuf = src._hostbuf if isinstance(src, BufferedData) else src.buffer
-        source = sbuf[soffset:soffset + snframes]
-        self._pending = _Call(soffset, len(source), offset - self.offset, len(buffer))
+        # the same span in source frames
+        first = floor(offset*src.rate/self.rate)
+        count = ceil((offset + nframes)*src.rate/self.rate) - first
+        # Margins.  The reference DIVIDES the margins in seconds by the rate where it means to
+        # multiply (buffereddata.py:96,99), which for any real rate gives no frame before and one
+        # frame after.  Kept as it is: it decides what process() gets to see.
+        lead = floor(self.source_tbefore/src.rate)
+        tail = ceil(self.source_tafter/src.rate)
+        first -= lead + src.offset               # from here on relative to the source's buffer
+        count += lead + tail
+        if first < 0:                             # the source's buffer starts later than that
+            lead, count, first = lead + first, count + first, 0
+        count = min(count, self._source_len() - first)
+        source = self._source_buffer()[first:first + count]
+        self._pending = _Call(first, len(source), offset - self.offset, len(buffer))
         try:
-            self.process(source, buffer, nbefore)
+            self.process(source, buffer, lead)
         finally:
             self._pending = None
 
@@ -497,40 +493,37 @@ class BufferedData(BufferedArray):
             self.buffer_changed[:] = True
 
     def recompute(self):
+        """(Re)allocate for the current geometry and compute the whole buffer (buffereddata.py:112-115)."""
         if self._source_len() > 0:
             self.allocate_buffer()
         self.reload_buffer()
 
     def is_visible(self):
-        for pi in self.plot_items:
-            if pi is not None and pi.isVisible():
-                return True
-        return False
+        return any(item is not None and item.isVisible() for item in self.plot_items)
 
     def set_visible(self, show):
-        for pi in self.plot_items:
-            if pi is not None:
-                pi.setVisible(show)
+        for item in self.plot_items:
+            if item is not None:
+                item.setVisible(show)
 
     def set_need_update(self):
-        self.need_update = False
-        for pi in self.plot_items:
-            if pi is not None and pi.isVisible():
-                self.need_update = True
-                break
-        for d in self.dests:
-            d.set_need_update()
-        # end of dependency chain:
-        if len(self.dests) == 0:
-            # go to sources and propagate needed update:
-            trace = self
-            while hasattr(trace, 'source'):
-                s = trace.source
-                s.need_update = trace.need_update or s.need_update
-                trace = s
+        """A trace needs computing if one of its plot items is shown; from every leaf of the
+        dependency tree the need then climbs up to all sources (buffereddata.py:131-146)."""
+        self.need_update = self.is_visible()
+        for dest in self.dests:
+            dest.set_need_update()
+        if self.dests:
+            return
+        node = self
+        while hasattr(node, 'source'):
+            node.source.need_update = node.need_update or node.source.need_update
+            node = node.source
 
     def recompute_all(self):
-        if self.need_update:
-            self.recompute()
-            for d in self.dests:
-                d.recompute_all()
+        """Recompute this trace and, recursively, the traces derived from it -- those that are
+        needed (buffereddata.py:149-153)."""
+        if not self.need_update:
+            return
+        self.recompute()
+        for dest in self.dests:
+            dest.recompute_all()

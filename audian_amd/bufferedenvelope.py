@@ -11,22 +11,19 @@ from .design import butter_sos
 
 
 class BufferedEnvelope(BufferedData):
+    """Same constructor and attributes as audian's class (bufferedenvelope.py:13-26):
+    envelope_cutoff, highpass_cutoff, filter_order, sos."""
 
-    def __init__(self, name='envelope', source='filtered',
-                 panel='trace', color='#ff8800',
-                 lw_thin=2.5, lw_thick=4, envelope_cutoff=500,
-                 filter_order=2, highpass_cutoff=0):
-        super().__init__(name, source, tbefore=1, panel=panel,
-                         panel_type='trace', color=color,
-                         lw_thin=lw_thin, lw_thick=lw_thick)
-        self.envelope_cutoff = envelope_cutoff
-        self.highpass_cutoff = highpass_cutoff
-        self.filter_order = filter_order
-        self.sos = None
+    def __init__(self, name='envelope', source='filtered', panel='trace', color='#ff8800', lw_thin=2.5,
+                 lw_thick=4, envelope_cutoff=500, filter_order=2, highpass_cutoff=0):
+        BufferedData.__init__(self, name, source, tbefore=1, panel=panel, panel_type='trace',
+                              color=color, lw_thin=lw_thin, lw_thick=lw_thick)
+        self.envelope_cutoff, self.highpass_cutoff = envelope_cutoff, highpass_cutoff
+        self.filter_order, self.sos = filter_order, None
         self._plan = None
 
     def open(self, source):
-        super().open(source)
+        BufferedData.open(self, source)
         self.sos = None
         self.update()
 
@@ -57,15 +54,14 @@ class BufferedEnvelope(BufferedData):
             self.ctx.synchronize()
 
     def update(self):
+        """Low-pass at envelope_cutoff, or band-pass (highpass_cutoff, envelope_cutoff) when a
+        high-pass is set; a design scipy would reject leaves sos = None, i.e. a zero envelope
+        (bufferedenvelope.py:44-55)."""
         from . import hipdsp, _lib
+        band = self.highpass_cutoff > 0
+        wn = (self.highpass_cutoff, self.envelope_cutoff) if band else self.envelope_cutoff
         try:
-            if self.highpass_cutoff > 0:
-                self.sos = butter_sos(self.filter_order,
-                                      (self.highpass_cutoff, self.envelope_cutoff),
-                                      'bandpass', self.rate)
-            else:
-                self.sos = butter_sos(self.filter_order, self.envelope_cutoff,
-                                      'lowpass', self.rate)
+            self.sos = butter_sos(self.filter_order, wn, 'bandpass' if band else 'lowpass', self.rate)
         except ValueError:
             self.sos = None
         if self.sos is not None:

@@ -17,25 +17,40 @@ def make_plans(ctx, sos, max_sections):
             for i in range(0, len(sos), max_sections)]
 
 
-class BufferedFilter(BufferedData):
+def choose_design(highpass, lowpass, rate):
+    """Which Butterworth response BufferedFilter.update asks for (bufferedfilter.py:39-52):
+    a high-pass below 0.1 % of Nyquist counts as "off", a low-pass within 1e-8 Hz of Nyquist too.
+    Returns (btype, Wn) or None for the pass-through."""
+    nyquist = rate/2
+    hp_off = highpass < 0.001*nyquist
+    lp_off = lowpass >= nyquist - 1e-8
+    if hp_off and lp_off:
+        return None
+    if hp_off:
+        return 'lowpass', lowpass
+    if lp_off:
+        return 'highpass', highpass
+    return 'bandpass', (highpass, lowpass)
 
-    def __init__(self, name='filtered', source='data', panel='trace',
-                 color='#00ee00', lw_thin=1.1, lw_thick=2):
-        super().__init__(name, source, tbefore=10, panel=panel,
-                         panel_type='trace', color=color,
-                         lw_thin=lw_thin, lw_thick=lw_thick)
-        self.highpass_cutoff = 0
-        self.lowpass_cutoff = 1
-        self.filter_order = 2
-        self.sos = None
+
+class BufferedFilter(BufferedData):
+    """Same constructor and attributes as audian's class (bufferedfilter.py:11-21):
+    highpass_cutoff, lowpass_cutoff, filter_order, sos."""
+
+    def __init__(self, name='filtered', source='data', panel='trace', color='#00ee00', lw_thin=1.1,
+                 lw_thick=2):
+        BufferedData.__init__(self, name, source, tbefore=10, panel=panel, panel_type='trace',
+                              color=color, lw_thin=lw_thin, lw_thick=lw_thick)
+        self._reset(lowpass=1)
         self._plans = []
 
+    def _reset(self, lowpass):
+        self.highpass_cutoff, self.lowpass_cutoff, self.filter_order, self.sos = 0, lowpass, 2, None
+
     def open(self, source):
-        super().open(source)
-        self.highpass_cutoff = 0
-        self.lowpass_cutoff = self.rate/2
-        self.filter_order = 2
-        self.sos = None
+        """Link to `source`; the filter starts wide open (0 Hz ... Nyquist, order 2)."""
+        BufferedData.open(self, source)
+        self._reset(lowpass=self.rate/2)
         self.update()
 
     def process(self, source, dest, nbefore):
@@ -70,25 +85,17 @@ class BufferedFilter(BufferedData):
             self.ctx.synchronize()
 
     def update(self):
+        """Design the filter for the current cut-offs and order, refresh the device plans and
+        recompute this trace and everything derived from it."""
         from . import _lib
-        if self.highpass_cutoff < 0.001*self.rate/2 and \
-           self.lowpass_cutoff >= self.rate/2 - 1e-8:
-            self.sos = None
-        elif self.highpass_cutoff < 0.001*self.rate/2:
-            self.sos = butter_sos(self.filter_order, self.lowpass_cutoff,
-                                  'lowpass', self.rate)
-        elif self.lowpass_cutoff >= self.rate/2 - 1e-8:
-            self.sos = butter_sos(self.filter_order, self.highpass_cutoff,
-                                  'highpass', self.rate)
-        else:
-            self.sos = butter_sos(self.filter_order,
-                                  (self.highpass_cutoff, self.lowpass_cutoff),
-                                  'bandpass', self.rate)
+        design = choose_design(self.highpass_cutoff, self.lowpass_cutoff, self.rate)
+        self.sos = None if design is None else butter_sos(self.filter_order, design[1], design[0], self.rate)
+        chunk = _lib.MAX_SECTIONS
         if self.sos is None:
             self._plans = []
-        elif len(self._plans) == (len(self.sos) + _lib.MAX_SECTIONS - 1)//_lib.MAX_SECTIONS:
+        elif len(self._plans) == -(-len(self.sos)//chunk):
             for i, plan in enumerate(self._plans):        # re-use the device blocks
-                plan.set(self.sos[i*_lib.MAX_SECTIONS:(i + 1)*_lib.MAX_SECTIONS])
+                plan.set(self.sos[i*chunk:(i + 1)*chunk])
         else:
-            self._plans = make_plans(self.ctx, self.sos, _lib.MAX_SECTIONS)
+            self._plans = make_plans(self.ctx, self.sos, chunk)
         self.recompute_all()

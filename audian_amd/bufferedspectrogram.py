@@ -19,36 +19,49 @@ def decibel(power, ref_power=1.0, min_power=1e-20):
     return out if out.ndim else float(out)
 
 
-class BufferedSpectrogram(BufferedData):
+# parameter limits of the reference (bufferedspectrogram.py:83-100)
+MIN_NFFT = 8
+MAX_NFFT = 2**30
+MAX_OVERLAP = 0.99999
 
-    def __init__(self, name='spectrogram', source='filtered',
-                 panel='spectrogram', nfft=256,
+
+def hop_for(nfft, overlap_frac):
+    """Frame advance for `nfft`-sample windows overlapping by `overlap_frac`: rounded to the
+    nearest sample and kept inside 1 ... nfft (what BufferedSpectrogram.set_hop settles on)."""
+    return int(min(max(np.round(nfft*(1 - overlap_frac)), 1), nfft))
+
+
+class BufferedSpectrogram(BufferedData):
+    """Same constructor and attributes as audian's class (bufferedspectrogram.py:14-29):
+    nfft / hop / overlap_frac, frequencies, fresolution, tresolution, spec_rect, use_spec, init."""
+
+    def __init__(self, name='spectrogram', source='filtered', panel='spectrogram', nfft=256,
                  overlap_frac=0.5):
-        super().__init__(name, source, tafter=10, panel=panel,
-                         panel_type='spectrogram')
-        self.nfft = nfft
-        self.hop = 0
-        self.overlap_frac = overlap_frac
+        BufferedData.__init__(self, name, source, tafter=10, panel=panel, panel_type='spectrogram')
+        self.nfft, self.overlap_frac, self.hop = nfft, overlap_frac, 0
         self.set_hop()
         self.frequencies = np.zeros(0)
-        self.fresolution = 1
-        self.tresolution = 1
-        self.spec_rect = []
-        self.use_spec = True
-        self.init = True
+        self.fresolution = self.tresolution = 1
+        self.spec_rect, self.use_spec, self.init = [], True, True
+
+    def _bins(self):
+        return self.nfft//2 + 1
+
+    def _set_resolutions(self, source_rate):
+        self.fresolution = source_rate/self.nfft
+        self.tresolution = self.hop/source_rate
 
     def open(self, source):
-        self.hop = int(self.nfft*(1 - self.overlap_frac))
-        self.fresolution = source.rate/self.nfft
-        self.frequencies = np.arange(0, source.rate/2 + self.fresolution/2,
-                                     self.fresolution)
-        self.tresolution = self.hop/source.rate
-        self.spec_rect = []
-        self.use_spec = True
-        super().open(source, self.hop, more_shape=(self.nfft//2 + 1,))
-        self.unit = f'{self.unit}^2/Hz'
-        self.ampl_min = 0
-        self.ampl_max = self.source.rate/2
+        """Link to `source` at a frame rate of one spectrum per hop.  Note that the reference
+        truncates the hop here (bufferedspectrogram.py:32) while set_hop() rounds it."""
+        self.hop = int((1 - self.overlap_frac)*self.nfft)
+        self._set_resolutions(source.rate)
+        self.frequencies = np.arange(0, 0.5*(source.rate + self.fresolution), self.fresolution)
+        self.spec_rect, self.use_spec = [], True
+        BufferedData.open(self, source, self.hop, more_shape=(self._bins(),))
+        self.unit = self.unit + '^2/Hz'
+        # the y axis of a spectrogram is frequency
+        self.ampl_min, self.ampl_max = 0, 0.5*self.source.rate
 
     def process(self, source, dest, nbefore):
         """dest[k, c, :] = one-sided PSD of source[k*hop : k*hop + nfft, c]; frames that do
@@ -74,42 +87,32 @@ class BufferedSpectrogram(BufferedData):
                           self.source.rate/2 + self.fresolution]
 
     def set_hop(self):
-        hop = int(np.round((1 - self.overlap_frac)*self.nfft))
-        if hop < 1:
-            hop = 1
-        if hop > self.nfft:
-            hop = self.nfft
-        if self.hop != hop:
+        """Recompute hop from nfft and overlap_frac; True if it changed (then overlap_frac is
+        snapped to the value the integer hop really gives)."""
+        hop = hop_for(self.nfft, self.overlap_frac)
+        changed = hop != self.hop
+        if changed:
             self.hop = hop
-            self.overlap_frac = 1 - self.hop/self.nfft
-            return True
-        else:
-            return False
+            self.overlap_frac = 1 - hop/self.nfft
+        return changed
 
     def update(self, nfft=None, overlap_frac=None):
-        spec_update = False
+        """New window length and/or overlap (DataBrowser.set_resolution, databrowser.py:1195):
+        nfft is limited to 8 ... min(len(source)//2, 2**30) with the upper limit winning,
+        overlap_frac to 0 ... 0.99999; everything is recomputed if nfft or hop changed."""
+        dirty = False
         if nfft is not None:
-            if nfft < 8:
-                nfft = 8
-            max_nfft = min(len(self.source)//2, 2**30)
-            if nfft > max_nfft:
-                nfft = max_nfft
-            if self.nfft != nfft:
-                self.nfft = nfft
-                spec_update = True
+            nfft = min(max(nfft, MIN_NFFT), min(len(self.source)//2, MAX_NFFT))
+            dirty = nfft != self.nfft
+            self.nfft = nfft
         if overlap_frac is not None:
-            if overlap_frac < 0.0:
-                overlap_frac = 0.0
-            elif overlap_frac > 0.99999:
-                overlap_frac = 0.99999
-            self.overlap_frac = overlap_frac
-        if self.set_hop():
-            spec_update = True
-        if spec_update:
-            self.tresolution = self.hop/self.source.rate
-            self.fresolution = self.source.rate/self.nfft
-            self.update_step(self.hop, more_shape=(self.nfft//2 + 1,))
-            self.recompute_all()
+            self.overlap_frac = min(max(overlap_frac, 0.0), MAX_OVERLAP)
+        dirty = self.set_hop() or dirty
+        if not dirty:
+            return
+        self._set_resolutions(self.source.rate)
+        self.update_step(self.hop, more_shape=(self._bins(),))
+        self.recompute_all()
 
     def decibel_image(self, channel, ref_power=1.0, min_power=1e-20):
         """decibel(buffer[:, channel, :].T) as SpecItem.update_plot needs it
@@ -186,9 +189,7 @@ class BufferedSpectrogram(BufferedData):
         from .buffereddata import _covers
         F = self._hostbuf.shape[2]
         n = len(self._hostbuf)
-        nf = F//16
-        if nf < 1:
-            nf = 1
+        nf = max(F//16, 1)                       # top 1/16 of the band
         if self._dev is not None and _covers(self._dev_valid, 0, n) and self._stale:
             base = self._dev.view(channel*n*F, (1,))
             band = hipdsp.DeviceArray(self.ctx, (n, nf), np.float32)
@@ -203,12 +204,10 @@ class BufferedSpectrogram(BufferedData):
             with np.errstate(all='ignore'):
                 zmin = np.percentile(decibel(self.buffer[:, channel, -nf:]), 95)
             zmax = np.max(decibel(self.buffer[:, channel, :]))
-        if not np.isfinite(zmin) or not np.isfinite(zmax):
+        if not (np.isfinite(zmin) and np.isfinite(zmax)):
             return None, None
-        self.init = False
-        zmax = zmin + 0.95*(zmax - zmin)
-        if zmax - zmin < 20:
-            zmax = zmin + 20
-        if zmax - zmin > 80:
-            zmin = zmax - 80
-        return zmin, zmax
+        self.init = False                       # once per trace
+        # upper end 5 % below the maximum; at least 20 dB of range, at most 80 dB
+        lift = max(0.95*(zmax - zmin), 20)
+        zmax = zmin + lift
+        return (zmax - 80 if lift > 80 else zmin), zmax
