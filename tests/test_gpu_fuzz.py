@@ -1,0 +1,104 @@
+"""Seeded random sweeps over slab length, nbefore, pitch, segmentation and filter design for the
+IIR entry points: lengths cluster around multiples of the 2048-sample tile and of the sosfiltfilt
+pad length, where the tile-border, odd-extension and prefetch paths change."""
+
+import numpy as np
+import pytest
+
+import gpu_helpers as gh
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+TILE = 2048
+
+
+def draw_length(rng, lo=1):
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        return int(rng.integers(lo, 200))
+    if kind == 1:
+        return max(lo, int(rng.integers(1, 12))*TILE + int(rng.integers(-40, 41)))
+    if kind == 2:
+        return int(rng.integers(lo, 40000))
+    return max(lo, int(rng.integers(40, 160))*TILE + int(rng.integers(-TILE, TILE)))
+
+
+def draw_design(rng, rate, envelope):
+    from audian_amd.design import butter_sos
+    order = int(rng.integers(1, 5 if not envelope else 4))
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        return butter_sos(order, float(rng.uniform(5.0, 0.4*rate)), 'lowpass', rate)
+    if kind == 1 and not envelope:
+        return butter_sos(order, float(rng.uniform(20.0, 0.3*rate)), 'highpass', rate)
+    lo = float(rng.uniform(20.0, 0.1*rate))
+    order = min(order, 2)
+    return butter_sos(order, (lo, float(rng.uniform(2*lo, 0.45*rate))), 'bandpass', rate)
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_random_envelope_cases(oracle, seed):
+    from audian_amd import hipdsp
+    rng = np.random.default_rng(1000 + seed)
+    rate = float(rng.choice([8000.0, 44100.0, 96000.0, 192000.0]))
+    sos = draw_design(rng, rate, envelope=True)
+    edge = oracle.sosfiltfilt_edge(sos)
+    T = draw_length(rng, lo=edge + 1)
+    C = int(rng.integers(1, 6))
+    skip = int(rng.choice([0, 0, 1, rng.integers(0, T + 1), min(T, TILE), min(T, TILE + 1)]))
+    pitch_in, pitch_out = T + int(rng.integers(0, 9)), max(T - skip, 1) + int(rng.integers(0, 9))
+    clamp, rectify = bool(rng.integers(0, 2)), bool(rng.integers(0, 4))
+    x = (rng.standard_normal((C, T))*rng.uniform(0.1, 3.0)).astype(np.float32)
+    c = gh.ctx()
+    c.set_max_segments(int(rng.choice([0, 0, 1, 3])))
+    try:
+        dx = hipdsp.DeviceArray(c, (C, pitch_in), np.float32)
+        host = np.zeros((C, pitch_in), dtype=np.float32)
+        host[:, :T] = x
+        hipdsp.lib.hipdsp_memcpy_h2d(c.handle, hipdsp._p(dx), host.ctypes.data, host.nbytes)
+        dy = hipdsp.DeviceArray(c, (C, pitch_out), np.float32)
+        hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(dy), 0x7f, 4*C*pitch_out)
+        hipdsp.envelope(c, hipdsp.SosPlan(c, sos), dx, pitch_in, dy, pitch_out, C, T, skip, rectify=rectify,
+                        gain=np.pi/2 if rectify else 1.0, clamp=clamp)
+        got = dy.to_host()
+    finally:
+        c.set_max_segments(0)
+    src = x.T.astype(np.float64)
+    want = oracle.sosfiltfilt(sos, (np.pi/2)*np.abs(src) if rectify else src)
+    if clamp:
+        want[want < 0] = 0
+    for ch in range(C):
+        if T - skip > 0:
+            ref = want[skip:, ch]
+            scale = max(np.max(np.abs(want[:, ch])), 1e-30)
+            assert np.max(np.abs(got[ch, :T - skip] - ref))/scale < TOL, (seed, T, skip, ch)
+        # nothing is written past the row
+        tail = got[ch, max(T - skip, 0):]
+        assert np.all(tail.view(np.uint32) == 0x7f7f7f7f), (seed, 'wrote past the row')
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_random_filter_envelope_chain_cases(oracle, seed):
+    from audian_amd import hipdsp
+    rng = np.random.default_rng(5000 + seed)
+    rate = float(rng.choice([44100.0, 96000.0]))
+    fsos = draw_design(rng, rate, envelope=False)
+    esos = draw_design(rng, rate, envelope=True)
+    edge = oracle.sosfiltfilt_edge(esos)
+    T = draw_length(rng, lo=edge + 1)
+    C = int(rng.integers(1, 5))
+    x = rng.standard_normal((T, C)).astype(np.float32)
+    c = gh.ctx()
+    dx = gh.to_planar(c, x)
+    yf = hipdsp.DeviceArray(c, (C, T), np.float32)
+    ye = hipdsp.DeviceArray(c, (C, T), np.float32)
+    hipdsp.sosfilt_envelope(c, hipdsp.SosPlan(c, fsos), hipdsp.SosPlan(c, esos), dx, T, yf, T, ye, T, C, T)
+    gf, ge = yf.to_host(), ye.to_host()
+    want_f = oracle.sosfilt(fsos, x.astype(np.float64))
+    want_e = np.zeros_like(want_f)
+    oracle.envelope_process(esos, gf.T.astype(np.float64), want_e, 0)
+    for ch in range(C):
+        assert rel_err(gf[ch], want_f[:, ch]) < TOL, (seed, T, ch)
+        if np.max(np.abs(want_e[:, ch])) > 0:
+            assert rel_err(ge[ch], want_e[:, ch]) < TOL, (seed, T, ch)
