@@ -102,3 +102,58 @@ def test_random_filter_envelope_chain_cases(oracle, seed):
         assert rel_err(gf[ch], want_f[:, ch]) < TOL, (seed, T, ch)
         if np.max(np.abs(want_e[:, ch])) > 0:
             assert rel_err(ge[ch], want_e[:, ch]) < TOL, (seed, T, ch)
+
+
+@pytest.mark.parametrize('seed', range(20))
+def test_random_spectrogram_cases(oracle, seed):
+    """Random window length (every kernel family: generic, two- and three-stage, direct DFT), hop,
+    slab length and destination length, incl. destinations longer than the source supports (zero
+    tail) and shorter (fewer frames than fit)."""
+    rng = np.random.default_rng(9000 + seed)
+    rate = float(rng.choice([22050.0, 96000.0]))
+    family = rng.integers(0, 4)
+    if family == 0:
+        nfft = int(2**rng.integers(3, 8))                 # generic radix-2 kernel
+    elif family == 1:
+        nfft = int(2**rng.integers(8, 13))                # register/LDS kernels
+    elif family == 2:
+        nfft = int(rng.choice([8192, 16384]))
+    else:
+        nfft = int(rng.integers(9, 600))                  # whatever the clamp can produce
+    hop = int(rng.choice([nfft//2, max(nfft//4, 1), nfft, int(rng.integers(1, nfft + 1))]))
+    hop = max(hop, 1)
+    nframes = int(rng.integers(1, 40))
+    T = (nframes - 1)*hop + nfft + int(rng.integers(-nfft//2, hop + 3))
+    T = max(T, 0)
+    C = int(rng.integers(1, 4))
+    nd = max(1, (T + hop - 1)//hop + int(rng.integers(-2, 3)))
+    x = (rng.standard_normal((T, C)) + 0.3).astype(np.float32)
+    got = gh.gpu_spectrogram(x, rate, nfft, hop, nd)
+    want = np.full((nd, C, nfft//2 + 1), 7.0)
+    if oracle.spectrogram_process(x.astype(np.float64), want, rate, nfft, hop) is None:
+        want[:] = 0
+    for k in range(nd):
+        for ch in range(C):
+            peak = np.max(np.abs(want[k, ch]))
+            if peak == 0:
+                assert np.all(got[k, ch] == 0), (seed, nfft, hop, k)
+            else:
+                assert np.max(np.abs(got[k, ch] - want[k, ch]))/peak < TOL, (seed, nfft, hop, T, k, ch)
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_random_sosfilt_cases(oracle, seed):
+    rng = np.random.default_rng(7000 + seed)
+    rate = float(rng.choice([8000.0, 48000.0, 192000.0]))
+    sos = draw_design(rng, rate, envelope=False)
+    T = draw_length(rng)
+    C = int(rng.integers(1, 6))
+    skip = int(rng.choice([0, 1, rng.integers(0, T + 1), min(T, TILE)]))
+    x = rng.standard_normal((T, C)).astype(np.float32)
+    got = gh.gpu_sosfilt(sos, x, skip=skip, max_segments=int(rng.choice([0, 0, 1, 5])))
+    want = oracle.sosfilt(sos, x.astype(np.float64))[skip:]
+    assert got.shape == want.shape
+    for ch in range(C):
+        if len(want):
+            scale = max(np.max(np.abs(oracle.sosfilt(sos, x[:, ch].astype(np.float64)))), 1e-30)
+            assert np.max(np.abs(got[:, ch] - want[:, ch]))/scale < TOL, (seed, T, skip, ch)
