@@ -46,3 +46,12 @@ for i in range(5):
     mm = f.minmax_decimate(f.offset, f.offset + len(f.buffer), len(f.buffer)//2000, channel=0)
 dt = (time.perf_counter() - t0)/5
 print(f'  + dB image of one channel + 2000 px min/max trace: {dt*1e3:.2f} ms', flush=True)
+s = g['spectrogram']
+t0 = time.perf_counter()
+for i in range(5):
+    f.highpass_cutoff = 200.0 + 60*i
+    f.update()
+    img = s.decimated_image(s.offset, s.offset + len(s.buffer), max(1, len(s.buffer)//2000), 0)
+    mm = f.minmax_decimate(f.offset, f.offset + len(f.buffer), len(f.buffer)//2000, channel=0)
+dt = (time.perf_counter() - t0)/5
+print(f'  + the same with the image at screen resolution {img.shape}: {dt*1e3:.2f} ms', flush=True)
