@@ -82,6 +82,8 @@ _SIGNATURES = {
     'hipdsp_graph_destroy': ([_vp, _vp], _int),
     'hipdsp_malloc': ([_vp, _sz, _pp], _int),
     'hipdsp_free': ([_vp, _vp], _int),
+    'hipdsp_pool_stats': ([_vp, ctypes.POINTER(_sz), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)], _int),
+    'hipdsp_pool_trim': ([_vp], _int),
     'hipdsp_memset': ([_vp, _vp, _int, _sz], _int),
     'hipdsp_memcpy_h2d': ([_vp, _vp, _vp, _sz], _int),
     'hipdsp_memcpy_d2h': ([_vp, _vp, _vp, _sz], _int),

@@ -24,6 +24,7 @@ struct hipdsp_ctx {
     int sos_prefetch;      // experiments: register prefetch of the next tile in the envelope sweeps
     int spec_no_half;      // experiments/tests: do not reuse the overlapped half frame
     int spec_fpw, spec_kernel;   // experiments (tools/), 0 = defaults
+    struct hd_pool *pool;  // stream-ordered cache of freed device blocks (ctx.hip)
 };
 
 struct hipdsp_graph {

@@ -1,7 +1,31 @@
 // Context, error reporting, memory and event helpers of libhip_dsp.
 #include "common.h"
+#include <map>
+#include <unordered_map>
 
 static thread_local char g_err[512] = "";
+
+// Stream-ordered cache of freed device blocks.  hipMalloc/hipFree synchronise the device, which
+// stalls an interactive loop that needs a temporary per redraw (a screen-resolution image, a
+// min/max trace); blocks up to `max_block` bytes go back into a size-ordered free list instead
+// and are handed out again for requests they fit without wasting more than a quarter.  Safe
+// because every kernel and copy of a context runs on the context's one stream: whatever still
+// uses a freed block is ahead of its next user in that stream.
+struct hd_pool {
+    std::multimap<size_t, void *> cached;            // size -> block
+    std::unordered_map<void *, size_t> live;         // handed out by hipdsp_malloc
+    size_t cached_bytes = 0;
+    size_t limit = (size_t)1 << 30;                  // bytes kept at most ("pool_limit_mb")
+    size_t max_block = (size_t)256 << 20;            // larger blocks are never cached
+    unsigned long long hits = 0, misses = 0;
+};
+
+static void pool_trim(hd_pool *p)
+{
+    for (auto &kv : p->cached) (void)hipFree(kv.second);
+    p->cached.clear();
+    p->cached_bytes = 0;
+}
 
 void hipdsp_set_error(const char *fmt, ...)
 {
@@ -52,6 +76,7 @@ int hipdsp_ctx_create(int device, void *stream, hipdsp_ctx **out)
     ctx->spec_fpw = ctx->spec_kernel = 0;
     ctx->sos_waves_per_cu = 0;
     ctx->spec_no_half = 0;
+    ctx->pool = new hd_pool();
     ctx->sos_prefetch = 1;
     for (int i = 0; i < 20; i++) ctx->fft_tables2[i] = nullptr;
     *out = ctx;
@@ -61,6 +86,10 @@ int hipdsp_ctx_create(int device, void *stream, hipdsp_ctx **out)
 int hipdsp_ctx_destroy(hipdsp_ctx *ctx)
 {
     if (!ctx) return HIPDSP_OK;
+    if (ctx->pool) {
+        pool_trim(ctx->pool);
+        delete ctx->pool;
+    }
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     for (int i = 0; i < 20; i++)
         if (ctx->fft_tables[i]) (void)hipFree(ctx->fft_tables[i]);
@@ -100,6 +129,15 @@ int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value)
     if (strcmp(name, "spec_fpw") == 0) { ctx->spec_fpw = (int)value; return HIPDSP_OK; }
     if (strcmp(name, "sos_waves_per_cu") == 0) { ctx->sos_waves_per_cu = (int)value; return HIPDSP_OK; }
     if (strcmp(name, "sos_prefetch") == 0) { ctx->sos_prefetch = value != 0; return HIPDSP_OK; }
+    if (strcmp(name, "pool_limit_mb") == 0) {
+        HD_REQUIRE(value >= 0, "pool_limit_mb must be >= 0");
+        ctx->pool->limit = (size_t)value << 20;
+        if (ctx->pool->cached_bytes > ctx->pool->limit) {
+            HD_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+            pool_trim(ctx->pool);
+        }
+        return HIPDSP_OK;
+    }
     if (strcmp(name, "spec_no_half") == 0) { ctx->spec_no_half = value != 0; return HIPDSP_OK; }
     if (strcmp(name, "spec_kernel") == 0) { ctx->spec_kernel = (int)value; return HIPDSP_OK; }
     hipdsp_set_error("unknown option '%s'", name);
@@ -125,20 +163,70 @@ int hipdsp_malloc(hipdsp_ctx *ctx, size_t bytes, void **dptr)
     *dptr = nullptr;
     if (bytes == 0) return HIPDSP_OK;
     HD_CHECK_HIP(hipSetDevice(ctx->device));
-    hipError_t e = hipMalloc(dptr, bytes);
+    hd_pool *p = ctx->pool;
+    const size_t want = (bytes + 511) & ~(size_t)511;
+    auto it = p->cached.lower_bound(want);
+    if (it != p->cached.end() && it->first <= want + want / 4 + 4096) {
+        *dptr = it->second;
+        p->live[*dptr] = it->first;
+        p->cached_bytes -= it->first;
+        p->cached.erase(it);
+        p->hits++;
+        return HIPDSP_OK;
+    }
+    hipError_t e = hipMalloc(dptr, want);
+    if (e == hipErrorOutOfMemory && !p->cached.empty()) {
+        (void)hipGetLastError();
+        pool_trim(p);                                  // give the cache back and try once more
+        e = hipMalloc(dptr, want);
+    }
     if (e == hipErrorOutOfMemory) {
         (void)hipGetLastError();
         hipdsp_set_error("hipMalloc(%zu bytes) out of memory", bytes);
         return HIPDSP_ERR_NOMEM;
     }
     HD_CHECK_HIP(e);
+    p->live[*dptr] = want;
+    p->misses++;
     return HIPDSP_OK;
 }
 
 int hipdsp_free(hipdsp_ctx *ctx, void *dptr)
 {
     HD_REQUIRE(ctx != nullptr, "ctx is NULL");
-    if (dptr) HD_CHECK_HIP(hipFree(dptr));
+    if (!dptr) return HIPDSP_OK;
+    hd_pool *p = ctx->pool;
+    auto it = p->live.find(dptr);
+    if (it == p->live.end()) {                         // not one of ours (or of another context)
+        HD_CHECK_HIP(hipFree(dptr));
+        return HIPDSP_OK;
+    }
+    const size_t size = it->second;
+    p->live.erase(it);
+    if (size <= p->max_block && p->cached_bytes + size <= p->limit) {
+        p->cached.emplace(size, dptr);
+        p->cached_bytes += size;
+        return HIPDSP_OK;
+    }
+    HD_CHECK_HIP(hipFree(dptr));
+    return HIPDSP_OK;
+}
+
+int hipdsp_pool_stats(hipdsp_ctx *ctx, size_t *cached_bytes, uint64_t *hits, uint64_t *misses)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (cached_bytes) *cached_bytes = ctx->pool->cached_bytes;
+    if (hits) *hits = ctx->pool->hits;
+    if (misses) *misses = ctx->pool->misses;
+    return HIPDSP_OK;
+}
+
+int hipdsp_pool_trim(hipdsp_ctx *ctx)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    HD_CHECK_HIP(hipSetDevice(ctx->device));
+    HD_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    pool_trim(ctx->pool);
     return HIPDSP_OK;
 }
 

@@ -39,6 +39,15 @@ class Context:
     def set_mid_event(self, ev):
         check(lib.hipdsp_ctx_set_mid_event(self._h, ev if ev is not None else ctypes.c_void_p(0)))
 
+    def pool_stats(self):
+        """(cached bytes, hits, misses) of the context's block cache behind hipdsp_malloc/free."""
+        cached, hits, misses = ctypes.c_size_t(), ctypes.c_uint64(), ctypes.c_uint64()
+        check(lib.hipdsp_pool_stats(self._h, ctypes.byref(cached), ctypes.byref(hits), ctypes.byref(misses)))
+        return int(cached.value), int(hits.value), int(misses.value)
+
+    def pool_trim(self):
+        check(lib.hipdsp_pool_trim(self._h))
+
     def reserve(self, nbytes):
         check(lib.hipdsp_ctx_reserve(self._h, int(nbytes)))
 

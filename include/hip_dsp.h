@@ -63,6 +63,7 @@ int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
 /* Named tuning/testing options (results do not depend on them beyond rounding):
  *   "max_segments"       as hipdsp_ctx_set_max_segments
  *   "sos_waves_per_cu"   resident waves per CU the IIR segment planner aims for (16)
+ *   "pool_limit_mb"      bytes (MiB) hipdsp_free may keep cached for hipdsp_malloc (1024)
  *   "sos_prefetch"       0: envelope sweeps without the register prefetch of the next tile (1)
  *   "force_generic_fft"  non-zero: every nfft takes the generic radix-2 spectrogram kernel
  *   "spec_kernel"        0 = default per size, 2 = two-stage, 3 = three-stage FFT kernel
@@ -95,8 +96,16 @@ int hipdsp_graph_destroy(hipdsp_ctx *ctx, hipdsp_graph *graph);
 
 /* ---- device memory helpers (so a non-torch host can keep stages resident) */
 
+/* hipdsp_free keeps blocks of up to 256 MiB in a per-context cache (at most "pool_limit_mb",
+ * default 1024; 0 turns it off) and hipdsp_malloc hands them out again, because hipMalloc /
+ * hipFree synchronise the device and an interactive redraw needs temporaries.  The cache is
+ * stream-ordered: free a block through a context whose stream is behind all work on it (order
+ * other contexts' streams with hipdsp_event_record / hipdsp_event_wait first). */
 int hipdsp_malloc(hipdsp_ctx *ctx, size_t bytes, void **dptr);
 int hipdsp_free(hipdsp_ctx *ctx, void *dptr);
+/* Cache statistics (any pointer may be NULL) / give every cached block back to the driver. */
+int hipdsp_pool_stats(hipdsp_ctx *ctx, size_t *cached_bytes, uint64_t *hits, uint64_t *misses);
+int hipdsp_pool_trim(hipdsp_ctx *ctx);
 int hipdsp_memset(hipdsp_ctx *ctx, void *dptr, int value, size_t bytes);
 int hipdsp_memcpy_h2d(hipdsp_ctx *ctx, void *dst, const void *host_src, size_t bytes);
 int hipdsp_memcpy_d2h(hipdsp_ctx *ctx, void *host_dst, const void *src, size_t bytes);

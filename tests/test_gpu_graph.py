@@ -113,3 +113,35 @@ def test_two_streams_ordered_by_events(oracle):
     assert np.array_equal(got_s, s1.to_host())
     for ch in range(C):
         assert rel_err(got_e[ch], e1.to_host()[ch]) < 1e-6
+
+
+def test_block_cache_reuses_freed_blocks():
+    """hipdsp_malloc / hipdsp_free keep freed blocks in a stream-ordered cache: no hipMalloc /
+    hipFree (device synchronisation) per temporary of an interactive redraw."""
+    from audian_amd import hipdsp
+    c = hipdsp.Context(0)
+    c.set_stream(c.create_stream())
+    a = hipdsp.DeviceArray(c, (1000, 1025), np.float32)
+    ptr = a.ptr
+    a.free()
+    cached, hits, misses = c.pool_stats()
+    assert cached >= 4*1000*1025 and misses == 1 and hits == 0
+    b = hipdsp.DeviceArray(c, (999, 1025), np.float32)          # fits the cached block
+    assert b.ptr == ptr and c.pool_stats()[1] == 1
+    big = hipdsp.DeviceArray(c, (300 << 20,), np.uint8)          # above the per-block limit: not cached
+    big.free()
+    assert c.pool_stats()[0] == 0
+    small = hipdsp.DeviceArray(c, (16,), np.float32)             # a much smaller request does not take it
+    b.free()
+    assert small.ptr != ptr
+    # data written through the stream before a block is recycled is still what a reader gets
+    src = np.arange(4096, dtype=np.float32)
+    x = hipdsp.DeviceArray.from_host(c, src)
+    y = hipdsp.DeviceArray(c, (4096,), np.float32)
+    hipdsp.lib.hipdsp_memcpy_d2d(c.handle, hipdsp._p(y), hipdsp._p(x), 4*4096)
+    x.free()                                                     # the copy may still be queued
+    z = hipdsp.DeviceArray.from_host(c, np.zeros(4096, dtype=np.float32))   # recycles x's block
+    assert np.array_equal(y.to_host(), src) and np.all(z.to_host() == 0)
+    c.set_option('pool_limit_mb', 0)
+    assert c.pool_stats()[0] == 0
+    c.pool_trim()
