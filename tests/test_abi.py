@@ -48,3 +48,18 @@ def test_product_does_not_import_oracle():
             if fn.endswith(('.py', '.hip', '.h')):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert 'oracle' not in text.lower(), f'{fn} mentions the oracle'
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 (no C++-isms, no torch or HIP types),
+    and a C translation unit can name every entry point."""
+    import shutil
+    import subprocess
+    import pytest
+    if shutil.which('gcc') is None:
+        pytest.skip('gcc not available')
+    src = tmp_path/'use_header.c'
+    calls = '\n'.join(f'    (void)&{name};' for name in declared_symbols())
+    src.write_text('#include "hip_dsp.h"\nint main(void)\n{\n' + calls + '\n    return HIPDSP_OK;\n}\n')
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Wextra', '-Werror', '-pedantic', '-I',
+                           os.path.join(ROOT, 'include'), '-c', str(src), '-o', str(tmp_path/'use_header.o')])
