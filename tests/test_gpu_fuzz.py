@@ -157,3 +157,53 @@ def test_random_sosfilt_cases(oracle, seed):
         if len(want):
             scale = max(np.max(np.abs(oracle.sosfilt(sos, x[:, ch].astype(np.float64)))), 1e-30)
             assert np.max(np.abs(got[:, ch] - want[:, ch]))/scale < TOL, (seed, T, skip, ch)
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_random_pitched_buffers(oracle, seed):
+    """Row pitches larger than the rows (ring-buffer mirrors are laid out like that): nothing outside
+    the valid part of a row may be read into the result or written."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rng = np.random.default_rng(3000 + seed)
+    rate = 48000.0
+    nfft = int(rng.choice([64, 256, 1024, 2048, 300]))
+    hop = int(rng.choice([nfft//2, nfft//4, nfft]))
+    C = int(rng.integers(1, 4))
+    T = int(rng.integers(nfft, 12*nfft))
+    nd = (T + hop - 1)//hop
+    F = nfft//2 + 1
+    xp, op = T + int(rng.integers(1, 50)), nd*F + int(rng.integers(1, 70))
+    x = rng.standard_normal((C, T)).astype(np.float32)
+    host = np.full((C, xp), np.float32(1e30))                  # poison behind every row
+    host[:, :T] = x
+    c = gh.ctx()
+    dx = hipdsp.DeviceArray.from_host(c, host)
+    out = hipdsp.DeviceArray(c, (C, op), np.float32)
+    hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(out), 0x7f, 4*C*op)
+    hipdsp.spectrogram(c, dx, xp, C, T, nfft, hop, rate, out, nd, out_pitch=op)
+    got = out.to_host()
+    want = np.zeros((nd, C, F))
+    if oracle.spectrogram_process(x.T.astype(np.float64), want, rate, nfft, hop) is None:
+        want[:] = 0
+    for ch in range(C):
+        g = got[ch, :nd*F].reshape(nd, F)
+        for k in range(nd):
+            peak = np.max(np.abs(want[k, ch]))
+            if peak == 0:
+                assert np.all(g[k] == 0)
+            else:
+                assert np.max(np.abs(g[k] - want[k, ch]))/peak < TOL, (seed, nfft, hop, k)
+        assert np.all(got[ch, nd*F:].view(np.uint32) == 0x7f7f7f7f), (seed, 'wrote past the row')
+    # the same for sosfilt
+    sos = butter_sos(2, (300.0, 3000.0), 'bandpass', rate)
+    skip = int(rng.integers(0, 5))
+    yp = T - skip + int(rng.integers(1, 40))
+    y = hipdsp.DeviceArray(c, (C, yp), np.float32)
+    hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(y), 0x7f, 4*C*yp)
+    hipdsp.sosfilt(c, hipdsp.SosPlan(c, sos), dx, xp, y, yp, C, T, skip)
+    gy = y.to_host()
+    wy = oracle.sosfilt(sos, x.T.astype(np.float64))[skip:]
+    for ch in range(C):
+        assert rel_err(gy[ch, :T - skip], wy[:, ch]) < TOL
+        assert np.all(gy[ch, T - skip:].view(np.uint32) == 0x7f7f7f7f)
