@@ -794,13 +794,12 @@ int fill_plan(SosPlanDev *p, const double *sos, int S)
 // Choose the number of time segments per channel.  One wave per (channel, segment);
 // a segment costs its own length plus the warm-up it re-reads, and waves run in rounds
 // of `slots` resident waves: minimise rounds * (segment + warm-up).
-void plan_segments(const hipdsp_ctx *ctx, long long N, long long channels, long long warm,
-                   long long *seg_len, int *n_seg)
+void plan_segments_for(long long slots, int max_segments, long long N, long long channels, long long warm,
+                       long long *seg_len, int *n_seg)
 {
-    const long long slots = (long long)ctx->n_cus * (ctx->sos_waves_per_cu > 0 ? ctx->sos_waves_per_cu : 16);
     long long max_seg = (N + TILE - 1) / TILE;            // at least one tile per segment
     if (warm >= (1LL << 40)) max_seg = 1;                 // non-decaying filter: never segment
-    if (ctx->max_segments > 0 && max_seg > ctx->max_segments) max_seg = ctx->max_segments;
+    if (max_segments > 0 && max_seg > max_segments) max_seg = max_segments;
     if (max_seg > 65536) max_seg = 65536;
     if (max_seg < 1) max_seg = 1;
     long long best_n = 1, best_len = (N + TILE - 1) / TILE * TILE;
@@ -821,6 +820,13 @@ void plan_segments(const hipdsp_ctx *ctx, long long N, long long channels, long 
     }
     *seg_len = best_len;
     *n_seg = (int)best_n;
+}
+
+void plan_segments(const hipdsp_ctx *ctx, long long N, long long channels, long long warm,
+                   long long *seg_len, int *n_seg)
+{
+    const long long slots = (long long)ctx->n_cus * (ctx->sos_waves_per_cu > 0 ? ctx->sos_waves_per_cu : 16);
+    plan_segments_for(slots, ctx->max_segments, N, channels, warm, seg_len, n_seg);
 }
 
 int launch_scan(hipdsp_ctx *ctx, const SosPlanDev *dev, int S, SeqArgs a, long long channels, long long warm)
@@ -1024,6 +1030,20 @@ int hipdsp_sos_plan_host(const double *host_sos, int n_sections, int64_t *warmup
     if (edge) *edge = tmp.edge;
     if (zi)
         for (int k = 0; k < 2 * n_sections; k++) zi[k] = tmp.zi[k];
+    return HIPDSP_OK;
+}
+
+int hipdsp_sos_segments_host(int64_t resident_waves, int max_segments, int64_t frames, int64_t channels,
+                             int64_t warmup, int64_t *segment_frames, int *n_segments)
+{
+    HD_REQUIRE(resident_waves >= 1 && frames >= 1 && channels >= 1 && warmup >= 0 && max_segments >= 0,
+               "bad argument");
+    HD_REQUIRE(segment_frames != nullptr && n_segments != nullptr, "NULL output");
+    long long len = 0;
+    int n = 0;
+    plan_segments_for(resident_waves, max_segments, frames, channels, warmup, &len, &n);
+    *segment_frames = len;
+    *n_segments = n;
     return HIPDSP_OK;
 }
 

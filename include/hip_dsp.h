@@ -171,6 +171,14 @@ int hipdsp_sosplan_upload(hipdsp_ctx *ctx, hipdsp_sosplan *plan);
  * scipy's sosfiltfilt pad length and sosfilt_zi (2*n_sections values); any output may be NULL. */
 int hipdsp_sos_plan_host(const double *host_sos, int n_sections, int64_t *warmup, int *edge,
                          double *zi);
+/* How the block-parallel IIR cuts `frames` samples of `channels` channels into time segments
+ * (one wave per channel and segment) when `resident_waves` waves fit on the device at once
+ * (CUs x "sos_waves_per_cu") and a segment has to re-read `warmup` samples before its range:
+ * the count that minimises rounds x (segment + warm-up); segment_frames is a multiple of the
+ * 2048-sample tile.  Host only (tests, capacity planning). */
+int hipdsp_sos_segments_host(int64_t resident_waves, int max_segments, int64_t frames,
+                             int64_t channels, int64_t warmup, int64_t *segment_frames,
+                             int *n_segments);
 /* Introspection (tests): warm-up length in samples, sosfiltfilt pad length. */
 int hipdsp_sosplan_info(hipdsp_ctx *ctx, hipdsp_sosplan *plan, int64_t *warmup, int *edge);
 

@@ -72,3 +72,48 @@ def test_plan_rejects_bad_tables():
         plan_host(np.tile(np.array([[1.0, 0.0, 0.0, 1.0, 0.0, 0.0]]), (5, 1)))   # > 4 sections
     with pytest.raises(ValueError):
         plan_host(np.array([[np.nan, 0.0, 0.0, 1.0, 0.0, 0.0]]))
+
+
+def segments(resident, frames, channels, warm, max_segments=0):
+    length = ctypes.c_int64()
+    count = ctypes.c_int()
+    _lib.check(_lib.lib.hipdsp_sos_segments_host(resident, max_segments, frames, channels, warm,
+                                                 ctypes.byref(length), ctypes.byref(count)))
+    return int(length.value), int(count.value)
+
+
+def test_segment_planner_properties():
+    """Segments are whole tiles, cover the slab, and their number follows the cost model
+    rounds x (segment + warm-up)."""
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        resident = int(rng.choice([256*8, 256*12, 256*16]))
+        channels = int(rng.integers(1, 300))
+        frames = int(rng.integers(1, 60_000_000))
+        warm = int(rng.choice([2048, 4096, 53248, 400*2048, 2**50*2048]))
+        cap = int(rng.choice([0, 0, 1, 7]))
+        length, count = segments(resident, frames, channels, warm, cap)
+        assert length % TILE == 0 and length >= TILE and count >= 1
+        assert count*length >= frames > (count - 1)*length
+        if cap:
+            assert count <= cap
+        if warm >= 2**40:
+            assert count == 1                                  # a filter that never forgets
+        # no other candidate the planner considers is cheaper
+        def cost(n):
+            ln = -(-(-(-frames//n))//TILE)*TILE
+            cnt = -(-frames//ln)
+            rounds = -(-channels*cnt//resident)
+            return rounds*(ln + (warm if cnt > 1 else 0))
+        assert cost(count) <= cost(1)
+
+
+def test_segment_planner_bench_configuration():
+    # BASELINE configs[2] on 256 CUs x 16 waves: 64 segments of 900 000 samples per channel
+    length, count = segments(256*16, 57_600_000, 64, 53248 + 4096)
+    assert count == 64 and length == -(-57_600_000//64//TILE)*TILE
+    # a short interactive slab is not cut below what the warm-up makes worthwhile
+    length, count = segments(256*16, 200_000, 2, 53248)
+    assert count*length >= 200_000 and length >= TILE
+    with pytest.raises(ValueError):
+        segments(0, 10, 1, 0)
