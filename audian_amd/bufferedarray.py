@@ -52,7 +52,9 @@ class BufferedArray(object):
         return self.buffer
 
     def _prepare_keep(self, a, b):
-        """Hook: frames [a, b) of the current buffer are about to be copied."""
+        """Hook: frames [a, b) of the current buffer are about to be copied.  Returns False when
+        the host copy of that range is not worth copying (a subclass keeps it elsewhere)."""
+        return True
 
     def _blank(self, nframes):
         return np.zeros((int(nframes),) + tuple(self.shape[1:]))
@@ -89,8 +91,8 @@ class BufferedArray(object):
             keep0 = keep1 = 0
         todo = []
         if keep1 > keep0:
-            self._prepare_keep(keep0 - old_off, keep1 - old_off)
-            new[keep0 - offset:keep1 - offset] = old[keep0 - old_off:keep1 - old_off]
+            if self._prepare_keep(keep0 - old_off, keep1 - old_off) is not False:
+                new[keep0 - offset:keep1 - offset] = old[keep0 - old_off:keep1 - old_off]
             if keep0 > offset:
                 todo.append((offset, keep0 - offset))
             if keep1 < offset + nframes:
@@ -159,8 +161,9 @@ class ArrayLoader(BufferedArray):
     with its ``buffer_time`` / ``back_time`` arguments."""
 
     def __init__(self, data, rate, buffer_time=60.0, back_time=20.0, unit='a.u.',
-                 ampl_max=1.0, verbose=0):
+                 ampl_max=1.0, verbose=0, view=False):
         super().__init__(verbose)
+        self.view = view          # buffer = a window onto `data` instead of a float64 copy of it
         data = np.asarray(data)
         if data.ndim == 1:
             data = data[:, None]
@@ -185,6 +188,16 @@ class ArrayLoader(BufferedArray):
 
     def load_buffer(self, offset, nframes, buffer):
         buffer[:, :] = self.data[offset:offset + nframes, :]
+
+    def move_buffer(self, offset, nframes):
+        if not self.view:
+            return BufferedArray.move_buffer(self, offset, nframes)
+        # the recording is in memory anyway: moving the buffer is re-slicing it
+        offset = int(max(0, offset))
+        nframes = int(max(0, min(nframes, self.frames - offset)))
+        self.buffer = self.data[offset:offset + nframes]
+        self.offset = offset
+        self.buffer_changed[:] = True
 
 
 class WavLoader(BufferedArray):

@@ -151,6 +151,7 @@ class BufferedData(BufferedArray):
     _dev_valid = ()
     _stale = ()
     _pending = None
+    _carry = None
     _ctx = None
 
     def __init__(self, name, source_name, tbefore=0, tafter=0, panel='none', panel_type='trace',
@@ -190,16 +191,23 @@ class BufferedData(BufferedArray):
         return self._hostbuf
 
     def _prepare_keep(self, a, b):
-        """Only the part of the host copy that survives a buffer move is read back."""
-        if self._stale:
-            keep = []
-            for r0, r1 in self._stale:
-                lo, hi = max(r0, a), min(r1, b)
-                if hi > lo:
-                    keep.append([lo, hi])
-            self._stale = keep
-            if keep:
-                self._flush()
+        """Frames [a, b) survive a buffer move.  When the device mirror holds them, nothing is
+        read back: the mirror is recycled on the device (_adopt_buffer) and what was stale on the
+        host simply stays stale at its new position -- a scroll then costs no PCIe traffic and no
+        host copy for results nobody has looked at.  Otherwise the stale part of the range is
+        read back now, before the old buffer goes away."""
+        self._carry = None
+        if not self._stale:
+            return True
+        inside = [[max(r0, a), min(r1, b)] for r0, r1 in self._stale if min(r1, b) > max(r0, a)]
+        if self._dev is not None and _covers(self._dev_valid, a, b):
+            self._carry = inside
+            self._stale = []                      # the old host buffer is about to be dropped
+            return not _covers(inside, a, b)      # all of it stale: no host copy at all
+        self._stale = inside
+        if inside:
+            self._flush()
+        return True
 
     @property
     def ctx(self):
@@ -275,7 +283,11 @@ class BufferedData(BufferedArray):
                             old_dev.view((keep0 - old_offset)*inner, (1,)), 4*old_nframes*inner,
                             4*(keep1 - keep0)*inner, self.channels)
             self._dev_valid = [[keep0 - offset, keep1 - offset]]
+            if self._carry:
+                shift = old_offset - offset
+                self._stale = _merge([[r0 + shift, r1 + shift] for r0, r1 in self._carry])
             self.ctx.synchronize()   # old mirror may be freed now
+        self._carry = None
         if old_dev is not None:
             old_dev.free()
 

@@ -132,6 +132,23 @@ def test_scroll_update_and_recompute_match_oracle_twins(oracle):
         g.update_times(t0, t1)
         o.update_times(t0, t1)
         compare(g, o)
+    # several moves with nothing read in between: what is stale on the host travels with the
+    # recycled mirror instead of being read back at every move ...
+    for t0, t1 in [(2.0, 4.0), (3.0, 5.0), (3.5, 6.0), (9.0, 11.0), (8.0, 10.0)]:
+        g.update_times(t0, t1)
+        o.update_times(t0, t1)
+    assert g['filtered']._stale and g['spectrogram']._stale
+    compare(g, o)
+    # ... also when a part of a buffer has been read (host current there, stale elsewhere)
+    for t0, t1 in [(20.0, 22.0), (21.0, 23.0)]:
+        g.update_times(t0, t1)
+        o.update_times(t0, t1)
+        f = g['filtered']
+        mid = f.offset + len(f.buffer)//2
+        assert np.array_equal(np.isfinite(f[mid:mid + 100, 0]), np.ones(100, dtype=bool))
+    g.update_times(22.5, 24.0)
+    o.update_times(22.5, 24.0)
+    compare(g, o)
     # interactive cut-off change: filter -> spectrogram -> envelope recomputed depth-first
     for hp, lp in [(1000.0, 5000.0), (0.0, 2000.0), (500.0, rate/2), (0.0, rate/2)]:
         for twin in (g, o):

@@ -15,14 +15,14 @@ class Item:
         return True
 
 
-rate, C, seconds = 192000.0, 16, 100.0
+rate, C, seconds = 192000.0, 16, 260.0
 rng = np.random.default_rng(1)
 x = rng.uniform(-1, 1, size=(int(rate*seconds), C)).astype(np.float32)
 g = TraceGraph(60.0, 20.0)
 for t in (BufferedFilter(), BufferedSpectrogram(nfft=2048), BufferedEnvelope(envelope_cutoff=500.0)):
     g.add_trace(t)
 g.setup_traces()
-g.open(x, rate)
+g.open(x, rate, view=os.environ.get('VIEW', '1') == '1')
 for t in g.traces:
     t.plot_items = [Item() for _ in range(t.channels)]
 g.set_need_update()
@@ -55,3 +55,16 @@ for i in range(5):
     mm = f.minmax_decimate(f.offset, f.offset + len(f.buffer), len(f.buffer)//2000, channel=0)
 dt = (time.perf_counter() - t0)/5
 print(f'  + the same with the image at screen resolution {img.shape}: {dt*1e3:.2f} ms', flush=True)
+
+# scrolling: the visible window moves by 5 s per step; every trace keeps the overlapping part of its
+# buffer and computes only what is new (plus the pre-roll the filters need)
+g.update_times(60.0, 70.0)
+f.ctx.synchronize()
+steps = 16
+off0 = g.data.offset
+t0 = time.perf_counter()
+for i in range(steps):
+    g.update_times(65.0 + 5.0*i, 75.0 + 5.0*i)
+f.ctx.synchronize()
+dt = (time.perf_counter() - t0)/steps
+print(f'scroll by 5 s: {dt*1e3:.2f} ms per step (raw buffer moved {(g.data.offset - off0)/rate:.0f} s in total)', flush=True)
