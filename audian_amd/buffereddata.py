@@ -106,6 +106,9 @@ class _LazyBuffer(object):
 
     def __getitem__(self, key):
         a, b = self._frames_of(key)
+        one = self._t._read_one_channel(key, a, b)
+        if one is not None:
+            return one
         self._t._flush_range(a, b)
         return self._t._hostbuf[key]
 
@@ -250,6 +253,40 @@ class BufferedData(BufferedArray):
                 hipdsp.unpack(self.ctx, src, pitch, tmp, n, self.channels)
                 self._hostbuf[a:b] = tmp.to_host()
             tmp.free()
+
+    def _read_one_channel(self, key, a, b):
+        """`buffer[frames, channel, ...]` as the plot items ask for it (traceitem.py:58-61,
+        specitem.py:36): in the planar device layout one channel's frames are contiguous, so only
+        they cross PCIe (float32) instead of every channel of the frame range (float64).  Returns
+        None when the access is of another kind or the host copy is current there anyway."""
+        if not (isinstance(key, tuple) and len(key) >= 2 and isinstance(key[1], (int, np.integer))):
+            return None
+        first, rest = key[0], key[2:]
+        if isinstance(first, slice):
+            step = first.indices(len(self._hostbuf))[2]
+            if step < 1:
+                return None
+        elif not isinstance(first, (int, np.integer)):
+            return None
+        if any(not isinstance(r, (int, np.integer, slice)) for r in rest) or len(rest) > self._hostbuf.ndim - 2:
+            return None
+        if b <= a or self._dev is None or not _covers(self._dev_valid, a, b):
+            return None
+        if not any(min(r1, b) > max(r0, a) for r0, r1 in self._stale):
+            return None                                   # nothing stale in there
+        ch = int(key[1])
+        if ch < 0:
+            ch += self.channels
+        if not 0 <= ch < self.channels:
+            return None                                   # let numpy raise its IndexError
+        inner, n = self._inner(), len(self._hostbuf)
+        block = self._dev.view((ch*n + a)*inner, ((b - a)*inner,)).to_host().astype(np.float64)
+        block = block.reshape((b - a,) + tuple(self._hostbuf.shape[2:]))
+        if isinstance(first, slice):
+            out = block[::step]
+            return out[(slice(None),) + tuple(rest)] if rest else out
+        out = block[0]
+        return out[tuple(rest)] if rest else out
 
     def _flush_range(self, a, b):
         """Read back only the stale parts of frames [a, b)."""

@@ -149,6 +149,23 @@ def test_scroll_update_and_recompute_match_oracle_twins(oracle):
     g.update_times(22.5, 24.0)
     o.update_times(22.5, 24.0)
     compare(g, o)
+    # per-channel reads as the plot items make them come straight from the planar mirror and
+    # leave the rest of the host copy stale; they equal what a full read-back gives
+    g.update_times(25.0, 27.0)
+    o.update_times(25.0, 27.0)
+    f, sp = g['filtered'], g['spectrogram']
+    assert f._stale and sp._stale
+    n, m = len(f.buffer), len(sp.buffer)
+    reads = [f.buffer[:, 1], f.buffer[10:n - 5, 0], f.buffer[3:900:7, 1], f.buffer[n//2, 1], f.buffer[-1, 0],
+             f[f.offset + 5:f.offset + 50, 1], sp.buffer[:, 1, :], sp.buffer[2:m - 1, 0, 5:9], sp.buffer[m//2, 1],
+             sp.buffer[1:m:3, 1, 7], sp.buffer[0, 0, -1]]
+    assert f._stale and sp._stale                     # nothing was flushed for them
+    fh, sh = np.array(f.buffer), np.array(sp.buffer)  # full read-back
+    want = [fh[:, 1], fh[10:n - 5, 0], fh[3:900:7, 1], fh[n//2, 1], fh[-1, 0], fh[5:50, 1], sh[:, 1, :],
+            sh[2:m - 1, 0, 5:9], sh[m//2, 1], sh[1:m:3, 1, 7], sh[0, 0, -1]]
+    for got, ref in zip(reads, want):
+        assert np.shape(got) == np.shape(ref) and np.array_equal(got, ref)
+    compare(g, o)
     # interactive cut-off change: filter -> spectrogram -> envelope recomputed depth-first
     for hp, lp in [(1000.0, 5000.0), (0.0, 2000.0), (500.0, rate/2), (0.0, rate/2)]:
         for twin in (g, o):
@@ -246,13 +263,18 @@ def test_chain_stays_on_the_device(oracle, monkeypatch):
     s = g['spectrogram']
     assert len(s.buffer) == len(s._hostbuf) and s.buffer.shape == s._hostbuf.shape   # no read-back
     assert counts['unpack_spectrum'] == 0
-    part = s.buffer[3:7, 1, :]                  # the display reads a few frames of one channel
-    assert counts['unpack_spectrum'] == 1 and s._stale == [[0, 3], [7, len(s._hostbuf)]]
+    part = s.buffer[3:7, 1, :]                  # the display reads a few frames of ONE channel:
+    assert counts['unpack_spectrum'] == 0 and s._stale == [[0, len(s._hostbuf)]]   # straight from the mirror
     assert part.shape == (4, s.shape[2])
+    some = s.buffer[3:7]                        # every channel of a few frames: that range is read back
+    assert counts['unpack_spectrum'] == 1 and s._stale == [[0, 3], [7, len(s._hostbuf)]]
+    assert np.array_equal(part, some[:, 1, :])
     _ = np.asarray(s.buffer)                    # ... or everything
     assert s._stale == [] and isinstance(s.buffer, np.ndarray)
-    _ = g['envelope'][g['envelope'].offset:g['envelope'].offset + 10, 0]
-    assert counts['unpack'] == 1
+    e = g['envelope']
+    one = e[e.offset:e.offset + 10, 0]
+    assert counts['unpack'] == 0
+    assert np.array_equal(one, e.buffer[0:10][:, 0]) and counts['unpack'] == 1
     # a loader that rewrites its buffer in place is noticed (fingerprint of the slab)
     g.data.buffer[::97, :] *= 0.5
     f.update()

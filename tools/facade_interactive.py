@@ -68,3 +68,19 @@ for i in range(steps):
 f.ctx.synchronize()
 dt = (time.perf_counter() - t0)/steps
 print(f'scroll by 5 s: {dt*1e3:.2f} ms per step (raw buffer moved {(g.data.offset - off0)/rate:.0f} s in total)', flush=True)
+
+# what audian's own plot items do, unchanged (specitem.py:36, traceitem.py:55-61): they slice one
+# channel out of the buffer -- which now crosses PCIe as that one channel only
+from audian_amd.bufferedspectrogram import decibel
+f.highpass_cutoff = 333.0
+f.update()
+t0 = time.perf_counter()
+img = decibel(s.buffer[:, 0, :].T)
+t1 = time.perf_counter()
+start, stop, step = f.offset, f.offset + len(f.buffer), len(f.buffer)//2000
+seg = np.arange(0, stop - start, step)
+col = f[start:stop, 0]
+lo, hi = np.minimum.reduceat(col, seg), np.maximum.reduceat(col, seg)
+t2 = time.perf_counter()
+print(f'reference plot code on one channel: spectrogram slab + decibel {1e3*(t1 - t0):.1f} ms, '
+      f'trace slice + reduceat {1e3*(t2 - t1):.1f} ms', flush=True)
