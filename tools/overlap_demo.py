@@ -39,15 +39,18 @@ def overlapped():
     A.wait_event(eS)
 
 
-for name, f in (('serial', serial), ('overlapped', overlapped), ('serial', serial), ('overlapped', overlapped)):
-    for _ in range(3):
-        f()
-    A.synchronize(); B.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(10):
-        f()
-    A.synchronize(); B.synchronize()
-    print(f'{name:11s} {(time.perf_counter() - t0)*100:.3f} ms/step', flush=True)
+for waves in [int(w) for w in os.environ.get('WAVES', '16,12,8').split(',')]:
+    A.set_option('sos_waves_per_cu', waves)
+    for name, f in (('serial', serial), ('overlapped', overlapped), ('serial', serial), ('overlapped', overlapped)):
+        for _ in range(3):
+            f()
+        A.synchronize(); B.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            f()
+        A.synchronize(); B.synchronize()
+        print(f'IIR waves/CU {waves:2d} {name:11s} {(time.perf_counter() - t0)*100:.3f} ms/step', flush=True)
+sys.exit(0)
 
 # ---- consecutive slabs pipelined: double-buffered filtered trace, three streams
 sC = A.create_stream()
