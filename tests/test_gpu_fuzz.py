@@ -207,3 +207,44 @@ def test_random_pitched_buffers(oracle, seed):
     for ch in range(C):
         assert rel_err(gy[ch, :T - skip], wy[:, ch]) < TOL
         assert np.all(gy[ch, T - skip:].view(np.uint32) == 0x7f7f7f7f)
+
+
+def test_bad_arguments_are_refused_not_launched():
+    """Every entry point checks its arguments on the host: an error status, never a faulting kernel."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    c = gh.ctx()
+    x = hipdsp.DeviceArray(c, (2, 5000), np.float32).zero_()
+    y = hipdsp.DeviceArray(c, (2, 5000), np.float32)
+    s = hipdsp.DeviceArray(c, (2, 40, 129), np.float32)
+    plan = hipdsp.SosPlan(c, butter_sos(2, 1000.0, 'lowpass', 48000.0))
+    for call in (
+            lambda: hipdsp.sosfilt(c, plan, x, 4000, y, 5000, 2, 5000, 0),          # pitch < frames
+            lambda: hipdsp.sosfilt(c, plan, x, 5000, y, 5000, 2, 5000, 5001),       # skip > frames
+            lambda: hipdsp.sosfilt(c, plan, x, 5000, y, 100, 2, 5000, 0),           # output pitch too small
+            lambda: hipdsp.sosfilt(c, plan, x, 5000, y, 5000, -1, 5000, 0),
+            lambda: hipdsp.envelope(c, plan, x, 5000, y, 5000, 2, 5000, -1),
+            lambda: hipdsp.envelope(c, plan, x, 5000, y, 5000, 2, 9, 0),            # not longer than padlen
+            lambda: hipdsp.spectrogram(c, x, 5000, 2, 5000, 4, 2, 48000.0, s, 40),  # nfft < 8
+            lambda: hipdsp.spectrogram(c, x, 5000, 2, 5000, 256, 0, 48000.0, s, 40),
+            lambda: hipdsp.spectrogram(c, x, 5000, 2, 5000, 256, 300, 48000.0, s, 40),   # hop > nfft
+            lambda: hipdsp.spectrogram(c, x, 5000, 2, 5000, 256, 128, -1.0, s, 40),
+            lambda: hipdsp.spectrogram(c, x, 100, 2, 5000, 256, 128, 48000.0, s, 40),    # pitch < frames
+            lambda: hipdsp.spectrogram(c, x, 5000, 2, 5000, 256, 128, 48000.0, s, 40, out_pitch=10),
+            lambda: hipdsp.minmax_decimate(c, x, 5000, 2, 10, 5, 3, y, 5000),       # stop < start
+            lambda: hipdsp.minmax_decimate(c, x, 5000, 2, 0, 5000, 0, y, 5000),     # step < 1
+            lambda: hipdsp.decibel_image_decimate(c, s, y, 40, 129, 0, 41, 2),
+            lambda: hipdsp.mean_spectrum_db(c, s, 129, 5, 5, y),                    # empty frame range
+            lambda: hipdsp.decibel(c, x, y, 100, ref_power=0.0),
+    ):
+        with pytest.raises((ValueError, IndexError)):
+            call()
+    with pytest.raises(NotImplementedError):
+        hipdsp.spectrogram(c, x, 5000, 2, 5000, 1 << 20, 1 << 19, 48000.0, s, 1)
+    with pytest.raises(NotImplementedError):
+        hipdsp.SosPlan(c, np.tile(butter_sos(2, 1000.0, 'lowpass', 48000.0), (5, 1)))
+    with pytest.raises(ValueError):
+        hipdsp.SosPlan(c, np.array([[1.0, 0.0, 0.0, 2.0, 0.0, 0.0]]))
+    c.synchronize()                                     # the context is still healthy
+    hipdsp.sosfilt(c, plan, x, 5000, y, 5000, 2, 5000, 0)
+    assert np.all(y.to_host() == 0)
