@@ -45,11 +45,13 @@ def parse():
     ap.add_argument('--lp', type=float, default=3000.0)
     ap.add_argument('--order', type=int, default=2)
     ap.add_argument('--env', type=float, default=20.0)
-    ap.add_argument('--tile-seconds', type=float, default=61.0,
-                    help='N>1: length of the spectrogram tile that is all-gathered: the resident '
-                         'buffer of the spectrogram trace, buffer_time 60 s + 11 s + 10 s of raw '
-                         'pre/post-roll minus the 10 s trimmed by the filter and the 10 s trimmed by '
-                         'the spectrogram in align_buffer (data.py:17,168; buffereddata.py:75-88)')
+    ap.add_argument('--tile-seconds', type=float, default=10.0,
+                    help='N>1: length of the spectrogram tile that is all-gathered every step: the visible '
+                         'window of the browser (10 s by default, plotranges.py:141-144) -- "gather only the '
+                         'visible tile when interactive" (SURVEY 7-6).  61 gathers the whole resident buffer '
+                         'of the spectrogram trace instead (buffer_time 60 s + 11 s + 10 s of raw pre/post-roll '
+                         'minus the 10 s + 10 s trimmed in align_buffer; data.py:17,168, buffereddata.py:75-88), '
+                         'which is xGMI-bound: 1.5 GB per rank and step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-seconds', type=float, default=60.0)
     ap.add_argument('--max-segments', type=int, default=0)
