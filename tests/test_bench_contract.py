@@ -1,0 +1,60 @@
+"""bench.py keeps the driver's contract: flags, defaults that finish within minutes, and (on a GPU)
+one JSON line with the required keys."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+REQUIRED = ['metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+            'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline']
+
+
+def test_flags_and_defaults():
+    sys.path.insert(0, ROOT)
+    import bench
+    argv, sys.argv = sys.argv, ['bench.py']
+    try:
+        a = bench.parse()
+    finally:
+        sys.argv = argv
+    assert (a.gpus, a.steps, a.warmup) == (1, 10, 3)
+    # BASELINE configs[2]
+    assert (a.channels, a.seconds, a.rate, a.nfft, a.hop) == (64, 600.0, 96000.0, 2048, 1024)
+    assert (a.hp, a.lp, a.order, a.env) == (300.0, 3000.0, 2, 20.0)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--help'], capture_output=True, text=True)
+    for flag in ('--gpus', '--steps', '--warmup'):
+        assert flag in out.stdout
+
+
+def test_n_gt_1_needs_a_launcher():
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True,
+                         text=True, env=env)
+    assert out.returncode != 0 and 'torch.distributed.run' in (out.stderr + out.stdout)
+
+
+@pytest.mark.gpu
+def test_one_json_line_with_the_contract_keys():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--seconds', '20', '--steps', '2',
+                          '--warmup', '1', '--cpu-sample-seconds', '1'], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in REQUIRED:
+        assert key in d, key
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['higher_is_better'] is True and d['scaling'] == 'weak'
+    assert d['unit'] == 'Msamples/s' and d['vs_baseline'] is None and 'workload' in d['config']
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+    assert abs(r['frac'] - r['achieved']/r['peak']) < 1e-3
+    c = d['cpu_baseline']
+    assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0
+    assert d['parity_max_rel_err'] < 1e-4 and 'invalid' not in d
