@@ -145,3 +145,63 @@ def test_block_cache_reuses_freed_blocks():
     c.set_option('pool_limit_mb', 0)
     assert c.pool_stats()[0] == 0
     c.pool_trim()
+
+
+def test_live_sliding_window_in_captured_graphs(oracle):
+    """configs[4] with live data: per frame a chunk of 16-bit PCM is appended to the resident window
+    (slide into the other of two windows + hipdsp_pcm_unpack, both captured) and the chain is
+    recomputed; the window and the results equal a from-scratch evaluation of the last T samples."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rate, C, T, chunk, nfft, hop = 48000.0, 3, 8192, 500, 256, 128
+    ctx = hipdsp.Context(0)
+    ctx.set_stream(ctx.create_stream())
+    rng = np.random.default_rng(12)
+    stream_pcm = (rng.standard_normal((T + 7*chunk, C))*4000).astype(np.int16)     # (frames, channels)
+    as_float = stream_pcm.astype(np.float64)/32768
+    win = [hipdsp.DeviceArray.from_host(ctx, np.ascontiguousarray(as_float[:T].T, dtype=np.float32)),
+           hipdsp.DeviceArray(ctx, (C, T), np.float32)]
+    staging = hipdsp.DeviceArray(ctx, (chunk, C), np.int16)
+    df = hipdsp.DeviceArray(ctx, (C, T), np.float32)
+    de = hipdsp.DeviceArray(ctx, (C, T), np.float32)
+    nd = (T + hop - 1)//hop
+    ds = hipdsp.DeviceArray(ctx, (C, nd, nfft//2 + 1), np.float32)
+    sos, esos = butter_sos(2, (300.0, 3000.0), 'bandpass', rate), butter_sos(2, 200.0, 'lowpass', rate)
+    plan, eplan = hipdsp.SosPlan(ctx, sos), hipdsp.SosPlan(ctx, esos)
+
+    def live(k):
+        src, dst = win[k], win[1 - k]
+        hipdsp.memcpy2d(ctx, dst, 4*T, src.view(chunk, (1,)), 4*T, 4*(T - chunk), C)
+        hipdsp.pcm_unpack(ctx, staging, 2, chunk, C, 1.0/32768, dst.view(T - chunk, (1,)), T)
+        hipdsp.sosfilt(ctx, plan, dst, T, df, T, C, T, 0)
+        hipdsp.spectrogram(ctx, df, T, C, T, nfft, hop, rate, ds, nd)
+        hipdsp.envelope(ctx, eplan, df, T, de, T, C, T, 0)
+
+    # warm up on scratch copies of the windows so that the real ones are untouched, then capture
+    keep = win[0].to_host()
+    graphs = []
+    for k in (0, 1):
+        live(k)
+        ctx.synchronize()
+        ctx.graph_begin()
+        live(k)
+        graphs.append(ctx.graph_end())
+    hipdsp.lib.hipdsp_memcpy_h2d(ctx.handle, hipdsp._p(win[0]), keep.ctypes.data, keep.nbytes)
+    ctx.synchronize()
+    for i in range(7):
+        part = np.ascontiguousarray(stream_pcm[T + i*chunk:T + (i + 1)*chunk])
+        hipdsp.lib.hipdsp_memcpy_h2d(ctx.handle, hipdsp._p(staging), part.ctypes.data, part.nbytes)
+        ctx.graph_launch(graphs[i % 2])
+        ctx.synchronize()
+        now = win[(i + 1) % 2].to_host()
+        want = as_float[(i + 1)*chunk:(i + 1)*chunk + T]
+        assert np.array_equal(now, want.T.astype(np.float32)), i
+    x = want
+    wf = oracle.sosfilt(sos, x)
+    gf, ge = df.to_host(), de.to_host()
+    we = np.zeros_like(wf)
+    oracle.envelope_process(esos, gf.T.astype(np.float64), we, 0)
+    for ch in range(C):
+        assert rel_err(gf[ch], wf[:, ch]) < 1e-4 and rel_err(ge[ch], we[:, ch]) < 1e-4
+    for g in graphs:
+        ctx.graph_destroy(g)
