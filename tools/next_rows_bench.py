@@ -45,6 +45,11 @@ top = hipdsp.DeviceArray(ctx, (1,), np.float32)
 timeit('max reduction 7500 x 1025', lambda: hipdsp.max_nonneg(ctx, spec, frames*F, top), 4.0*frames*F)
 img = hipdsp.DeviceArray(ctx, (F, frames), np.float32)
 timeit('decibel image 7500 x 1025 -> (F, T)', lambda: hipdsp.decibel_image(ctx, spec, img, frames, F), 8.0*frames*F)
+for step in (4, 28):
+    ncols = (frames + step - 1)//step
+    small = hipdsp.DeviceArray(ctx, (F, ncols), np.float32)
+    timeit(f'decibel image 7500 x 1025 -> (F, {ncols}), max over {step} frames',
+           lambda: hipdsp.decibel_image_decimate(ctx, spec, small, frames, F, 0, frames, step), 4.0*frames*F + 4.0*ncols*F)
 # PCM ingest: 64 ch x 60 s int16
 Tp = int(60*rate)
 pcm = hipdsp.DeviceArray(ctx, (Tp, C), np.int16)
