@@ -44,6 +44,56 @@ __global__ __launch_bounds__(256) void copy_segments_wg(const float4 *__restrict
     }
 }
 
+// (b') like (b) with non-temporal loads and/or stores (streaming data is touched once)
+template <bool NTL, bool NTS>
+__global__ __launch_bounds__(64) void copy_segments_nt(const float4 *__restrict__ in, float4 *__restrict__ out,
+                                                       long long seg4, long long n4)
+{
+    long long base = (long long)blockIdx.x * seg4;
+    long long end = base + seg4 < n4 ? base + seg4 : n4;
+    for (long long t = base; t < end; t += 512) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float4 *p = in + t + 64 * k + threadIdx.x;
+            if (NTL) {
+                v[k].x = __builtin_nontemporal_load(&p->x); v[k].y = __builtin_nontemporal_load(&p->y);
+                v[k].z = __builtin_nontemporal_load(&p->z); v[k].w = __builtin_nontemporal_load(&p->w);
+            } else {
+                v[k] = *p;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            float4 *q = out + t + 64 * k + threadIdx.x;
+            if (NTS) {
+                __builtin_nontemporal_store(v[k].x, &q->x); __builtin_nontemporal_store(v[k].y, &q->y);
+                __builtin_nontemporal_store(v[k].z, &q->z); __builtin_nontemporal_store(v[k].w, &q->w);
+            } else {
+                *q = v[k];
+            }
+        }
+    }
+}
+
+// (b'') like (b) but walking the segment from its end to its start (the envelope's backward sweep)
+template <bool BACKWARD>
+__global__ __launch_bounds__(64) void copy_segments_dir(const float4 *__restrict__ in, float4 *__restrict__ out,
+                                                        long long seg4, long long n4)
+{
+    const long long base = (long long)blockIdx.x * seg4;
+    const long long end = base + seg4 < n4 ? base + seg4 : n4;
+    const long long tiles = (end - base) / 512;
+    float4 v[8];
+    for (long long i = 0; i < tiles; i++) {
+        const long long t = base + (BACKWARD ? tiles - 1 - i : i) * 512;
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = in[t + 64 * k + threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < 8; k++) out[t + 64 * k + threadIdx.x] = v[k];
+    }
+}
+
 // (d) read-only: each wave sums its segment (read ceiling)
 __global__ __launch_bounds__(64) void read_segments(const float4 *__restrict__ in, float *__restrict__ out,
                                                     long long seg4, long long n4)
@@ -88,6 +138,22 @@ int main()
         int nb = (int)((n4 + seg4 - 1) / seg4);
         float ms = timeit([&] { hipLaunchKernelGGL(copy_segments, dim3(nb), dim3(64), 0, 0, in, out, seg4, n4); }, 5);
         printf("copy_segments   waves %6d: %.3f ms %.0f GB/s\n", nb, ms, gb / ms * 1e3);
+    }
+    {
+        long long seg4 = (n4 / 4096 + 511) / 512 * 512;
+        int nb = (int)((n4 + seg4 - 1) / seg4);
+        float ms = timeit([&] { hipLaunchKernelGGL((copy_segments_nt<false, true>), dim3(nb), dim3(64), 0, 0, in, out, seg4, n4); }, 5);
+        printf("copy_segments nt stores        : %.3f ms %.0f GB/s\n", ms, gb / ms * 1e3);
+        ms = timeit([&] { hipLaunchKernelGGL((copy_segments_nt<true, false>), dim3(nb), dim3(64), 0, 0, in, out, seg4, n4); }, 5);
+        printf("copy_segments nt loads         : %.3f ms %.0f GB/s\n", ms, gb / ms * 1e3);
+        ms = timeit([&] { hipLaunchKernelGGL((copy_segments_nt<true, true>), dim3(nb), dim3(64), 0, 0, in, out, seg4, n4); }, 5);
+        printf("copy_segments nt loads + stores: %.3f ms %.0f GB/s\n", ms, gb / ms * 1e3);
+    }
+    for (int waves : {2048, 4096}) {
+        long long seg4 = (n4 / waves + 511) / 512 * 512;
+        int nb = (int)((n4 + seg4 - 1) / seg4);
+        float ms = timeit([&] { hipLaunchKernelGGL((copy_segments_dir<true>), dim3(nb), dim3(64), 0, 0, in, out, seg4, n4); }, 5);
+        printf("copy_segments backward waves %5d: %.3f ms %.0f GB/s\n", nb, ms, gb / ms * 1e3);
     }
     for (int wgs : {1024, 2048, 4096}) {
         long long seg4 = (n4 / wgs + 2047) / 2048 * 2048;
