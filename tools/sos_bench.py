@@ -20,7 +20,7 @@ def run(C, seconds, rate, what, **kw):
     else:
         plan = hipdsp.SosPlan(ctx, butter_sos(2, kw.get('env', 20.0), 'lowpass', rate))
         f = lambda: hipdsp.envelope(ctx, plan, dx, T, dy, T, C, T, 0)
-        nbytes = 16.0*C*T
+        nbytes = 12.0*C*T          # state sweep 4 B + backward sweep 8 B per sample
     for _ in range(2):
         f()
     ctx.record(e0)

@@ -15,7 +15,7 @@ eplan = hipdsp.SosPlan(ctx, butter_sos(2, 20.0, 'lowpass', rate))
 for w in (8, 12, 16, 20, 24, 32, 40):
     ctx.set_option('sos_waves_per_cu', w)
     for name, f, nb in (('filt', lambda: hipdsp.sosfilt(ctx, plan, dx, T, dy, T, C, T, 0), 8.0*C*T),
-                        ('env', lambda: hipdsp.envelope(ctx, eplan, dx, T, dy, T, C, T, 0), 16.0*C*T)):
+                        ('env', lambda: hipdsp.envelope(ctx, eplan, dx, T, dy, T, C, T, 0), 12.0*C*T)):
         f(); f()
         ctx.record(e0)
         for _ in range(5): f()
