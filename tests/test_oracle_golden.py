@@ -102,3 +102,51 @@ def test_chain_process_bodies(oracle):
     assert np.array_equal(d2, x[5:])
     oracle.envelope_process(None, x, env, 0)
     assert np.all(env == 0)
+
+
+def _scipy_signal():
+    import pytest
+    return pytest.importorskip('scipy.signal')
+
+
+def test_oracle_against_live_scipy_random_cases(oracle):
+    """Beyond the committed vectors: where scipy is installed (this image has it; the GPU box too),
+    the oracle is re-checked against scipy itself on random designs, lengths and window
+    parameters -- the reference's own calls (bufferedfilter.py:36, bufferedenvelope.py:39,
+    bufferedspectrogram.py:51-56 through thunderlab)."""
+    import numpy as np
+    sig = _scipy_signal()
+    rng = np.random.default_rng(2024)
+    for _ in range(25):
+        rate = float(rng.choice([8000.0, 44100.0, 96000.0, 192000.0]))
+        order = int(rng.integers(1, 5))
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            sos = sig.butter(order, float(rng.uniform(5, 0.4*rate)), 'lowpass', fs=rate, output='sos')
+        elif kind == 1:
+            sos = sig.butter(order, float(rng.uniform(20, 0.3*rate)), 'highpass', fs=rate, output='sos')
+        else:
+            lo = float(rng.uniform(20, 0.1*rate))
+            sos = sig.butter(min(order, 2), (lo, float(rng.uniform(2*lo, 0.45*rate))), 'bandpass', fs=rate, output='sos')
+        n = int(rng.integers(40, 6000))
+        x = rng.standard_normal((n, 2))
+        want = np.column_stack([sig.sosfilt(sos, x[:, c]) for c in range(2)])
+        assert np.allclose(oracle.sosfilt(sos, x), want, rtol=1e-12, atol=1e-14)
+        assert np.allclose(oracle.sosfilt_zi(sos), sig.sosfilt_zi(sos), rtol=1e-12, atol=1e-15)
+        if n > oracle.sosfiltfilt_edge(sos):
+            r = (np.pi/2)*np.abs(x)
+            want = sig.sosfiltfilt(sos, r, axis=0)
+            got = oracle.sosfiltfilt(sos, r)
+            assert np.max(np.abs(got - want)) <= 1e-9*max(1.0, np.max(np.abs(want)))
+    for _ in range(15):
+        rate = float(rng.choice([22050.0, 96000.0]))
+        nfft = int(rng.choice([8, 64, 256, 300, 1024, 2048]))
+        hop = int(rng.integers(1, nfft + 1))
+        n = nfft + int(rng.integers(0, 9*nfft))
+        x = rng.standard_normal((n, 2)) + 0.2
+        f, t, S = sig.spectrogram(x, fs=rate, window='hann', nperseg=nfft, noverlap=nfft - hop, detrend='constant',
+                                  scaling='density', mode='psd', axis=0)
+        want = np.transpose(S, (0, 2, 1))                    # thunderlab's (F, T, C)
+        fo, to, So = oracle.spectrogram(x, rate, nfft, nfft - hop)
+        assert So.shape == want.shape and np.allclose(fo, f)
+        assert np.max(np.abs(So - want)) <= 1e-10*np.max(np.abs(want))
