@@ -173,7 +173,8 @@ def test_spectrogram_golden():
 
 
 @pytest.mark.parametrize('nfft,hop', [(256, 128), (256, 37), (512, 256), (512, 128), (1024, 256),
-                                      (2048, 1024), (2048, 512), (4096, 2048), (128, 64), (8192, 4096)])
+                                      (2048, 1024), (2048, 512), (4096, 2048), (128, 64), (8192, 4096), (128, 17), (64, 32),
+                                      (64, 64), (32, 16), (32, 5), (16, 8), (8, 4)])
 def test_spectrogram_fast_and_generic_vs_oracle(oracle, nfft, hop):
     """Every supported size through its own kernel and through the generic radix-2 kernel."""
     rng = np.random.default_rng(nfft + hop)
