@@ -232,7 +232,7 @@ __device__ __forceinline__ void asm_load8(v2f &r, const float *p, int imm)
 //   and writes out[(j/NS)*NS*R + k + t*NS].
 // `tw` is this stage's own table, tw[(t-1)*NS + k] = exp(-2 pi i k t / (NS R)): lanes
 // with consecutive k read consecutive entries (no LDS bank conflicts).
-template <int R, int NS, int M, int LPF, bool LOAD, bool STORE, bool POWERS = false>
+template <int R, int NS, int M, int LPF, bool LOAD, bool STORE, bool POWERS = false, bool COMPUTE = true>
 __device__ __forceinline__ void stockham_stage(float2 *v, float2 *fb, const float2 *tw, int l)
 {
     constexpr int PPL = M / LPF;
@@ -256,7 +256,7 @@ __device__ __forceinline__ void stockham_stage(float2 *v, float2 *fb, const floa
             }
     }
 #pragma unroll
-    for (int u = 0; u < NB; u++) {
+    for (int u = 0; u < (COMPUTE ? NB : 0); u++) {
         const int j = l + LPF * u;
         float2 *b = v + u * R;
         if (NS > 1) {
@@ -709,6 +709,124 @@ __global__ __launch_bounds__(64 * WAVES) void spec2_kernel(
     }
 }
 
+// ---- workgroup path: nfft 8192, 16384 and 32768 ------------------------------------------
+// One frame per workgroup of LPF = 256 or 512 threads at a time: the same three Stockham stages
+// as spec_fast_kernel with LPF "lanes" (16 or 32 points per thread), so the exchanges cross
+// waves and every stage boundary is a workgroup barrier; a stage that loads AND stores needs one
+// between the two as well (the exchange is in place).  The partner bin of the split step lives in
+// another wave, so the transform takes one more trip through LDS in natural order.  Window and
+// split twiddles stay in global memory (L2): with them in LDS only one workgroup would fit.
+template <int NFFT, int LPF, int R1, int R2, int R3, int OCC, bool DB>
+__global__ __launch_bounds__(LPF, OCC) void spec_wg_kernel(
+    const float *__restrict__ x, long long x_pitch, long long n_valid, long long frames_out,
+    long long out_pitch, int hop, float scale, const float *__restrict__ tables, float *__restrict__ out,
+    float *__restrict__ db_out, int frames_per_block)
+{
+    constexpr int M = NFFT / 2;
+    constexpr int PPL = M / LPF;
+    constexpr int F = M + 1;
+    constexpr int MP = M + M / 16;
+    static_assert(R1 * R2 * R3 == M, "radices must multiply to M");
+    static_assert(PPL % R1 == 0 && PPL % R2 == 0 && PPL == R3, "one stage-3 butterfly per thread");
+    constexpr int TW2 = (R2 - 1) * R1;
+    constexpr int TW3 = R1 * R2;
+    constexpr int TWN = M / 2 + 1;
+    __shared__ float2 smem[TW2 + TW3 + MP];
+    __shared__ float red[LPF / 64];
+    const float2 *tw2 = smem;
+    const float2 *tw3 = smem + TW2;
+    float2 *fb = smem + TW2 + TW3;
+    const float2 *gtab = reinterpret_cast<const float2 *>(tables);
+    const float2 *twn = gtab + TW2 + TW3;
+    const float2 *win = twn + TWN;
+    const int l = threadIdx.x;
+    const int wave = l >> 6;
+    for (int i = l; i < TW2 + TW3; i += LPF) smem[i] = gtab[i];
+    __syncthreads();
+
+    const long long ch = blockIdx.y;
+    const float *xc = x + ch * x_pitch;
+    for (int it = 0; it < frames_per_block; it++) {
+        const long long frame = (long long)blockIdx.x * frames_per_block + it;   // workgroup-uniform
+        if (frame >= frames_out) break;
+        const long long obase = ch * out_pitch + frame * (long long)F;
+        if (frame >= n_valid) {                              // zero tail (bufferedspectrogram.py:59)
+            for (int f = l; f < F; f += LPF) {
+                out[obase + f] = 0.f;
+                if (DB) db_out[obase + f] = -INFINITY;
+            }
+            continue;
+        }
+        const float *seg = xc + frame * (long long)hop;
+        float2 v[PPL];
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < PPL / R1; u++)
+#pragma unroll
+            for (int t = 0; t < R1; t++) {
+                const int n = l + LPF * u + t * (M / R1);
+                const f2u r = *reinterpret_cast<const f2u *>(seg + 2 * n);
+                v[u * R1 + t] = make_float2(r.x, r.y);
+                s += r.x + r.y;
+            }
+        s = wave_sum(s);
+        if ((l & 63) == 0) red[wave] = s;
+        __syncthreads();          // also: the previous frame's partner reads of fb are done
+        float total = 0.f;
+#pragma unroll
+        for (int w = 0; w < LPF / 64; w++) total += red[w];
+        const float mean = total * (1.0f / (float)NFFT);
+#pragma unroll
+        for (int u = 0; u < PPL / R1; u++)
+#pragma unroll
+            for (int t = 0; t < R1; t++) {
+                const float2 w = win[l + LPF * u + t * (M / R1)];
+                float2 &e = v[u * R1 + t];
+                e = make_float2((e.x - mean) * w.x, (e.y - mean) * w.y);
+            }
+        stockham_stage<R1, 1, M, LPF, false, true>(v, fb, tw2, l);
+        __syncthreads();
+        stockham_stage<R2, R1, M, LPF, true, false>(v, fb, tw2, l);
+        __syncthreads();
+        stockham_stage<R2, R1, M, LPF, false, true, false, false>(v, fb, tw2, l);
+        __syncthreads();
+        stockham_stage<R3, R1 * R2, M, LPF, true, false, true>(v, fb, tw3, l);
+        __syncthreads();
+        // v[m] = Z[k], k = l + LPF m; natural order into LDS for the partner bins Z[M-k]
+#pragma unroll
+        for (int m = 0; m < PPL; m++) fb[pad16(l) + LPF * m + LPF * m / 16] = v[m];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < PPL / 2; m++) {
+            const int k = l + LPF * m;
+            const float2 zk = v[m];
+            const float2 zm = fb[pad16((M - k) & (M - 1))];
+            float pk, pm;
+            if (m == 0 && l == 0) {
+                const float a = zk.x + zk.y, b = zk.x - zk.y;    // DC and Nyquist, not doubled
+                pk = a * a * scale;
+                pm = b * b * scale;
+            } else {
+                const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+                const float2 o = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
+                const float2 t = cmul(o, twn[k]);
+                const float2 a = cadd(e, t), b = csub(e, t);
+                pk = 2.f * scale * (a.x * a.x + a.y * a.y);
+                pm = 2.f * scale * (b.x * b.x + b.y * b.y);
+            }
+            out[obase + k] = pk;
+            out[obase + M - k] = pm;
+            if (DB) { db_out[obase + k] = to_db(pk); db_out[obase + M - k] = to_db(pm); }
+        }
+        if (l == 0) {                                        // k = M/2 pairs with itself
+            const float2 z = v[PPL / 2];
+            const float p = 2.f * scale * (z.x * z.x + z.y * z.y);
+            out[obase + M / 2] = p;
+            if (DB) db_out[obase + M / 2] = to_db(p);
+        }
+    }
+}
+
 // ---- direct path: any nfft that is not a power of two ---------------------------------
 // The reference clamps nfft to len(source)//2 (bufferedspectrogram.py:88-90), which on a short
 // recording yields a non power of two.  Rare and small, so a plain O(nfft^2) DFT does: one
@@ -1135,6 +1253,27 @@ int run_fast(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long chann
                                                      hop, scale, tables, out, db_out);
 }
 
+template <int NFFT, int LPF, int R1, int R2, int R3, int OCC>
+int run_wg(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long channels, long long n_valid,
+           long long frames_out, long long out_pitch, int hop, float scale, float *out, float *db_out)
+{
+    const float *tables = nullptr;
+    int rc = fft_tables(ctx, NFFT, R1, R2, R3, &tables);
+    if (rc != HIPDSP_OK) return rc;
+    // a few frames per workgroup once there are many more frames than the chip holds workgroups
+    long long fpb = frames_out * channels / ((long long)ctx->n_cus * 8);
+    if (fpb < 1) fpb = 1;
+    if (fpb > 8) fpb = 8;
+    const dim3 grid((unsigned)((frames_out + fpb - 1) / fpb), (unsigned)channels);
+    if (db_out)
+        hipLaunchKernelGGL((spec_wg_kernel<NFFT, LPF, R1, R2, R3, OCC, true>), grid, dim3(LPF), 0, ctx->stream, x, x_pitch,
+                           n_valid, frames_out, out_pitch, hop, scale, tables, out, db_out, (int)fpb);
+    else
+        hipLaunchKernelGGL((spec_wg_kernel<NFFT, LPF, R1, R2, R3, OCC, false>), grid, dim3(LPF), 0, ctx->stream, x, x_pitch,
+                           n_valid, frames_out, out_pitch, hop, scale, tables, out, db_out, (int)fpb);
+    return hd_launch_status("spec_wg_kernel");
+}
+
 }  // namespace
 
 extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, int64_t channels,
@@ -1204,6 +1343,12 @@ extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pit
             return run_fast<4096, 64, 16, 16, 8, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
         }
     }
+    if (!ctx->force_generic_fft && nfft == 8192)
+        return run_wg<8192, 256, 16, 16, 16, 3>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+    if (!ctx->force_generic_fft && nfft == 16384)
+        return run_wg<16384, 256, 16, 16, 32, 2>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+    if (!ctx->force_generic_fft && nfft == 32768)
+        return run_wg<32768, 512, 16, 32, 32, 2>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
     if (nfft > 8192)
         return run_big(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, nfft, hop, scale, out, db_out);
     size_t lds = sizeof(float2) * 2 * (size_t)nfft;

@@ -174,12 +174,13 @@ def test_spectrogram_golden():
 
 @pytest.mark.parametrize('nfft,hop', [(256, 128), (256, 37), (512, 256), (512, 128), (1024, 256),
                                       (2048, 1024), (2048, 512), (4096, 2048), (128, 64), (8192, 4096), (128, 17), (64, 32),
-                                      (64, 64), (32, 16), (32, 5), (16, 8), (8, 4)])
+                                      (64, 64), (32, 16), (32, 5), (16, 8), (8, 4), (8192, 1000), (16384, 8192),
+                                      (16384, 3000), (32768, 16384)])
 def test_spectrogram_fast_and_generic_vs_oracle(oracle, nfft, hop):
     """Every supported size through its own kernel and through the generic radix-2 kernel."""
     rng = np.random.default_rng(nfft + hop)
     rate = 96000.0
-    nframes = 70
+    nframes = 70 if nfft < 8192 else 11
     T = (nframes - 1)*hop + nfft + 5
     x = (synth(rng, T, 3, rate) + np.float32(0.1)).astype(np.float32)
     nd = (T + hop - 1)//hop
@@ -362,11 +363,12 @@ def test_decimated_db_image(oracle, frames, F, start, stop, step):
         hipdsp.decibel_image_decimate(c, ds, img, frames, F, 0, frames + 1, step)
 
 
-@pytest.mark.parametrize('nfft,hop,nframes', [(16384, 8192, 5), (32768, 4096, 4), (65536, 16384, 3),
+@pytest.mark.parametrize('nfft,hop,nframes', [(8192, 2048, 6), (16384, 8192, 5), (32768, 4096, 4), (65536, 16384, 3),
                                               (262144, 131072, 3), (524288, 262144, 2)])
 def test_spectrogram_large_nfft_four_step(oracle, nfft, hop, nframes):
-    """The upper part of the reference's nfft selector (2^14 .. 2^19, databrowser.py:516):
-    four-step FFT through the context scratch, with a zero tail and the fused dB output."""
+    """The upper part of the reference's nfft selector (2^13 .. 2^19, databrowser.py:516):
+    workgroup FFT (8192, 16384) and four-step FFT through the context scratch (larger), with a
+    zero tail and the fused dB output."""
     rng = np.random.default_rng(nfft)
     rate = 96000.0
     T = (nframes - 1)*hop + nfft + 3
