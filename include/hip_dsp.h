@@ -65,7 +65,7 @@ int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
  *   "sos_waves_per_cu"   resident waves per CU the IIR segment planner aims for (16)
  *   "pool_limit_mb"      bytes (MiB) hipdsp_free may keep cached for hipdsp_malloc (1024)
  *   "sos_prefetch"       0: envelope sweeps without the register prefetch of the next tile (1)
- *   "force_generic_fft"  non-zero: every nfft takes the generic radix-2 spectrogram kernel
+ *   "force_generic_fft"  non-zero: every nfft takes the generic radix-2 / four-step kernels
  *   "spec_kernel"        0 = default per size, 2 = two-stage, 3 = three-stage FFT kernel
  *   "spec_fpw"           consecutive frames per wave (0 = automatic)
  *   "spec_no_half"       non-zero: do not reuse the overlapped half frame at 50 % overlap */
@@ -217,7 +217,7 @@ int hipdsp_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const float *x,
  * phase: 0 = both sweeps; 1 = forward sweep only (yf complete, states parked in the context
  * scratch); 2 = backward sweep only (env from yf and those states) -- so that other work on yf
  * (the spectrogram) can be enqueued in between; no call that uses the scratch of THIS context
- * (envelope, nfft > 8192, mean_spectrum_db) may come between phase 1 and phase 2. */
+ * (envelope, nfft > 32768, mean_spectrum_db) may come between phase 1 and phase 2. */
 int hipdsp_sosfilt_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan,
                             const hipdsp_sosplan *eplan, const float *x, int64_t x_pitch,
                             float *yf, int64_t yf_pitch, float *env, int64_t env_pitch,
@@ -235,7 +235,7 @@ int hipdsp_sosfilt_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan,
  * elements between consecutive channels (0 = compact, frames_out*(nfft/2 + 1)).
  * If db_out != NULL it additionally receives decibel(out) (fused epilogue,
  * specitem.py:36) in the same layout.  nfft: any power of two in [8, 524288] (the reference's
- * nfft selector, databrowser.py:516; above 8192 a four-step FFT over the context scratch)
+ * nfft selector, databrowser.py:516; above 32768 a four-step FFT over the context scratch)
  * and, for the values the reference's clamp to len(source)//2 can produce, any other size up
  * to 131072 (direct DFT, O(nfft^2), meant for the rare short recording). */
 int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, int64_t channels,
