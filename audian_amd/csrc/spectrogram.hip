@@ -1319,11 +1319,14 @@ extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pit
                            scale, out, db_out);
         return hd_launch_status("spec_direct_kernel");
     }
-    if (!ctx->force_generic_fft && nfft >= 32 && nfft <= 4096) {
+    if (!ctx->force_generic_fft && nfft <= 4096) {
         // spec_kernel: 0 = default choice per size, 2 = two-stage kernel, 3 = three-stage kernel
         const int want = ctx->spec_kernel;
         switch (nfft) {
-        // short windows: 32, 16 or 8 frames side by side in a wave (two-stage kernel)
+        // short windows: 64 (one frame per lane), 32, 16 or 8 frames side by side in a wave
+        // (two-stage kernel)
+        case 8: return run_fast2<8, 1, 2, 2, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+        case 16: return run_fast2<16, 1, 4, 2, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
         case 32: return run_fast2<32, 2, 8, 2, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
         case 64: return run_fast2<64, 4, 8, 4, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
         case 128: return run_fast2<128, 8, 8, 8, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);

@@ -106,18 +106,19 @@ def test_random_filter_envelope_chain_cases(oracle, seed):
 
 @pytest.mark.parametrize('seed', range(20))
 def test_random_spectrogram_cases(oracle, seed):
-    """Random window length (every kernel family: generic, two- and three-stage, direct DFT), hop,
+    """Random window length (every kernel family: generic, two- and three-stage, workgroup, four-step,
+    direct DFT), hop,
     slab length and destination length, incl. destinations longer than the source supports (zero
     tail) and shorter (fewer frames than fit)."""
     rng = np.random.default_rng(9000 + seed)
     rate = float(rng.choice([22050.0, 96000.0]))
     family = rng.integers(0, 4)
     if family == 0:
-        nfft = int(2**rng.integers(3, 8))                 # generic radix-2 kernel
+        nfft = int(2**rng.integers(3, 8))                 # generic radix-2 (8, 16), short two-stage kernels
     elif family == 1:
         nfft = int(2**rng.integers(8, 13))                # register/LDS kernels
     elif family == 2:
-        nfft = int(rng.choice([8192, 16384]))
+        nfft = int(rng.choice([8192, 16384, 32768, 65536]))   # workgroup FFT, four-step FFT
     else:
         nfft = int(rng.integers(9, 600))                  # whatever the clamp can produce
     hop = int(rng.choice([nfft//2, max(nfft//4, 1), nfft, int(rng.integers(1, nfft + 1))]))
