@@ -17,7 +17,8 @@ __device__ __forceinline__ float to_db(float p)
 }
 
 // ---- generic path: any power-of-two nfft in [8, 8192] ---------------------------
-// One 256-thread workgroup per (frame, channel); radix-2 Stockham autosort in LDS.
+// One 256-thread workgroup per (frame, channel); radix-2 Stockham autosort in LDS.  Every size
+// has a faster kernel below; this one stays as their in-tree cross-check ("force_generic_fft").
 __global__ __launch_bounds__(256) void spec_generic_kernel(
     const float *__restrict__ x, long long x_pitch, long long n_valid, long long frames_out,
     long long out_pitch, int nfft, int hop, float scale, float *__restrict__ out,
@@ -85,8 +86,8 @@ __global__ __launch_bounds__(256) void spec_generic_kernel(
 // stages go through a per-frame LDS buffer and need no barrier because the whole frame
 // lives in one wave (LDS operations of a wave execute in order).  Stage 1 reads the
 // samples straight from HBM (8 B per lane, contiguous over lanes), subtracts the frame
-// mean and applies the register-resident Hann window.  Twiddles come from LDS tables
-// computed on the host in float64.
+// mean and applies the LDS-staged Hann window.  Twiddles come from LDS tables computed on
+// the host in float64.
 
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 
@@ -900,7 +901,7 @@ __global__ __launch_bounds__(256) void spec_direct_kernel(
 //   P2  for each k1: FFT over n2 of B[k1][.]                  -> Z[k1 + N1*k2]
 //   P3  split step + PSD scaling (+ dB)                       -> out
 // Twiddles come from sincospif on exact dyadic arguments.  This path is about coverage of the
-// reference's parameter range, not about the roofline: it moves ~4x the minimal bytes.
+// reference's parameter range, not about the roofline: it moves ~6x the algorithmic bytes.
 
 constexpr int BIG_W = 16;                 // sub-transforms per workgroup
 
@@ -912,8 +913,16 @@ __global__ __launch_bounds__(256) void big_mean_kernel(const float *__restrict__
     const long long item = item0 + blockIdx.x;
     const long long ch = item / frames_valid, frame = item % frames_valid;
     const float *seg = x + ch * x_pitch + frame * (long long)hop;
-    double s = 0.0;
-    for (int i = threadIdx.x; i < nfft; i += 256) s += (double)seg[i];
+    // four independent partial sums: the loop is a chain of load latencies otherwise (nfft is a
+    // multiple of 1024 on this path)
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int i = threadIdx.x; i < nfft; i += 1024) {
+        s0 += (double)seg[i];
+        s1 += (double)seg[i + 256];
+        s2 += (double)seg[i + 512];
+        s3 += (double)seg[i + 768];
+    }
+    double s = (s0 + s1) + (s2 + s3);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -921,22 +930,48 @@ __global__ __launch_bounds__(256) void big_mean_kernel(const float *__restrict__
     if (threadIdx.x == 0) mean[blockIdx.x] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)nfft);
 }
 
-// BIG_W radix-2 Stockham transforms of length n (power of two) side by side in LDS:
-// element e of transform j at buf[j*n + e]; returns the buffer that holds the result.
-__device__ float2 *big_fft_lds(float2 *a, float2 *b, int n)
+// BIG_W Stockham transforms of length n (power of two) side by side in LDS, radix-4 stages and
+// one radix-2 stage when log2(n) is odd: element e of transform j at buf[j*n + e]; returns the
+// buffer that holds the result.  `tw` (n entries of LDS) receives exp(-2 pi i m / n) once; a
+// stage of radix R at Ns takes W^(k q) from entry k q n / (R Ns) instead of a sincospif per point.
+__device__ float2 *big_fft_lds(float2 *a, float2 *b, float2 *tw, int n)
 {
-    const int half = n >> 1;
-    for (int Ns = 1; Ns < n; Ns <<= 1) {
+    for (int m = threadIdx.x; m < n; m += 256) {
+        float sn, cs;
+        sincospif(-2.0f * (float)m / (float)n, &sn, &cs);
+        tw[m] = make_float2(cs, sn);
+    }
+    __syncthreads();
+    const int quarter = n >> 2;
+    int Ns = 1;
+    for (; Ns * 4 <= n; Ns <<= 2) {
+        const int stride = quarter / Ns;
+        for (int i = threadIdx.x; i < BIG_W * quarter; i += 256) {
+            const int j = i / quarter, e = i - j * quarter;
+            const int k = e & (Ns - 1);
+            const float2 *in = a + j * n + e;
+            const float2 v0 = in[0];
+            const float2 v1 = cmul(in[quarter], tw[k * stride]);
+            const float2 v2 = cmul(in[2 * quarter], tw[2 * k * stride]);
+            const float2 v3 = cmul(in[3 * quarter], tw[3 * k * stride]);
+            const float2 t0 = cadd(v0, v2), t1 = csub(v0, v2), t2 = cadd(v1, v3), t3 = mul_negi(csub(v1, v3));
+            float2 *o = b + j * n + ((e - k) << 2) + k;
+            o[0] = cadd(t0, t2);
+            o[Ns] = cadd(t1, t3);
+            o[2 * Ns] = csub(t0, t2);
+            o[3 * Ns] = csub(t1, t3);
+        }
+        __syncthreads();
+        float2 *tmp = a; a = b; b = tmp;
+    }
+    if (Ns < n) {                              // one radix-2 stage is left: Ns == n / 2
+        const int half = n >> 1;
         for (int i = threadIdx.x; i < BIG_W * half; i += 256) {
             const int j = i / half, e = i - j * half;
-            const int k = e & (Ns - 1);
-            float sn, cs;
-            sincospif(-(float)k / (float)Ns, &sn, &cs);
-            const float2 v0 = a[j * n + e], v1 = a[j * n + e + half];
-            const float2 t = make_float2(v1.x * cs - v1.y * sn, v1.x * sn + v1.y * cs);
-            const int e0 = ((e - k) << 1) + k;
-            b[j * n + e0] = make_float2(v0.x + t.x, v0.y + t.y);
-            b[j * n + e0 + Ns] = make_float2(v0.x - t.x, v0.y - t.y);
+            const float2 v0 = a[j * n + e];
+            const float2 t = cmul(a[j * n + e + half], tw[e]);
+            b[j * n + e] = cadd(v0, t);
+            b[j * n + e + half] = csub(v0, t);
         }
         __syncthreads();
         float2 *tmp = a; a = b; b = tmp;
@@ -949,7 +984,7 @@ __global__ __launch_bounds__(256) void big_pass1_kernel(const float *__restrict_
                                                         int hop, int N1, int N2, const float *__restrict__ mean,
                                                         float2 *__restrict__ B)
 {
-    extern __shared__ float2 big_lds[];                    // 2 * BIG_W * N1
+    extern __shared__ float2 big_lds[];                    // 2 * BIG_W * N1 + N1
     const long long item = item0 + blockIdx.y;
     const long long ch = item / frames_valid, frame = item % frames_valid;
     const float *seg = x + ch * x_pitch + frame * (long long)hop;
@@ -966,7 +1001,7 @@ __global__ __launch_bounds__(256) void big_pass1_kernel(const float *__restrict_
         a[j * N1 + n1] = make_float2((x0 - mu) * w0, (x1 - mu) * w1);
     }
     __syncthreads();
-    float2 *r = big_fft_lds(a, b, N1);
+    float2 *r = big_fft_lds(a, b, big_lds + 2 * BIG_W * N1, N1);
     float2 *Bi = B + (long long)blockIdx.y * M;
     for (int i = threadIdx.x; i < BIG_W * N1; i += 256) {
         const int k1 = i / BIG_W, j = i - k1 * BIG_W;
@@ -982,7 +1017,7 @@ __global__ __launch_bounds__(256) void big_pass1_kernel(const float *__restrict_
 __global__ __launch_bounds__(256) void big_pass2_kernel(const float2 *__restrict__ B, int M, int N1, int N2,
                                                         float2 *__restrict__ Z)
 {
-    extern __shared__ float2 big_lds[];                    // 2 * BIG_W * N2
+    extern __shared__ float2 big_lds[];                    // 2 * BIG_W * N2 + N2
     const int k1_0 = blockIdx.x * BIG_W;
     const float2 *Bi = B + (long long)blockIdx.y * M;
     float2 *a = big_lds, *b = big_lds + BIG_W * N2;
@@ -991,7 +1026,7 @@ __global__ __launch_bounds__(256) void big_pass2_kernel(const float2 *__restrict
         a[j * N2 + n2] = Bi[(long long)(k1_0 + j) * N2 + n2];
     }
     __syncthreads();
-    float2 *r = big_fft_lds(a, b, N2);
+    float2 *r = big_fft_lds(a, b, big_lds + 2 * BIG_W * N2, N2);
     float2 *Zi = Z + (long long)blockIdx.y * M;
     for (int i = threadIdx.x; i < BIG_W * N2; i += 256) {
         const int k2 = i / BIG_W, j = i - k2 * BIG_W;
@@ -1079,7 +1114,7 @@ int run_big(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long channe
     float *mean = (float *)work;
     float2 *B = (float2 *)((char *)work + off_b);
     float2 *Z = B + (size_t)batch * M;
-    const size_t lds1 = 2 * (size_t)BIG_W * N1 * sizeof(float2), lds2 = 2 * (size_t)BIG_W * N2 * sizeof(float2);
+    const size_t lds1 = (2 * (size_t)BIG_W * N1 + N1) * sizeof(float2), lds2 = (2 * (size_t)BIG_W * N2 + N2) * sizeof(float2);
     HD_CHECK_HIP(hipFuncSetAttribute((const void *)big_pass1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     HD_CHECK_HIP(hipFuncSetAttribute((const void *)big_pass2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     for (long long item0 = 0; item0 < items; item0 += batch) {
