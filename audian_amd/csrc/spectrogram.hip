@@ -728,7 +728,8 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wg_kernel(
     constexpr int F = M + 1;
     constexpr int MP = M + M / 16;
     static_assert(R1 * R2 * R3 == M, "radices must multiply to M");
-    static_assert(PPL % R1 == 0 && PPL % R2 == 0 && PPL == R3, "one stage-3 butterfly per thread");
+    static_assert(PPL % R1 == 0 && PPL % R2 == 0 && PPL % R3 == 0, "radix must divide points per thread");
+    constexpr int NB3 = PPL / R3;
     constexpr int TW2 = (R2 - 1) * R1;
     constexpr int TW3 = R1 * R2;
     constexpr int TWN = M / 2 + 1;
@@ -793,14 +794,15 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wg_kernel(
         __syncthreads();
         stockham_stage<R3, R1 * R2, M, LPF, true, false, true>(v, fb, tw3, l);
         __syncthreads();
-        // v[m] = Z[k], k = l + LPF m; natural order into LDS for the partner bins Z[M-k]
+        // v[(m % NB3) * R3 + m / NB3] = Z[k], k = l + LPF m; natural order into LDS for the
+        // partner bins Z[M-k]
 #pragma unroll
-        for (int m = 0; m < PPL; m++) fb[pad16(l) + LPF * m + LPF * m / 16] = v[m];
+        for (int m = 0; m < PPL; m++) fb[pad16(l) + LPF * m + LPF * m / 16] = v[(m % NB3) * R3 + m / NB3];
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < PPL / 2; m++) {
             const int k = l + LPF * m;
-            const float2 zk = v[m];
+            const float2 zk = v[(m % NB3) * R3 + m / NB3];
             const float2 zm = fb[pad16((M - k) & (M - 1))];
             float pk, pm;
             if (m == 0 && l == 0) {
@@ -820,7 +822,7 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wg_kernel(
             if (DB) { db_out[obase + k] = to_db(pk); db_out[obase + M - k] = to_db(pm); }
         }
         if (l == 0) {                                        // k = M/2 pairs with itself
-            const float2 z = v[PPL / 2];
+            const float2 z = v[((PPL / 2) % NB3) * R3 + (PPL / 2) / NB3];
             const float p = 2.f * scale * (z.x * z.x + z.y * z.y);
             out[obase + M / 2] = p;
             if (DB) db_out[obase + M / 2] = to_db(p);
@@ -1378,6 +1380,7 @@ extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pit
             if (want == 2) return run_fast2<2048, 32, 32, 32, 8>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
             return run_fast<2048, 64, 16, 16, 4, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
         case 4096:
+            if (want == 2) return run_wg<4096, 128, 16, 16, 8, 3>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
             return run_fast<4096, 64, 16, 16, 8, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
         }
     }

@@ -7,6 +7,8 @@ from audian_amd import hipdsp
 sizes = [int(a) for a in sys.argv[1:]] or [8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536]
 C, T, rate = 64, int(120*96000), 96000.0
 ctx = hipdsp.Context(0)
+if os.environ.get('SPEC_KERNEL'):
+    ctx.set_option('spec_kernel', int(os.environ['SPEC_KERNEL']))      # 2: the alternative kernel of a size
 dx = hipdsp.DeviceArray(ctx, (C, T), np.float32)
 hipdsp.synth(ctx, dx, T, C, T, rate, 7)
 e0, e1 = ctx.event(), ctx.event()
