@@ -151,6 +151,11 @@ def parity_subset(args, hipdsp, ctx, dx, df, ds, de, T, nd, sos, esos):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON result: whatever libraries print on the way (RCCL
+    # writes a version banner to stdout when its communicator comes up) goes to stderr instead
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     # enough hardware queues that the compute, spectrogram and RCCL streams do not share one
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     rank = int(os.environ.get('RANK', '0'))
@@ -176,8 +181,10 @@ def main():
         if args.same_device:
             local_rank = 0
         torch.cuda.set_device(local_rank)
-        if world == 1 and 'MASTER_ADDR' not in os.environ:
-            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
+        if world == 1:                        # --force-dist without a launcher
+            for key, val in (('MASTER_ADDR', '127.0.0.1'), ('MASTER_PORT', '29533'), ('RANK', '0'),
+                             ('WORLD_SIZE', '1')):
+                os.environ.setdefault(key, val)
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
@@ -443,7 +450,8 @@ def main():
         }
         if parity is None or not parity < 1e-4:
             line['invalid'] = 'parity gate failed'
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(line) + '\n').encode())
     if multi:
         dist.destroy_process_group()
 

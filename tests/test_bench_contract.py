@@ -45,8 +45,8 @@ def test_one_json_line_with_the_contract_keys():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--seconds', '20', '--steps', '2',
                           '--warmup', '1', '--cpu-sample-seconds', '1'], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1, out.stdout[:2000]            # nothing but the JSON line on stdout
     d = json.loads(lines[0])
     for key in REQUIRED:
         assert key in d, key
@@ -57,4 +57,19 @@ def test_one_json_line_with_the_contract_keys():
     assert abs(r['frac'] - r['achieved']/r['peak']) < 1e-3
     c = d['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0
+    assert d['parity_max_rel_err'] < 1e-4 and 'invalid' not in d
+
+
+@pytest.mark.gpu
+def test_multi_rank_code_path_prints_only_the_json_line():
+    """The N > 1 code path (torch.distributed over RCCL, non-default streams, tile all-gather)
+    with a single rank: RCCL's start-up banner must not end up on stdout."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--force-dist', '--seconds', '20',
+                          '--steps', '2', '--warmup', '1', '--no-cpu-baseline'], capture_output=True, text=True,
+                         timeout=600, env=dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29577'))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1, out.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and 'all-gather' in d['config']['parallelism']
     assert d['parity_max_rel_err'] < 1e-4 and 'invalid' not in d
