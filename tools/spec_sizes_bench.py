@@ -1,11 +1,13 @@
-"""PSD kernel rate per window length (hop = nfft/2), 64 ch x 120 s x 96 kHz resident in HBM:
-algorithmic bytes (4 per sample read + 4 per bin written) / event time.  Usage: [sizes ...]"""
+"""PSD kernel rate per window length (hop = nfft/HOPDIV, default 2), 64 ch x SECONDS_ (120) s x 96 kHz
+resident in HBM: algorithmic bytes (4 per sample read + 4 per bin written) / event time.
+Usage: [sizes ...]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audian_amd import hipdsp
 sizes = [int(a) for a in sys.argv[1:]] or [8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536]
-C, T, rate = 64, int(120*96000), 96000.0
+C, T, rate = 64, int(float(os.environ.get('SECONDS_', '120'))*96000), 96000.0
+hopdiv = int(os.environ.get('HOPDIV', '2'))
 ctx = hipdsp.Context(0)
 if os.environ.get('SPEC_KERNEL'):
     ctx.set_option('spec_kernel', int(os.environ['SPEC_KERNEL']))      # 2: the alternative kernel of a size
@@ -13,7 +15,7 @@ dx = hipdsp.DeviceArray(ctx, (C, T), np.float32)
 hipdsp.synth(ctx, dx, T, C, T, rate, 7)
 e0, e1 = ctx.event(), ctx.event()
 for nfft in sizes:
-    hop = nfft//2
+    hop = max(nfft//hopdiv, 1)
     t = T if nfft >= 64 else T//8          # the tiny windows write 2x the input: keep the output small
     nd = (t + hop - 1)//hop
     for want_db in (False, True):
@@ -27,7 +29,7 @@ for nfft in sizes:
         ctx.record(e1)
         ms = ctx.elapsed_ms(e0, e1)/4
         gb = (4.0*C*t + (8.0 if want_db else 4.0)*C*nd*(nfft//2 + 1))/1e9
-        print(f'nfft {nfft:6d} {"PSD+dB" if want_db else "PSD   "}: {ms:8.3f} ms  {gb/ms*1e3:6.0f} GB/s', flush=True)
+        print(f'nfft {nfft:6d} hop {hop:6d} {"PSD+dB" if want_db else "PSD   "}: {ms:8.3f} ms  {gb/ms*1e3:6.0f} GB/s', flush=True)
         ds.free()
         if db is not None:
             db.free()
