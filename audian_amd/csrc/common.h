@@ -24,6 +24,7 @@ struct hipdsp_ctx {
     int sos_prefetch;      // experiments: register prefetch of the next tile in the envelope sweeps
     int spec_no_half;      // experiments/tests: do not reuse the overlapped half frame
     int spec_fpw, spec_kernel;   // experiments (tools/), 0 = defaults
+    int chain_debug;       // experiments: ablation bits of the fused forward kernel
     struct hd_pool *pool;  // stream-ordered cache of freed device blocks (ctx.hip)
 };
 
@@ -61,3 +62,5 @@ static inline int hd_launch_status(const char *what)
 }
 
 int hipdsp_scratch(hipdsp_ctx *ctx, size_t bytes, void **out);
+// tw2 | tw3 | twn | window of the 2048-point PSD kernel (radix 16 x 16 x 4), device memory (spectrogram.hip)
+int hd_fft_tables_2048(hipdsp_ctx *ctx, const float **dev);

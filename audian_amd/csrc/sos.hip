@@ -20,6 +20,7 @@
 //     swizzled so the row-per-lane and the coalesced views are both conflict-free.
 // Coefficients and state are float64, HBM traffic is float32.
 #include "common.h"
+#include "fft_device.h"
 #include <cmath>
 #include <vector>
 
@@ -632,6 +633,359 @@ __global__ void copy_skip_kernel(const float *__restrict__ x, long long x_pitch,
         yo[i] = xi[i];
 }
 
+// ---- forward sweep of the batch chain with the spectrogram fused in -------------------------
+// The filtered trace is the one array of the chain that is read twice (by the spectrogram and by
+// the envelope's backward sweep).  Here the forward sweep hands every finished tile to an FFT wave
+// of its own workgroup through LDS, so the spectrogram never reads it from HBM: 12 instead of
+// 16 B/sample for band-pass + envelope states + PSD.  nfft == TILE (2048), hop == TILE/2: tile t
+// IS frame 2t, and frame 2t-1 is the second half of tile t-1 followed by the first half of tile t.
+//
+// A workgroup is P IIR waves (exactly sos_ckpt_kernel<SF, SE, true>'s walk over one
+// (channel, segment) each) and P FFT waves, FFT wave p serving IIR wave p.  Two workgroup
+// barriers per tile:
+//   B1  the tile holds the band-pass output      -> the FFT wave copies it into registers
+//   B2  the copy is done                         -> the IIR wave may rectify the tile in place
+// and between B2 and the next B1 the FFT wave computes its (at most) two frames while the IIR
+// wave finishes the tile (envelope state sweep) and brings in the next one.  All waves of the
+// grid walk the same number of iterations (tile = lo - warm + k*TILE; a segment without warm-up,
+// or without the extra extension tile, idles through the others) so that the barriers pair up.
+// Within a wave the single-wave kernels' __syncthreads() become wave-local fences.
+struct ChainArgs {
+    CkptArgs c;
+    float *psd;               // (channels, frames_out, TILE/2 + 1)
+    long long psd_pitch;
+    long long n_valid;        // frames that lie inside the trace
+    const float *tables;      // tw2 | tw3 | twn | window of the 2048-point PSD kernel (fft_tables)
+    float scale;              // 1 / (fs * sum w^2)
+    int n_iter;
+    long long warm_total;     // band-pass + envelope warm-up samples
+    long long units;          // channels * n_seg
+    int debug;                // experiments: 1 = FFT waves only copy, 2 = IIR waves skip the cascades
+};
+
+#define WAVE_SYNC()                                          \
+    do {                                                     \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                     \
+    } while (0)
+
+// One 2048-sample frame from its two register halves (lo: samples 2l + 128 t, t < 8; hi: the
+// same 1024 samples later) -> detrend, Hann, half-length complex FFT 16 x 16 x 4, split step, PSD.
+// Same arithmetic as spec_fast_kernel<2048, 64, 16, 16, 4, ...>.
+__device__ __forceinline__ void psd_frame_2048(const v2f *lo, const v2f *hi, float2 *fb, const float2 *tw2,
+                                               const float2 *tw3, const float2 *twn, const float2 *win, int l,
+                                               float scale, float *__restrict__ o)
+{
+    constexpr int NFFT = 2048, M = 1024, LPF = 64, PPL = 16, R1 = 16, R2 = 16, R3 = 4;
+    float2 v[PPL];
+    v2f acc = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < R1; t++) {
+        const v2f r = t < R1 / 2 ? lo[t] : hi[t - R1 / 2];
+        v[t] = make_float2(r.x, r.y);
+        acc += r;
+    }
+    const float mean = wave_sum(acc.x + acc.y) * (1.0f / (float)NFFT);
+    const v2f mean2 = {mean, mean};
+#pragma unroll
+    for (int t = 0; t < R1; t++) v[t] = as_f2((as_v2f(v[t]) - mean2) * as_v2f(win[l + LPF * t]));
+    stockham_stage<R1, 1, M, LPF, false, true>(v, fb, tw2, l);
+    stockham_stage<R2, R1, M, LPF, true, true>(v, fb, tw2, l);
+    stockham_stage<R3, R1 * R2, M, LPF, true, false, true>(v, fb, tw3, l);
+    // v[u*R3 + t] = Z[k], k = l + LPF*m, m = u + NB3*t; partner bin Z[M-k] from lane 64-l
+    constexpr int NB3 = PPL / R3;
+    const int partner = (LPF - l) & (LPF - 1);
+    float pk_last = 0.f;
+    const v2f hscale2 = {0.5f * scale, 0.5f * scale};
+#pragma unroll
+    for (int m = 0; m < PPL / 2; m++) {
+        const int k = l + LPF * m;
+        const float2 zk = v[(m % NB3) * R3 + m / NB3];
+        const int mp = PPL - 1 - m;
+        const float2 zsrc = v[(mp % NB3) * R3 + mp / NB3];
+        float2 zm;
+        zm.x = __shfl(zsrc.x, partner, 64);
+        zm.y = __shfl(zsrc.y, partner, 64);
+        if (m > 0) {
+            const int m0 = PPL - m;
+            const float2 z0 = v[(m0 % NB3) * R3 + m0 / NB3];
+            zm = (l == 0) ? z0 : zm;
+        }
+        const v2f e = pk_add_conj(as_v2f(zk), as_v2f(zm));
+        const v2f t = pk_cmul_negi(pk_sub_conj(as_v2f(zk), as_v2f(zm)), as_v2f(twn[k]));
+        const v2f re = pk_sumdiff_x(e, t), im = pk_sumdiff_y(e, t);
+        const v2f pw = (re * re + im * im) * hscale2;
+        float pk = pw.x, pm = pw.y;
+        if (m == 0) {
+            const float dc0 = zk.x + zk.y, ny = zk.x - zk.y;
+            pk = (l == 0) ? dc0 * dc0 * scale : pk;
+            pm = (l == 0) ? ny * ny * scale : pm;
+        }
+        o[k] = pk;
+        o[M - k] = pm;
+        pk_last = pk;
+    }
+    {
+        constexpr int mh = PPL / 2;
+        const float2 z = v[(mh % NB3) * R3 + mh / NB3];
+        const float ph = 2.f * scale * (z.x * z.x + z.y * z.y);
+        const int kk = (l == 0) ? M / 2 : l + LPF * (PPL / 2 - 1);
+        o[kk] = (l == 0) ? ph : pk_last;
+    }
+}
+
+template <int SF, int SE, int NP>
+__global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPlanDev *__restrict__ PF0,
+                                                                   const SosPlanDev *__restrict__ PE0, ChainArgs a)
+{
+    static_assert(SF > 0 && NP % 2 == 0, "band-pass in front; whole waves per SIMD");
+    constexpr int DF = 2 * SF, DE = 2 * SE;
+    constexpr int M = TILE / 2, F = M + 1, MP = M + M / 16;
+    constexpr int TW2 = 15 * 16, TW3 = 256, TWN = M / 2 + 1, NTAB = TW2 + TW3 + TWN + M;
+    __shared__ float4 tiles[NP][64 * 8];
+    __shared__ float rprevs[NP][64];
+    __shared__ float2 fbs[NP][MP];
+    __shared__ float2 tab[NTAB];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int pair = wave < NP ? wave : wave - NP;
+    {
+        const float2 *src = reinterpret_cast<const float2 *>(a.tables);
+        for (int i = tid; i < NTAB; i += 128 * NP) tab[i] = src[i];
+    }
+    __syncthreads();
+
+    const long long unit = (long long)blockIdx.x * NP + pair;
+    const bool unit_ok = unit < a.units;
+    const int seg = unit_ok ? (int)(unit % a.c.n_seg) : 0;
+    const long long ch = unit_ok ? unit / a.c.n_seg : 0;
+    const long long T = a.c.T;
+    const int edge = a.c.edge;
+    const long long lo = (long long)seg * a.c.seg_len;
+    long long hi = lo + a.c.seg_len;
+    const bool last_seg = hi >= T;
+    if (hi > T) hi = T;
+    long long env_start = lo - PE0->warm;
+    const bool env_true = env_start <= 0;
+    if (env_start < 0) env_start = 0;
+    long long start = env_start - PF0->warm;
+    if (start < 0) start = 0;
+    long long loop_end = last_seg ? T + edge : hi;
+    if (!unit_ok) loop_end = start;                     // a pair without a unit only takes the barriers
+    const long long base = lo - a.warm_total;           // tile of iteration 0 (negative: idle iterations)
+
+    if (wave < NP) {
+        // ================= IIR role: sos_ckpt_kernel<SF, SE, true> with the barriers added ==========
+        float4 *lds = tiles[pair];
+        float *ldsf = reinterpret_cast<float *>(lds);
+        float *rprev = rprevs[pair];
+        const float *in = a.c.in + ch * a.c.in_pitch;
+        float *yf = a.c.yf + ch * a.c.yf_pitch;
+        double *ckpt = a.c.ckpt + ch * a.c.ckpt_pitch;
+        double cf_[DF], ce_[DE];
+#pragma unroll
+        for (int r = 0; r < DF; r++) cf_[r] = 0.0;
+#pragma unroll
+        for (int r = 0; r < DE; r++) ce_[r] = 0.0;
+        rprev[lane] = 0.f;
+        v4f nx[8];
+        bool pre = false;
+        const long long top_full = (T / TILE - 1) * TILE;            // host guarantees >= 0
+        auto fetch = [&](long long t0) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) nx[k] = asm_load16(in + t0 + 256 * k + 4 * lane);
+        };
+        // what iteration k + 1 will read: its tile if that is a full tile of this unit, else a dummy
+        auto prefetchable = [&](long long t0) { return t0 >= start && t0 < loop_end && t0 + TILE <= T; };
+        pre = prefetchable(base);
+        fetch(pre ? base : top_full);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        for (int it = 0; it < a.n_iter; it++) {
+            const long long tile = base + (long long)it * TILE;
+            const bool active = tile >= start && tile < loop_end;
+            if (active) {
+                if (pre) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        asm volatile("" : "+v"(nx[k]));
+                        lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = make_float4(nx[k].x, nx[k].y, nx[k].z, nx[k].w);
+                    }
+                } else {
+                    // a tile that reaches past T: untracked loads from clamped addresses, zeros past T
+#pragma unroll 1
+                    for (int k = 0; k < 8; k++) {
+                        const long long p = tile + 256 * k + 4 * lane;
+                        v4f t;
+                        t.x = asm_load4(in + (p < T ? p : T - 1));
+                        t.y = asm_load4(in + (p + 1 < T ? p + 1 : T - 1));
+                        t.z = asm_load4(in + (p + 2 < T ? p + 2 : T - 1));
+                        t.w = asm_load4(in + (p + 3 < T ? p + 3 : T - 1));
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        asm volatile("" : "+v"(t));
+                        lds[lds_slot(8 * k + (lane >> 3), lane & 7)] =
+                            make_float4(p < T ? t.x : 0.f, p + 1 < T ? t.y : 0.f, p + 2 < T ? t.z : 0.f, p + 3 < T ? t.w : 0.f);
+                    }
+                }
+            }
+            WAVE_SYNC();
+            // unconditional, like in sos_ckpt_kernel (a conditional fetch would turn `nx` into a phi
+            // whose copies read registers with loads in flight)
+            {
+                const long long next = tile + TILE;
+                pre = prefetchable(next);
+                fetch(pre ? next : top_full);
+            }
+            if (active && !(a.debug & 2)) {
+#define CASC_S SF
+#define CASC_PLAN() PLAN_OF(PF0)
+#define CASC_CARRY cf_
+#define CASC_IN(v) (v)
+#define CASC_ROLLED_GROUPS
+#include "sos_cascade.inc"
+#undef CASC_ROLLED_GROUPS
+#undef CASC_S
+#undef CASC_PLAN
+#undef CASC_CARRY
+#undef CASC_IN
+            }
+            WAVE_SYNC();
+            __syncthreads();                                   // B1: the tile holds the filtered samples
+            if (active && tile >= lo && tile + TILE <= hi) {
+                // interior tile: exactly 8 vector stores, then the counted wait
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const float4 v = lds[lds_slot(8 * k + (lane >> 3), lane & 7)];
+                    f4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+                    *reinterpret_cast<f4u *>(yf + tile + 256 * k + 4 * lane) = t;
+                }
+                asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            } else {
+                // border tile of the segment, warm-up or idle: whatever is stored, no stores to count
+                if (active && tile + TILE > lo && tile < hi) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        store_four(yf, tile + 256 * k + 4 * lane, lds[lds_slot(8 * k + (lane >> 3), lane & 7)], lo, hi, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();                                   // B2: the FFT wave has its copy
+            if (active && tile >= env_start && !(a.debug & 2)) {
+                // ---- envelope input in place: r = gain*|y|, then the odd extension past T
+                if (a.c.rectify) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        float4 v = lds[lds_slot(lane, q)];
+                        v = make_float4(a.c.gain * fabsf(v.x), a.c.gain * fabsf(v.y), a.c.gain * fabsf(v.z),
+                                        a.c.gain * fabsf(v.w));
+                        lds[lds_slot(lane, q)] = v;
+                    }
+                }
+                WAVE_SYNC();
+                auto rval = [&](long long j) -> float {
+                    return j >= tile ? ldsf[lds_float_index((int)(j - tile))] : rprev[64 - (int)(tile - j)];
+                };
+                if (tile + TILE > T) {
+                    float pv = 0.f;
+                    long long pj = -1;
+                    if (lane < edge) {
+                        pj = T + lane;
+                        if (pj >= tile && pj < tile + TILE) pv = 2.f * rval(T - 1) - rval(T - 2 - lane);
+                    }
+                    WAVE_SYNC();
+                    if (lane < edge && pj >= tile && pj < tile + TILE) ldsf[lds_float_index((int)(pj - tile))] = pv;
+                    WAVE_SYNC();
+                }
+                if (env_true && tile == 0) {
+                    const SosPlanDev *Pz = PLAN_OF(PE0);
+                    const float r0 = ldsf[lds_float_index(0)];
+                    const double x0 = (double)(2.f * r0 - ldsf[lds_float_index(edge)]);
+#pragma unroll
+                    for (int r = 0; r < DE; r++) ce_[r] = Pz->zi[r] * x0;
+                    for (int i = 0; i < edge; i++) {
+                        double cur = (double)(2.f * r0 - ldsf[lds_float_index(edge - i)]);
+#pragma unroll
+                        for (int s2 = 0; s2 < SE; s2++) {
+                            const double y = fma(Pz->coef[s2][0], cur, ce_[2 * s2]);
+                            ce_[2 * s2] = fma(-Pz->coef[s2][3], y, fma(Pz->coef[s2][1], cur, ce_[2 * s2 + 1]));
+                            ce_[2 * s2 + 1] = fma(-Pz->coef[s2][4], y, Pz->coef[s2][2] * cur);
+                            cur = y;
+                        }
+                    }
+                }
+                if (tile >= lo && lane == 0) {
+#pragma unroll
+                    for (int r = 0; r < DE; r++) ckpt[(tile / TILE) * DE + r] = ce_[r];
+                }
+                if (tile + TILE < loop_end) {
+                    {
+                        const float4 keep0 = lds[lds_slot(62 + ((lane >> 3) & 1), lane & 7)];
+                        WAVE_SYNC();
+                        if (lane < 16) {
+                            rprev[4 * lane] = keep0.x; rprev[4 * lane + 1] = keep0.y;
+                            rprev[4 * lane + 2] = keep0.z; rprev[4 * lane + 3] = keep0.w;
+                        }
+                    }
+#define CASC_S SE
+#define CASC_PLAN() PLAN_OF(PE0)
+#define CASC_CARRY ce_
+#define CASC_IN(v) (v)
+#define CASC_NO_OUTPUT
+#define CASC_ROLLED_GROUPS
+#include "sos_cascade.inc"
+#undef CASC_ROLLED_GROUPS
+#undef CASC_NO_OUTPUT
+#undef CASC_S
+#undef CASC_PLAN
+#undef CASC_CARRY
+#undef CASC_IN
+                }
+                WAVE_SYNC();
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last (dummy) prefetch
+    } else {
+        // ================= FFT role ===================================================================
+        float2 *fb = fbs[pair];
+        const float *tlf = reinterpret_cast<const float *>(tiles[pair]);
+        const float2 *tw2 = tab, *tw3 = tab + TW2, *twn = tab + TW2 + TW3, *win = tab + TW2 + TW3 + TWN;
+        float *oc = a.psd + ch * a.psd_pitch;
+        v2f lo_[8], hi_[8], hp_[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { lo_[j] = (v2f){0.f, 0.f}; hi_[j] = (v2f){0.f, 0.f}; hp_[j] = (v2f){0.f, 0.f}; }
+        bool have_prev = false;
+        for (int it = 0; it < a.n_iter; it++) {
+            const long long tile = base + (long long)it * TILE;
+            const bool active = tile >= start && tile < loop_end;
+            __syncthreads();                                   // B1
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    lo_[j] = *reinterpret_cast<const v2f *>(tlf + lds_float_index(2 * lane + 128 * j));
+                    hi_[j] = *reinterpret_cast<const v2f *>(tlf + lds_float_index(1024 + 2 * lane + 128 * j));
+                }
+            }
+            __syncthreads();                                   // B2
+            if (active) {
+                const long long t = tile / TILE;
+                if (tile >= lo && tile < hi) {                 // the unit that owns the tile writes its frames
+                    const long long f1 = 2 * t - 1;
+                  if (!(a.debug & 1)) {
+                    if (have_prev && f1 >= 0 && f1 < a.n_valid)
+                        psd_frame_2048(hp_, lo_, fb, tw2, tw3, twn, win, lane, a.scale, oc + f1 * (long long)F);
+                    if (2 * t < a.n_valid)
+                        psd_frame_2048(lo_, hi_, fb, tw2, tw3, twn, win, lane, a.scale, oc + 2 * t * (long long)F);
+                  } else if (f1 == -12345) oc[lane] = lo_[0].x + hi_[1].y + hp_[2].x;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) hp_[j] = hi_[j];
+                have_prev = true;
+            }
+        }
+    }
+}
+
 __global__ void zero_rows_kernel(float *__restrict__ y, long long y_pitch, long long n)
 {
     long long ch = blockIdx.y;
@@ -1102,6 +1456,81 @@ int hipdsp_sosfilt_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const 
     return launch_env_ckpt(ctx, fplan->dev, eplan->dev, fplan->host->n_sections, eplan->host->n_sections,
                            fplan->host->warm, eplan->host->warm, edge, x, x_pitch, yf, yf_pitch, env, env_pitch,
                            channels, frames, 0, rectify, gain, clamp, phase);
+}
+
+int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hipdsp_sosplan *eplan,
+                         const float *x, int64_t x_pitch, float *yf, int64_t yf_pitch, int64_t channels,
+                         int64_t frames, int rectify, double gain, int nfft, int hop, double fs, float *psd,
+                         int64_t frames_out, int64_t psd_pitch)
+{
+    HD_REQUIRE(ctx != nullptr && fplan != nullptr && eplan != nullptr, "NULL argument");
+    HD_REQUIRE(channels >= 0 && frames >= 0 && frames_out >= 0, "negative size");
+    HD_REQUIRE(fs > 0, "fs must be positive");
+    const int SF = fplan->host->n_sections, SE = eplan->host->n_sections;
+    HD_REQUIRE(SF > 0 && SE > 0, "plan has no coefficients");
+    if (nfft != TILE || hop != TILE / 2 || SF > 2 || SE > 2 || frames < 4 * TILE ||
+        fplan->host->warm >= (1LL << 40) || eplan->host->warm >= (1LL << 40)) {
+        hipdsp_set_error("the fused forward sweep covers nfft %d / hop %d, plans of at most two sections that "
+                         "decay, and traces of at least %d frames: use hipdsp_sosfilt_envelope + "
+                         "hipdsp_spectrogram", TILE, TILE / 2, 4 * TILE);
+        return HIPDSP_ERR_UNSUPPORTED;
+    }
+    HD_CHECK_HIP(hipSetDevice(ctx->device));
+    const int edge = eplan->host->edge;
+    if (channels == 0) return HIPDSP_OK;
+    HD_REQUIRE(x != nullptr && yf != nullptr && (psd != nullptr || frames_out == 0), "NULL data pointer");
+    HD_REQUIRE(x_pitch >= frames && yf_pitch >= frames, "pitch smaller than row length");
+    const long long F = TILE / 2 + 1;
+    if (psd_pitch == 0) psd_pitch = frames_out * F;
+    HD_REQUIRE(psd_pitch >= frames_out * F, "psd_pitch smaller than one channel");
+    // frames inside the trace, as in hipdsp_spectrogram (bufferedspectrogram.py:46-49)
+    long long nsource = (frames_out - 1) * (long long)hop + nfft;
+    if (nsource > frames) nsource = frames;
+    long long n_valid = 0;
+    if (frames_out > 0 && nsource >= nfft) n_valid = (nsource - (nfft - hop)) / hop;
+    if (n_valid > frames_out) n_valid = frames_out;
+    double wss = 0.0;
+    for (int i = 0; i < nfft; i++) {
+        const double w = 0.5 - 0.5 * cos(2.0 * M_PI * (double)i / (double)nfft);
+        wss += w * w;
+    }
+    ChainArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = hd_fft_tables_2048(ctx, &a.tables);
+    if (rc != HIPDSP_OK) return rc;
+    const long long n_tiles = (frames + edge + TILE - 1) / TILE;
+    const long long ckpt_pitch = n_tiles * 2 * SE;                 // the layout the backward sweep expects
+    void *work = nullptr;
+    rc = hipdsp_scratch(ctx, sizeof(double) * (size_t)ckpt_pitch * (size_t)channels, &work);
+    if (rc != HIPDSP_OK) return rc;
+    a.c.in = x; a.c.yf = yf; a.c.ckpt = (double *)work;
+    a.c.in_pitch = x_pitch; a.c.yf_pitch = yf_pitch; a.c.ckpt_pitch = ckpt_pitch;
+    a.c.T = frames; a.c.edge = edge; a.c.rectify = rectify; a.c.gain = (float)gain;
+    a.psd = psd; a.psd_pitch = psd_pitch; a.n_valid = n_valid;
+    a.scale = (float)(1.0 / (fs * wss));
+    a.warm_total = fplan->host->warm + eplan->host->warm;
+    a.debug = ctx->chain_debug;
+    constexpr int P = 8;                                           // IIR waves (and FFT waves) per workgroup, one per CU
+    plan_segments_for((long long)ctx->n_cus * P, ctx->max_segments, frames, channels, a.warm_total, &a.c.seg_len,
+                      &a.c.n_seg);
+    a.units = channels * a.c.n_seg;
+    a.n_iter = (int)((a.warm_total + a.c.seg_len + edge + TILE - 1) / TILE) + 1;
+    const long long blocks = (a.units + P - 1) / P;
+    HD_REQUIRE(blocks <= 0x7fffffffLL, "grid too large");
+    if (frames_out > n_valid) {                                    // zero tail (bufferedspectrogram.py:59)
+        const long long n = (frames_out - n_valid) * F;
+        unsigned gx = (unsigned)((n + 1023) / 1024 > 4096 ? 4096 : (n + 1023) / 1024);
+        hipLaunchKernelGGL(zero_rows_kernel, dim3(gx, (unsigned)channels), dim3(256), 0, ctx->stream,
+                           psd + n_valid * F, (long long)psd_pitch, n);
+    }
+    dim3 grid((unsigned)blocks), block(128 * P);
+    switch (SF * 8 + SE) {
+    case 1 * 8 + 1: hipLaunchKernelGGL((chain_fwd_kernel<1, 1, P>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a); break;
+    case 1 * 8 + 2: hipLaunchKernelGGL((chain_fwd_kernel<1, 2, P>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a); break;
+    case 2 * 8 + 1: hipLaunchKernelGGL((chain_fwd_kernel<2, 1, P>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a); break;
+    case 2 * 8 + 2: hipLaunchKernelGGL((chain_fwd_kernel<2, 2, P>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a); break;
+    }
+    return hd_launch_status("chain_fwd_kernel");
 }
 
 int hipdsp_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const float *x, int64_t x_pitch,

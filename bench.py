@@ -66,6 +66,12 @@ def parse():
     ap.add_argument('--no-overlap', action='store_true',
                     help='spectrogram on the main stream instead of a second stream next to the '
                          'envelope backward sweep')
+    ap.add_argument('--no-fuse-spectrogram', action='store_true',
+                    help='N = 1 runs band-pass + envelope state sweep + spectrogram as ONE launch '
+                         '(hipdsp_chain_forward: FFT waves take the filtered tiles from LDS, 20 instead of '
+                         '24 B/sample for the step) whenever the shape allows it (nfft 2048 / hop 1024, plans of '
+                         '<= 2 sections); this flag keeps the separate launches.  N > 1 always uses them: the '
+                         'fused kernel wants a whole CU per workgroup, which RCCL\'s resident kernels deny')
     ap.add_argument('--force-dist', action='store_true',
                     help='rehearsal: take the multi-rank code path even with one rank')
     return ap.parse_args()
@@ -200,7 +206,10 @@ def main():
     if args.max_segments:
         ctx.set_max_segments(args.max_segments)
     # The spectrogram and the envelope backward sweep both only read the filtered trace: they run next to each other on two streams, ordered by events.
-    overlap = not args.no_overlap
+    fuse3 = (not args.no_fuse_spectrogram and not args.no_fuse and not (world > 1 or args.force_dist)
+             and args.nfft == 2048 and args.hop == 1024 and args.order <= 2
+             and args.seconds*args.rate >= 8192)
+    overlap = not args.no_overlap and not fuse3      # nothing left to run next to the backward sweep
     sctx, sstream = ctx, None
     if overlap:
         if multi:
@@ -265,7 +274,10 @@ def main():
         ev = events[i] if i >= 0 else None
         if ev:
             ctx.record(ev[0])
-        if fused:
+        if fuse3:
+            hipdsp.chain_forward(ctx, plan, eplan, dx, T, df, T, C, T, args.nfft, args.hop, args.rate, ds, nd,
+                                 rectify=True, gain=np.pi/2)
+        elif fused:
             # band-pass + envelope forward sweep in one pass over x: writes the filtered trace and
             # the envelope state entering every 2048-sample tile; the backward sweep (which
             # recomputes the forward output tile by tile) follows after the spectrogram
@@ -280,7 +292,8 @@ def main():
             sctx.wait_event(ev_filtered)
         if ev:
             sctx.record(ev[5])
-        hipdsp.spectrogram(sctx, df, T, C, T, args.nfft, args.hop, args.rate, ds, nd)
+        if not fuse3:
+            hipdsp.spectrogram(sctx, df, T, C, T, args.nfft, args.hop, args.rate, ds, nd)
         if ev:
             sctx.record(ev[6])
         if multi:
@@ -349,7 +362,10 @@ def main():
         dt = float(tt.item())
 
     # per-kernel averages from the HIP events recorded inside the timed region
-    if fused:
+    if fuse3:
+        names = ['chain_fwd<S=%d+%d,filt+env_state+psd>' % (len(sos), len(esos)), 'spectrogram(fused)',
+                 'tile_copy+gather_wait', 'env_bwd<S=%d>' % len(esos), 'unused']
+    elif fused:
         names = ['sos_ckpt<S=%d+%d,filt+env_state>' % (len(sos), len(esos)), 'spectrogram', 'tile_copy+gather_wait',
                  'env_bwd<S=%d>' % len(esos), 'unused']
     else:
@@ -368,7 +384,12 @@ def main():
     for k in ms:
         ms[k] /= args.steps
     ckpt_bytes = 8.0*C*((T + edge + 2047)//2048)*2*len(esos)
-    if fused:
+    if fuse3:
+        alg_bytes = {
+            names[0]: 8.0*C*T + ckpt_bytes + 4.0*C*nd*F,     # x read; filtered trace, tile states and PSD written
+            names[3]: 8.0*C*T + ckpt_bytes,
+        }
+    elif fused:
         alg_bytes = {                   # algorithmic HBM bytes per launch
             names[0]: 8.0*C*T + ckpt_bytes,            # x read, filtered trace + tile states written
             names[1]: 4.0*C*T + 4.0*C*nd*F,
@@ -383,7 +404,7 @@ def main():
         }
     # with the spectrogram on its own stream its event-bracketed time and the envelope sweeps'
     # overlap; the roofline entry is taken from the kernels that run alone
-    alone = [names[0]] if overlap else list(alg_bytes)
+    alone = [names[0]] if (overlap or fuse3) else list(alg_bytes)
     dom = max(alone, key=lambda k: ms[k])
     achieved = alg_bytes[dom]/(ms[dom]*1e-3)/1e9
     # HBM bytes per launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE x 2
@@ -437,6 +458,7 @@ def main():
                 'streams': ('spectrogram on a second stream next to the envelope backward sweep '
                             '(their event-bracketed times overlap)' if overlap else 'one stream'),
                 'envelope_forward': ('state checkpoints, ' + ('fused into the band-pass kernel' if fused else 'own launch')),
+                'spectrogram': ('FFT waves inside the forward sweep (filtered tiles from LDS)' if fuse3 else 'own launch'),
             },
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -68,7 +68,9 @@ int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
  *   "force_generic_fft"  non-zero: every nfft takes the generic radix-2 / four-step kernels
  *   "spec_kernel"        0 = default per size, 2 = two-stage, 3 = three-stage FFT kernel
  *   "spec_fpw"           consecutive frames per wave (0 = automatic)
- *   "spec_no_half"       non-zero: do not reuse the overlapped half frame at 50 % overlap */
+ *   "spec_no_half"       non-zero: do not reuse the overlapped half frame at 50 % overlap
+ *   "chain_debug"        measurements only (results become wrong): 1 = the FFT waves of
+ *                        hipdsp_chain_forward only copy their tiles, 2 = its IIR waves skip the cascades */
 int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value);
 /* Pre-size the internal scratch (envelope state checkpoints: 16 * n_sections bytes per
  * 2048-sample tile and channel; four-step FFT work area) so that later calls do not
@@ -223,6 +225,23 @@ int hipdsp_sosfilt_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan,
                             float *yf, int64_t yf_pitch, float *env, int64_t env_pitch,
                             int64_t channels, int64_t frames, int rectify, double gain, int clamp,
                             int phase);
+
+/* The forward half of the batch chain in ONE pass over x: BufferedFilter.process
+ * (bufferedfilter.py:31-36) writes yf, the envelope's forward sweep parks its tile states in the
+ * context scratch exactly like hipdsp_sosfilt_envelope(..., phase = 1), and
+ * BufferedSpectrogram.process (bufferedspectrogram.py:45-59) of yf goes to psd -- the spectrogram
+ * takes the filtered tiles from on-chip memory instead of reading yf back (12 instead of 16 bytes
+ * per sample).  Follow with hipdsp_sosfilt_envelope(..., phase = 2) for the envelope.  Results
+ * equal hipdsp_sosfilt_envelope(phase 1) + hipdsp_spectrogram up to float32 rounding of the
+ * frames that straddle an internal segment border.
+ * Covers nfft 2048 / hop 1024, plans of one or two decaying sections and frames >= 8192;
+ * anything else returns HIPDSP_ERR_UNSUPPORTED (use the separate calls).  psd layout and the
+ * zero tail as in hipdsp_spectrogram. */
+int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan,
+                         const hipdsp_sosplan *eplan, const float *x, int64_t x_pitch, float *yf,
+                         int64_t yf_pitch, int64_t channels, int64_t frames, int rectify,
+                         double gain, int nfft, int hop, double fs, float *psd,
+                         int64_t frames_out, int64_t psd_pitch);
 
 /* BufferedSpectrogram.process (bufferedspectrogram.py:45-59) ==
  * scipy.signal.spectrogram(x, fs, 'hann', nperseg=nfft, noverlap=nfft-hop,

@@ -58,6 +58,18 @@ def test_one_json_line_with_the_contract_keys():
     c = d['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0
     assert d['parity_max_rel_err'] < 1e-4 and 'invalid' not in d
+    assert d['roofline']['kernel'].startswith('chain_fwd')      # N = 1 default: the fused forward sweep
+
+
+@pytest.mark.gpu
+def test_separate_launches_on_request():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--seconds', '20', '--steps', '2',
+                          '--warmup', '1', '--no-cpu-baseline', '--no-fuse-spectrogram'], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.splitlines()[-1])
+    assert d['roofline']['kernel'].startswith('sos_ckpt') and 'spectrogram' in d['kernels']
+    assert d['parity_max_rel_err'] < 1e-4 and 'invalid' not in d
 
 
 @pytest.mark.gpu

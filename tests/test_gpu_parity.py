@@ -449,3 +449,59 @@ def test_fused_filter_envelope_equals_separate_calls(oracle, T):
     with pytest.raises(ValueError):
         plan = hipdsp.SosPlan(c, butter_sos(2, 20.0, 'lowpass', rate))
         hipdsp.sosfilt_envelope(c, plan, plan, dx, T, dx, T, dx, T, C, 9)
+
+
+@pytest.mark.parametrize('T,max_segments', [(8192, 0), (20480, 0), (70001, 0), (300000, 0), (300000, 3),
+                                            (1500000, 0), (1500000, 1)])
+def test_chain_forward_equals_separate_calls(oracle, T, max_segments):
+    """hipdsp_chain_forward (band-pass + envelope state sweep + spectrogram 2048/1024 in one pass) and
+    the backward sweep after it, against the separate calls and the oracle: one and many segments
+    (frames that straddle a segment border), traces that end inside a tile, zero tail."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rate, C, nfft, hop = 96000.0, 3, 2048, 1024
+    rng = np.random.default_rng(T + max_segments)
+    x = (synth(rng, T, C, rate) + np.float32(0.05)).astype(np.float32)
+    c = gh.ctx()
+    c.set_max_segments(max_segments)
+    try:
+        dx = gh.to_planar(c, x)
+        nd = (T + hop - 1)//hop
+        F = nfft//2 + 1
+        for band, order, env, eorder in (((300.0, 3000.0), 2, 20.0, 2), ((1000.0, 20000.0), 1, 500.0, 4)):
+            sos = butter_sos(order, band, 'bandpass', rate)
+            esos = butter_sos(eorder, env, 'lowpass', rate)
+            fplan, eplan = hipdsp.SosPlan(c, sos), hipdsp.SosPlan(c, esos)
+            yf = hipdsp.DeviceArray(c, (C, T), np.float32)
+            ye = hipdsp.DeviceArray(c, (C, T), np.float32)
+            ps = hipdsp.DeviceArray(c, (C, nd, F), np.float32)
+            hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(ps), 0x7f, 4*C*nd*F)      # every bin must be written
+            hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, nfft, hop, rate, ps, nd)
+            hipdsp.sosfilt_envelope(c, fplan, eplan, dx, T, yf, T, ye, T, C, T, phase=2)
+            f1 = hipdsp.DeviceArray(c, (C, T), np.float32)
+            e1 = hipdsp.DeviceArray(c, (C, T), np.float32)
+            s1 = hipdsp.DeviceArray(c, (C, nd, F), np.float32)
+            hipdsp.sosfilt_envelope(c, fplan, eplan, dx, T, f1, T, e1, T, C, T)
+            hipdsp.spectrogram(c, f1, T, C, T, nfft, hop, rate, s1, nd)
+            gf, ge, gs = yf.to_host(), ye.to_host(), ps.to_host()
+            sf, se, ss = f1.to_host(), e1.to_host(), s1.to_host()
+            want_f = oracle.sosfilt(sos, x.astype(np.float64))
+            want_e = np.zeros_like(want_f)
+            oracle.envelope_process(esos, sf.T.astype(np.float64), want_e, 0)
+            want_s = np.zeros((nd, C, F))
+            oracle.spectrogram_process(sf.T.astype(np.float64), want_s, rate, nfft, hop)
+            for ch in range(C):
+                assert rel_err(gf[ch], sf[ch]) < 1e-6, (T, order, ch)
+                assert rel_err(ge[ch], se[ch]) < 2e-6, (T, env, ch)
+                assert rel_err(gf[ch], want_f[:, ch]) < TOL
+                assert rel_err(ge[ch], want_e[:, ch]) < TOL
+                for j in range(nd):
+                    if np.max(np.abs(want_s[j, ch])) == 0:
+                        assert np.all(gs[ch, j] == 0) and np.all(ss[ch, j] == 0), (T, j, ch)
+                    else:
+                        assert rel_err(gs[ch, j], want_s[j, ch]) < TOL, (T, max_segments, j, ch)
+                        assert rel_err(gs[ch, j], ss[ch, j]) < 1e-5, (T, max_segments, j, ch)
+        with pytest.raises(NotImplementedError):
+            hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, 1024, 512, rate, ps, nd)
+    finally:
+        c.set_max_segments(0)
