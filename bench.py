@@ -425,6 +425,12 @@ def main():
         kernels['||'.join(shared)] = {'ms': round(pair_ms, 4),
                                       'GBps': round(sum(alg_bytes[k] for k in shared)/(pair_ms*1e-3)/1e9, 1)}
 
+    # the fused forward sweep does the work of two BufferedData stages; SURVEY 8d counts those per
+    # stage (band-pass 4 R + 4 W, spectrogram 4 R + 4.004 W): reported next to the launch's own bytes
+    stage_gbps = None
+    if fuse3:
+        stage_gbps = round((12.0*C*T + 4.0*C*nd*F + ckpt_bytes)/(ms[names[0]]*1e-3)/1e9, 1)
+
     parity = None
     cpu = None
     if rank == 0:
@@ -464,7 +470,8 @@ def main():
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved/HBM_PEAK_GBS, 4), 'traffic': traffic,
                          'algorithmic_bytes': alg_bytes[dom],
-                         'device_copy_GBps': round(copy_gbps, 1)},
+                         'device_copy_GBps': round(copy_gbps, 1),
+                         'per_stage_accounting_GBps': stage_gbps},
             'kernels': kernels,
             'chain_algorithmic_GBps': round(sum(alg_bytes.values())/(dt/args.steps)/1e9, 1),
             'parity_max_rel_err': parity,
