@@ -501,6 +501,19 @@ def test_chain_forward_equals_separate_calls(oracle, T, max_segments):
                     else:
                         assert rel_err(gs[ch, j], want_s[j, ch]) < TOL, (T, max_segments, j, ch)
                         assert rel_err(gs[ch, j], ss[ch, j]) < 1e-5, (T, max_segments, j, ch)
+        # fewer destination frames than the trace supports, more (zero tail), and a channel pitch
+        # with a gap: nothing outside [0, frames_out) of a channel may be touched
+        for nf in (max(nd - 7, 1), nd + 5):
+            pitch = (nf + 3)*F
+            big = hipdsp.DeviceArray(c, (C, nf + 3, F), np.float32)
+            hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(big), 0x7f, 4*C*pitch)
+            hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, nfft, hop, rate, big, nf, psd_pitch=pitch)
+            got = big.to_host()
+            guard = np.frombuffer(b'\x7f\x7f\x7f\x7f', dtype=np.float32)[0]
+            assert np.all(got[:, nf:, :] == guard)
+            m = min(nf, nd)
+            assert np.array_equal(got[:, :m, :], gs[:, :m, :])
+            assert np.all(got[:, nd:nf, :] == 0)
         with pytest.raises(NotImplementedError):
             hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, 1024, 512, rate, ps, nd)
     finally:
