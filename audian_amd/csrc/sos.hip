@@ -641,15 +641,17 @@ __global__ void copy_skip_kernel(const float *__restrict__ x, long long x_pitch,
 // IS frame 2t, and frame 2t-1 is the second half of tile t-1 followed by the first half of tile t.
 //
 // A workgroup is P IIR waves (exactly sos_ckpt_kernel<SF, SE, true>'s walk over one
-// (channel, segment) each) and P FFT waves, FFT wave p serving IIR wave p.  Two workgroup
-// barriers per tile:
-//   B1  the tile holds the band-pass output      -> the FFT wave copies it into registers
-//   B2  the copy is done                         -> the IIR wave may rectify the tile in place
-// and between B2 and the next B1 the FFT wave computes its (at most) two frames while the IIR
-// wave finishes the tile (envelope state sweep) and brings in the next one.  All waves of the
-// grid walk the same number of iterations (tile = lo - warm + k*TILE; a segment without warm-up,
-// or without the extra extension tile, idles through the others) so that the barriers pair up.
-// Within a wave the single-wave kernels' __syncthreads() become wave-local fences.
+// (channel, segment) each) and P FFT waves, FFT wave p serving IIR wave p.  Two hand-overs per tile:
+//   H1  the tile holds the band-pass output      -> the FFT wave copies it into registers
+//   H2  the copy is done                         -> the IIR wave may rectify the tile in place
+// and between H2 and the next H1 the FFT wave computes its (at most) two frames while the IIR
+// wave finishes the tile (envelope state sweep) and brings in the next one.  FLAGS: the hand-overs
+// are two monotonic counters per pair in LDS (ready / taken, one writer each, bounded polling with
+// s_sleep), so a pair never waits for another pair; otherwise they are workgroup barriers, for which
+// all waves of the grid walk the same number of iterations (tile = lo - warm + k*TILE; a segment
+// without warm-up, or without the extra extension tile, idles through the others) -- the flag
+// variant keeps that iteration space.  Within a wave the single-wave kernels' __syncthreads()
+// become wave-local fences.
 struct ChainArgs {
     CkptArgs c;
     float *psd;               // (channels, frames_out, TILE/2 + 1)
@@ -661,6 +663,7 @@ struct ChainArgs {
     long long warm_total;     // band-pass + envelope warm-up samples
     long long units;          // channels * n_seg
     int debug;                // experiments: 1 = FFT waves only copy, 2 = IIR waves skip the cascades
+                              // (bit 4, host side: workgroup barriers instead of the pairwise flags)
 };
 
 #define WAVE_SYNC()                                          \
@@ -734,7 +737,7 @@ __device__ __forceinline__ void psd_frame_2048(const v2f *lo, const v2f *hi, flo
     }
 }
 
-template <int SF, int SE, int NP>
+template <int SF, int SE, int NP, bool FLAGS>
 __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPlanDev *__restrict__ PF0,
                                                                    const SosPlanDev *__restrict__ PE0, ChainArgs a)
 {
@@ -746,10 +749,30 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
     __shared__ float rprevs[NP][64];
     __shared__ float2 fbs[NP][MP];
     __shared__ float2 tab[NTAB];
+    // FLAGS: pairwise hand-over instead of the two workgroup barriers -- ready[p] counts the tiles IIR
+    // wave p has finished, taken[p] the tiles FFT wave p has copied (monotonic, one writer each)
+    __shared__ int ready[NP], taken[NP];
+    if (threadIdx.x < NP) { ready[threadIdx.x] = 0; taken[threadIdx.x] = 0; }
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int pair = wave < NP ? wave : wave - NP;
+    // bounded polling (a logic error must not hang the GPU: after ~2^20 naps the wave moves on);
+    // macros, not lambdas: through a pointer parameter the flags would be accessed with flat
+    // instructions, whose wait also drains the prefetch of the IIR role
+#define CHAIN_WAIT_FOR(arr, want)                                                   \
+    do {                                                                            \
+        for (int spin_ = 0; spin_ < (1 << 20); spin_++) {                           \
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&arr[pair], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= (want)) break; \
+            __builtin_amdgcn_s_sleep(1);                                            \
+        }                                                                           \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");            \
+    } while (0)
+#define CHAIN_POST(arr, value)                                                      \
+    do {                                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");            \
+        if (lane == 0) __hip_atomic_store(&arr[pair], (value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    } while (0)
     {
         const float2 *src = reinterpret_cast<const float2 *>(a.tables);
         for (int i = tid; i < NTAB; i += 128 * NP) tab[i] = src[i];
@@ -851,7 +874,8 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
 #undef CASC_IN
             }
             WAVE_SYNC();
-            __syncthreads();                                   // B1: the tile holds the filtered samples
+            if (FLAGS) { if (active) CHAIN_POST(ready, it + 1); }
+            else __syncthreads();                              // B1: the tile holds the filtered samples
             if (active && tile >= lo && tile + TILE <= hi) {
                 // interior tile: exactly 8 vector stores, then the counted wait
 #pragma unroll
@@ -870,7 +894,8 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            __syncthreads();                                   // B2: the FFT wave has its copy
+            if (FLAGS) { if (active) CHAIN_WAIT_FOR(taken, it + 1); }
+            else __syncthreads();                              // B2: the FFT wave has its copy
             if (active && tile >= env_start && !(a.debug & 2)) {
                 // ---- envelope input in place: r = gain*|y|, then the odd extension past T
                 if (a.c.rectify) {
@@ -958,7 +983,8 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
         for (int it = 0; it < a.n_iter; it++) {
             const long long tile = base + (long long)it * TILE;
             const bool active = tile >= start && tile < loop_end;
-            __syncthreads();                                   // B1
+            if (FLAGS) { if (active) CHAIN_WAIT_FOR(ready, it + 1); }
+            else __syncthreads();                              // B1
             if (active) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
@@ -966,7 +992,8 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                     hi_[j] = *reinterpret_cast<const v2f *>(tlf + lds_float_index(1024 + 2 * lane + 128 * j));
                 }
             }
-            __syncthreads();                                   // B2
+            if (FLAGS) { if (active) CHAIN_POST(taken, it + 1); }   // (the release fence waits for the loads)
+            else __syncthreads();                              // B2
             if (active) {
                 const long long t = tile / TILE;
                 if (tile >= lo && tile < hi) {                 // the unit that owns the tile writes its frames
@@ -985,6 +1012,9 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
         }
     }
 }
+
+#undef CHAIN_WAIT_FOR
+#undef CHAIN_POST
 
 __global__ void zero_rows_kernel(float *__restrict__ y, long long y_pitch, long long n)
 {
@@ -1524,11 +1554,24 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
                            psd + n_valid * F, (long long)psd_pitch, n);
     }
     dim3 grid((unsigned)blocks), block(128 * P);
+    const bool flags = (ctx->chain_debug & 4) == 0;       // bit 4: workgroup barriers instead of the pairwise flags
     switch (SF * 8 + SE) {
-    case 1 * 8 + 1: hipLaunchKernelGGL((chain_fwd_kernel<1, 1, P>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a); break;
-    case 1 * 8 + 2: hipLaunchKernelGGL((chain_fwd_kernel<1, 2, P>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a); break;
-    case 2 * 8 + 1: hipLaunchKernelGGL((chain_fwd_kernel<2, 1, P>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a); break;
-    case 2 * 8 + 2: hipLaunchKernelGGL((chain_fwd_kernel<2, 2, P>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a); break;
+    case 1 * 8 + 1:
+        if (flags) hipLaunchKernelGGL((chain_fwd_kernel<1, 1, P, true>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);
+        else hipLaunchKernelGGL((chain_fwd_kernel<1, 1, P, false>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);
+        break;
+    case 1 * 8 + 2:
+        if (flags) hipLaunchKernelGGL((chain_fwd_kernel<1, 2, P, true>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);
+        else hipLaunchKernelGGL((chain_fwd_kernel<1, 2, P, false>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);
+        break;
+    case 2 * 8 + 1:
+        if (flags) hipLaunchKernelGGL((chain_fwd_kernel<2, 1, P, true>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);
+        else hipLaunchKernelGGL((chain_fwd_kernel<2, 1, P, false>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);
+        break;
+    case 2 * 8 + 2:
+        if (flags) hipLaunchKernelGGL((chain_fwd_kernel<2, 2, P, true>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);
+        else hipLaunchKernelGGL((chain_fwd_kernel<2, 2, P, false>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);
+        break;
     }
     return hd_launch_status("chain_fwd_kernel");
 }

@@ -451,9 +451,10 @@ def test_fused_filter_envelope_equals_separate_calls(oracle, T):
         hipdsp.sosfilt_envelope(c, plan, plan, dx, T, dx, T, dx, T, C, 9)
 
 
+@pytest.mark.parametrize('handover', [0, 4])
 @pytest.mark.parametrize('T,max_segments', [(8192, 0), (20480, 0), (70001, 0), (300000, 0), (300000, 3),
                                             (1500000, 0), (1500000, 1)])
-def test_chain_forward_equals_separate_calls(oracle, T, max_segments):
+def test_chain_forward_equals_separate_calls(oracle, T, max_segments, handover):
     """hipdsp_chain_forward (band-pass + envelope state sweep + spectrogram 2048/1024 in one pass) and
     the backward sweep after it, against the separate calls and the oracle: one and many segments
     (frames that straddle a segment border), traces that end inside a tile, zero tail."""
@@ -464,6 +465,7 @@ def test_chain_forward_equals_separate_calls(oracle, T, max_segments):
     x = (synth(rng, T, C, rate) + np.float32(0.05)).astype(np.float32)
     c = gh.ctx()
     c.set_max_segments(max_segments)
+    c.set_option('chain_debug', handover)      # 0: pairwise flags in LDS, 4: workgroup barriers
     try:
         dx = gh.to_planar(c, x)
         nd = (T + hop - 1)//hop
@@ -518,3 +520,4 @@ def test_chain_forward_equals_separate_calls(oracle, T, max_segments):
             hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, 1024, 512, rate, ps, nd)
     finally:
         c.set_max_segments(0)
+        c.set_option('chain_debug', 0)
