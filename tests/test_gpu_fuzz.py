@@ -249,3 +249,65 @@ def test_bad_arguments_are_refused_not_launched():
     c.synchronize()                                     # the context is still healthy
     hipdsp.sosfilt(c, plan, x, 5000, y, 5000, 2, 5000, 0)
     assert np.all(y.to_host() == 0)
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_random_chain_forward_cases(oracle, seed):
+    """hipdsp_chain_forward + backward sweep under random trace lengths (around tile multiples),
+    channel counts, pitches, segmentations, one- and two-section plans: everything against the
+    oracle, the PSD also against the separate spectrogram call on the same filtered trace."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rng = np.random.default_rng(7000 + seed)
+    rate = float(rng.choice([44100.0, 96000.0, 192000.0]))
+    nfft, hop = 2048, 1024
+    F = nfft//2 + 1
+    T = int(rng.integers(4, 60))*TILE + int(rng.integers(-TILE + 1, TILE)) if rng.integers(0, 3) else \
+        int(rng.integers(4*TILE, 6*TILE))
+    T = max(T, 4*TILE)
+    C = int(rng.integers(1, 7))
+    lo = float(rng.uniform(50.0, 0.05*rate))
+    sos = butter_sos(int(rng.integers(1, 3)), (lo, float(rng.uniform(2*lo, 0.4*rate))), 'bandpass', rate)
+    esos = butter_sos(int(rng.integers(1, 5)), float(rng.uniform(5.0, 2000.0)), 'lowpass', rate)
+    xp, fp = T + int(rng.integers(0, 9)), T + int(rng.integers(0, 9))
+    nd = (T + hop - 1)//hop + int(rng.integers(-3, 4))
+    pp = (nd + int(rng.integers(0, 3)))*F
+    x = (rng.standard_normal((C, T))*rng.uniform(0.1, 3.0) + 0.1).astype(np.float32)
+    c = gh.ctx()
+    c.set_max_segments(int(rng.choice([0, 0, 1, 2, 5])))
+    c.set_option('chain_debug', int(rng.choice([0, 4])))
+    try:
+        host = np.zeros((C, xp), dtype=np.float32)
+        host[:, :T] = x
+        dx = hipdsp.DeviceArray(c, (C, xp), np.float32)
+        hipdsp.lib.hipdsp_memcpy_h2d(c.handle, hipdsp._p(dx), host.ctypes.data, host.nbytes)
+        yf = hipdsp.DeviceArray(c, (C, fp), np.float32)
+        ye = hipdsp.DeviceArray(c, (C, T), np.float32)
+        ps = hipdsp.DeviceArray(c, (C*pp,), np.float32)
+        hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(ps), 0x7f, 4*C*pp)
+        fplan, eplan = hipdsp.SosPlan(c, sos), hipdsp.SosPlan(c, esos)
+        hipdsp.chain_forward(c, fplan, eplan, dx, xp, yf, fp, C, T, nfft, hop, rate, ps, nd, psd_pitch=pp)
+        hipdsp.sosfilt_envelope(c, fplan, eplan, dx, xp, yf, fp, ye, T, C, T, phase=2)
+        s1 = hipdsp.DeviceArray(c, (C*pp,), np.float32)
+        hipdsp.spectrogram(c, yf, fp, C, T, nfft, hop, rate, s1, nd, out_pitch=pp)
+        gf = yf.to_host()[:, :T]
+        ge = ye.to_host()
+        gs = ps.to_host().reshape(C, pp)[:, :nd*F].reshape(C, nd, F)
+        ss = s1.to_host().reshape(C, pp)[:, :nd*F].reshape(C, nd, F)
+        guard = np.frombuffer(b'\x7f\x7f\x7f\x7f', dtype=np.float32)[0]
+        assert np.all(ps.to_host().reshape(C, pp)[:, nd*F:] == guard)
+        want_f = oracle.sosfilt(sos, x.T.astype(np.float64))
+        want_e = np.zeros_like(want_f)
+        oracle.envelope_process(esos, gf.T.astype(np.float64), want_e, 0)
+        for ch in range(C):
+            assert rel_err(gf[ch], want_f[:, ch]) < TOL, (seed, ch)
+            assert rel_err(ge[ch], want_e[:, ch]) < TOL, (seed, ch)
+            for j in range(nd):
+                peak = np.max(np.abs(ss[ch, j]))
+                if peak == 0:
+                    assert np.all(gs[ch, j] == 0), (seed, j, ch)
+                else:
+                    assert np.max(np.abs(gs[ch, j] - ss[ch, j]))/peak < 1e-5, (seed, T, j, ch)
+    finally:
+        c.set_max_segments(0)
+        c.set_option('chain_debug', 0)
