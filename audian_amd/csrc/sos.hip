@@ -655,6 +655,7 @@ __global__ void copy_skip_kernel(const float *__restrict__ x, long long x_pitch,
 struct ChainArgs {
     CkptArgs c;
     float *psd;               // (channels, frames_out, TILE/2 + 1)
+    float *db;                // optional: decibel(psd), same layout
     long long psd_pitch;
     long long n_valid;        // frames that lie inside the trace
     const float *tables;      // tw2 | tw3 | twn | window of the 2048-point PSD kernel (fft_tables)
@@ -675,9 +676,10 @@ struct ChainArgs {
 // One 2048-sample frame from its two register halves (lo: samples 2l + 128 t, t < 8; hi: the
 // same 1024 samples later) -> detrend, Hann, half-length complex FFT 16 x 16 x 4, split step, PSD.
 // Same arithmetic as spec_fast_kernel<2048, 64, 16, 16, 4, ...>.
+template <bool DB>
 __device__ __forceinline__ void psd_frame_2048(const v2f *lo, const v2f *hi, float2 *fb, const float2 *tw2,
                                                const float2 *tw3, const float2 *twn, const float2 *win, int l,
-                                               float scale, float *__restrict__ o)
+                                               float scale, float *__restrict__ o, float *__restrict__ od)
 {
     constexpr int NFFT = 2048, M = 1024, LPF = 64, PPL = 16, R1 = 16, R2 = 16, R3 = 4;
     float2 v[PPL];
@@ -726,6 +728,7 @@ __device__ __forceinline__ void psd_frame_2048(const v2f *lo, const v2f *hi, flo
         }
         o[k] = pk;
         o[M - k] = pm;
+        if (DB) { od[k] = to_db(pk); od[M - k] = to_db(pm); }
         pk_last = pk;
     }
     {
@@ -733,11 +736,13 @@ __device__ __forceinline__ void psd_frame_2048(const v2f *lo, const v2f *hi, flo
         const float2 z = v[(mh % NB3) * R3 + mh / NB3];
         const float ph = 2.f * scale * (z.x * z.x + z.y * z.y);
         const int kk = (l == 0) ? M / 2 : l + LPF * (PPL / 2 - 1);
-        o[kk] = (l == 0) ? ph : pk_last;
+        const float pv = (l == 0) ? ph : pk_last;
+        o[kk] = pv;
+        if (DB) od[kk] = to_db(pv);
     }
 }
 
-template <int SF, int SE, int NP, bool FLAGS>
+template <int SF, int SE, int NP, bool FLAGS, bool DB>
 __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPlanDev *__restrict__ PF0,
                                                                    const SosPlanDev *__restrict__ PE0, ChainArgs a)
 {
@@ -976,6 +981,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
         const float *tlf = reinterpret_cast<const float *>(tiles[pair]);
         const float2 *tw2 = tab, *tw3 = tab + TW2, *twn = tab + TW2 + TW3, *win = tab + TW2 + TW3 + TWN;
         float *oc = a.psd + ch * a.psd_pitch;
+        float *dc = DB ? a.db + ch * a.psd_pitch : nullptr;
         v2f lo_[8], hi_[8], hp_[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) { lo_[j] = (v2f){0.f, 0.f}; hi_[j] = (v2f){0.f, 0.f}; hp_[j] = (v2f){0.f, 0.f}; }
@@ -1000,9 +1006,11 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                     const long long f1 = 2 * t - 1;
                   if (!(a.debug & 1)) {
                     if (have_prev && f1 >= 0 && f1 < a.n_valid)
-                        psd_frame_2048(hp_, lo_, fb, tw2, tw3, twn, win, lane, a.scale, oc + f1 * (long long)F);
+                        psd_frame_2048<DB>(hp_, lo_, fb, tw2, tw3, twn, win, lane, a.scale, oc + f1 * (long long)F,
+                                           dc + f1 * (long long)F);
                     if (2 * t < a.n_valid)
-                        psd_frame_2048(lo_, hi_, fb, tw2, tw3, twn, win, lane, a.scale, oc + 2 * t * (long long)F);
+                        psd_frame_2048<DB>(lo_, hi_, fb, tw2, tw3, twn, win, lane, a.scale, oc + 2 * t * (long long)F,
+                                           dc + 2 * t * (long long)F);
                   } else if (f1 == -12345) oc[lane] = lo_[0].x + hi_[1].y + hp_[2].x;
                 }
 #pragma unroll
@@ -1016,13 +1024,13 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
 #undef CHAIN_WAIT_FOR
 #undef CHAIN_POST
 
-__global__ void zero_rows_kernel(float *__restrict__ y, long long y_pitch, long long n)
+__global__ void zero_rows_kernel(float *__restrict__ y, long long y_pitch, long long n, float value)
 {
     long long ch = blockIdx.y;
     float *yo = y + ch * y_pitch;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x)
-        yo[i] = 0.f;
+        yo[i] = value;
 }
 
 // ---- host-side plan mathematics (float64) -----------------------------------
@@ -1491,7 +1499,7 @@ int hipdsp_sosfilt_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const 
 int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hipdsp_sosplan *eplan,
                          const float *x, int64_t x_pitch, float *yf, int64_t yf_pitch, int64_t channels,
                          int64_t frames, int rectify, double gain, int nfft, int hop, double fs, float *psd,
-                         int64_t frames_out, int64_t psd_pitch)
+                         float *db_out, int64_t frames_out, int64_t psd_pitch)
 {
     HD_REQUIRE(ctx != nullptr && fplan != nullptr && eplan != nullptr, "NULL argument");
     HD_REQUIRE(channels >= 0 && frames >= 0 && frames_out >= 0, "negative size");
@@ -1536,7 +1544,7 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     a.c.in = x; a.c.yf = yf; a.c.ckpt = (double *)work;
     a.c.in_pitch = x_pitch; a.c.yf_pitch = yf_pitch; a.c.ckpt_pitch = ckpt_pitch;
     a.c.T = frames; a.c.edge = edge; a.c.rectify = rectify; a.c.gain = (float)gain;
-    a.psd = psd; a.psd_pitch = psd_pitch; a.n_valid = n_valid;
+    a.psd = psd; a.db = db_out; a.psd_pitch = psd_pitch; a.n_valid = n_valid;
     a.scale = (float)(1.0 / (fs * wss));
     a.warm_total = fplan->host->warm + eplan->host->warm;
     a.debug = ctx->chain_debug;
@@ -1551,28 +1559,27 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
         const long long n = (frames_out - n_valid) * F;
         unsigned gx = (unsigned)((n + 1023) / 1024 > 4096 ? 4096 : (n + 1023) / 1024);
         hipLaunchKernelGGL(zero_rows_kernel, dim3(gx, (unsigned)channels), dim3(256), 0, ctx->stream,
-                           psd + n_valid * F, (long long)psd_pitch, n);
+                           psd + n_valid * F, (long long)psd_pitch, n, 0.f);
+        if (db_out)
+            hipLaunchKernelGGL(zero_rows_kernel, dim3(gx, (unsigned)channels), dim3(256), 0, ctx->stream,
+                               db_out + n_valid * F, (long long)psd_pitch, n, -INFINITY);
     }
     dim3 grid((unsigned)blocks), block(128 * P);
     const bool flags = (ctx->chain_debug & 4) == 0;       // bit 4: workgroup barriers instead of the pairwise flags
+#define HD_CHAIN(A, B)                                                                                              \
+    case (A) * 8 + (B):                                                                                            \
+        if (db_out) {                                                                                              \
+            if (flags) hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, true>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);  \
+            else hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, false, true>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);       \
+        } else {                                                                                                   \
+            if (flags) hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, false>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a); \
+            else hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, false, false>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);      \
+        }                                                                                                          \
+        break
     switch (SF * 8 + SE) {
-    case 1 * 8 + 1:
-        if (flags) hipLaunchKernelGGL((chain_fwd_kernel<1, 1, P, true>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);
-        else hipLaunchKernelGGL((chain_fwd_kernel<1, 1, P, false>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);
-        break;
-    case 1 * 8 + 2:
-        if (flags) hipLaunchKernelGGL((chain_fwd_kernel<1, 2, P, true>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);
-        else hipLaunchKernelGGL((chain_fwd_kernel<1, 2, P, false>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);
-        break;
-    case 2 * 8 + 1:
-        if (flags) hipLaunchKernelGGL((chain_fwd_kernel<2, 1, P, true>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);
-        else hipLaunchKernelGGL((chain_fwd_kernel<2, 1, P, false>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);
-        break;
-    case 2 * 8 + 2:
-        if (flags) hipLaunchKernelGGL((chain_fwd_kernel<2, 2, P, true>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);
-        else hipLaunchKernelGGL((chain_fwd_kernel<2, 2, P, false>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);
-        break;
+        HD_CHAIN(1, 1); HD_CHAIN(1, 2); HD_CHAIN(2, 1); HD_CHAIN(2, 2);
     }
+#undef HD_CHAIN
     return hd_launch_status("chain_fwd_kernel");
 }
 
@@ -1591,7 +1598,7 @@ int hipdsp_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const float *x,
         HD_REQUIRE(y != nullptr && y_pitch >= n, "bad output");
         unsigned gx = (unsigned)((n + 1023) / 1024 > 4096 ? 4096 : (n + 1023) / 1024);
         hipLaunchKernelGGL(zero_rows_kernel, dim3(gx, (unsigned)channels), dim3(256), 0, ctx->stream, y,
-                           (long long)y_pitch, n);
+                           (long long)y_pitch, n, 0.f);
         return hd_launch_status("zero_rows_kernel");
     }
     HD_REQUIRE(plan->host->n_sections > 0, "plan has no coefficients");

@@ -236,12 +236,12 @@ int hipdsp_sosfilt_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan,
  * equal hipdsp_sosfilt_envelope(phase 1) + hipdsp_spectrogram up to float32 rounding of the
  * frames that straddle an internal segment border.
  * Covers nfft 2048 / hop 1024, plans of one or two decaying sections and frames >= 8192;
- * anything else returns HIPDSP_ERR_UNSUPPORTED (use the separate calls).  psd layout and the
- * zero tail as in hipdsp_spectrogram. */
+ * anything else returns HIPDSP_ERR_UNSUPPORTED (use the separate calls).  psd layout, the optional
+ * db_out (decibel(psd), fused epilogue) and the zero tail as in hipdsp_spectrogram. */
 int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan,
                          const hipdsp_sosplan *eplan, const float *x, int64_t x_pitch, float *yf,
                          int64_t yf_pitch, int64_t channels, int64_t frames, int rectify,
-                         double gain, int nfft, int hop, double fs, float *psd,
+                         double gain, int nfft, int hop, double fs, float *psd, float *db_out,
                          int64_t frames_out, int64_t psd_pitch);
 
 /* BufferedSpectrogram.process (bufferedspectrogram.py:45-59) ==

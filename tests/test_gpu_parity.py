@@ -509,13 +509,20 @@ def test_chain_forward_equals_separate_calls(oracle, T, max_segments, handover):
             pitch = (nf + 3)*F
             big = hipdsp.DeviceArray(c, (C, nf + 3, F), np.float32)
             hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(big), 0x7f, 4*C*pitch)
-            hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, nfft, hop, rate, big, nf, psd_pitch=pitch)
-            got = big.to_host()
+            bigdb = hipdsp.DeviceArray(c, (C, nf + 3, F), np.float32)
+            hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(bigdb), 0x7f, 4*C*pitch)
+            hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, nfft, hop, rate, big, nf, psd_pitch=pitch,
+                                 db_out=bigdb)
+            got, gdb = big.to_host(), bigdb.to_host()
             guard = np.frombuffer(b'\x7f\x7f\x7f\x7f', dtype=np.float32)[0]
-            assert np.all(got[:, nf:, :] == guard)
+            assert np.all(got[:, nf:, :] == guard) and np.all(gdb[:, nf:, :] == guard)
             m = min(nf, nd)
             assert np.array_equal(got[:, :m, :], gs[:, :m, :])
-            assert np.all(got[:, nd:nf, :] == 0)
+            assert np.all(got[:, nd:nf, :] == 0) and np.all(gdb[:, nd:nf, :] == -np.inf)
+            want_db = oracle.decibel(got[:, :nf, :])             # the fused dB epilogue (specitem.py:36)
+            fin = np.isfinite(want_db)
+            assert np.array_equal(np.isfinite(gdb[:, :nf, :]), fin)
+            assert np.max(np.abs(gdb[:, :nf, :][fin] - want_db[fin])) < 1e-3
         with pytest.raises(NotImplementedError):
             hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, 1024, 512, rate, ps, nd)
     finally:

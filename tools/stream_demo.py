@@ -21,11 +21,18 @@ db = hipdsp.DeviceArray(ctx, (C, nd, nfft//2 + 1), np.float32)
 plan = hipdsp.SosPlan(ctx, butter_sos(2, (100.0, 20000.0), 'bandpass', rate))
 eplan = hipdsp.SosPlan(ctx, butter_sos(2, 500.0, 'lowpass', rate))
 
+FUSED = os.environ.get('FUSED', '1') != '0'      # hipdsp_chain_forward + backward sweep (2 launches)
+
+
 def chain():
     plan.upload()
-    hipdsp.sosfilt(ctx, plan, dx, T, df, T, C, T, 0)
-    hipdsp.spectrogram(ctx, df, T, C, T, nfft, hop, rate, ds, nd, db_out=db)
-    hipdsp.envelope(ctx, eplan, df, T, de, T, C, T, 0)
+    if FUSED:
+        hipdsp.chain_forward(ctx, plan, eplan, dx, T, df, T, C, T, nfft, hop, rate, ds, nd, db_out=db)
+        hipdsp.sosfilt_envelope(ctx, plan, eplan, dx, T, df, T, de, T, C, T, phase=2)
+    else:
+        hipdsp.sosfilt(ctx, plan, dx, T, df, T, C, T, 0)
+        hipdsp.spectrogram(ctx, df, T, C, T, nfft, hop, rate, ds, nd, db_out=db)
+        hipdsp.envelope(ctx, eplan, df, T, de, T, C, T, 0)
 
 chain(); ctx.synchronize()
 ctx.graph_begin(); chain(); graph = ctx.graph_end()
@@ -61,9 +68,13 @@ def live(k):
     hipdsp.memcpy2d(ctx, dst, 4*T, src.view(chunk, (1,)), 4*T, 4*(T - chunk), C)          # slide
     hipdsp.pcm_unpack(ctx, staging, 2, chunk, C, 1.0/32768, dst.view(T - chunk, (1,)), T)   # append
     plan.upload()
-    hipdsp.sosfilt(ctx, plan, dst, T, df, T, C, T, 0)
-    hipdsp.spectrogram(ctx, df, T, C, T, nfft, hop, rate, ds, nd, db_out=db)
-    hipdsp.envelope(ctx, eplan, df, T, de, T, C, T, 0)
+    if FUSED:
+        hipdsp.chain_forward(ctx, plan, eplan, dst, T, df, T, C, T, nfft, hop, rate, ds, nd, db_out=db)
+        hipdsp.sosfilt_envelope(ctx, plan, eplan, dst, T, df, T, de, T, C, T, phase=2)
+    else:
+        hipdsp.sosfilt(ctx, plan, dst, T, df, T, C, T, 0)
+        hipdsp.spectrogram(ctx, df, T, C, T, nfft, hop, rate, ds, nd, db_out=db)
+        hipdsp.envelope(ctx, eplan, df, T, de, T, C, T, 0)
 
 
 graphs = []
