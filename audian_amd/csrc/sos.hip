@@ -762,12 +762,13 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int pair = wave < NP ? wave : wave - NP;
-    // bounded polling (a logic error must not hang the GPU: after ~2^20 naps the wave moves on);
+    // bounded polling (a logic error must not hang the GPU: after 2^23 naps, a third of a second, the wave moves
+    // on -- far beyond anything a partner wave of the same workgroup can be late by);
     // macros, not lambdas: through a pointer parameter the flags would be accessed with flat
     // instructions, whose wait also drains the prefetch of the IIR role
 #define CHAIN_WAIT_FOR(arr, want)                                                   \
     do {                                                                            \
-        for (int spin_ = 0; spin_ < (1 << 20); spin_++) {                           \
+        for (int spin_ = 0; spin_ < (1 << 23); spin_++) {                           \
             if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&arr[pair], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= (want)) break; \
             __builtin_amdgcn_s_sleep(1);                                            \
         }                                                                           \
