@@ -804,6 +804,9 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
     if (!unit_ok) loop_end = start;                     // a pair without a unit only takes the barriers
     const long long base = lo - a.warm_total;           // tile of iteration 0 (negative: idle iterations)
 
+    // "chain_debug" bit 16: IIR wave 0 of workgroup 0 reports shader clocks and 100 MHz ticks spent in
+    // the kernel into the first 16 bytes of the PSD (measurement of the engine clock under this load)
+    const long long dbg_c0 = (a.debug & 16) ? clock64() : 0, dbg_w0 = (a.debug & 16) ? wall_clock64() : 0;
     if (wave < NP) {
         // ================= IIR role: sos_ckpt_kernel<SF, SE, true> with the barriers added ==========
         float4 *lds = tiles[pair];
@@ -976,6 +979,11 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last (dummy) prefetch
+        if ((a.debug & 16) && blockIdx.x == 0 && wave == 0 && lane == 0) {
+            long long *dbg = reinterpret_cast<long long *>(a.psd);
+            dbg[0] = clock64() - dbg_c0;
+            dbg[1] = wall_clock64() - dbg_w0;
+        }
     } else {
         // ================= FFT role ===================================================================
         float2 *fb = fbs[pair];

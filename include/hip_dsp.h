@@ -71,7 +71,8 @@ int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
  *   "spec_no_half"       non-zero: do not reuse the overlapped half frame at 50 % overlap
  *   "chain_debug"        measurements only (results become wrong): 1 = the FFT waves of
  *                        hipdsp_chain_forward only copy their tiles, 2 = its IIR waves skip the cascades;
- *                        4 (results unchanged) = workgroup barriers instead of pairwise LDS flags */
+ *                        4 (results unchanged) = workgroup barriers instead of pairwise LDS flags;
+ *                        16 = clock counters of one wave into the first 16 bytes of the PSD */
 int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value);
 /* Pre-size the internal scratch (envelope state checkpoints: 16 * n_sections bytes per
  * 2048-sample tile and channel; four-step FFT work area) so that later calls do not

@@ -48,6 +48,13 @@ if os.environ.get('ABLATE'):
         ctx.set_option('chain_debug', bits)
         print(f'fused, debug bits {bits} (1: FFT waves only copy, 2: IIR waves without cascades): {timed(fused):.3f} ms', flush=True)
 ctx.set_option('chain_debug', int(os.environ.get('CHAIN_DEBUG', '0')))
+if os.environ.get('CLOCK'):
+    ctx.set_option('chain_debug', 16)
+    fused(); fused(); ctx.synchronize()
+    raw = ds.view(0, (4,)).to_host().view(np.int64)
+    print(f'engine clock during the fused kernel: {raw[0]/(raw[1]/100e6)/1e6:.0f} MHz '
+          f'({raw[0]} shader clocks in {raw[1]/100e3:.3f} ms)', flush=True)
+    ctx.set_option('chain_debug', 0)
 s = timed(separate)
 print(f'separate forward sweep + spectrogram: {s:.3f} ms', flush=True)
 f = timed(fused)
