@@ -27,6 +27,82 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 }
 __device__ __forceinline__ float2 mul_negi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f as_v2f(float2 a) { v2f r = {a.x, a.y}; return r; }
+__device__ __forceinline__ float2 as_f2(v2f a) { return make_float2(a.x, a.y); }
+
+// In-register DFTs in explicit packed fp32: a complex value is one aligned register pair, an
+// addition one v_pk_add_f32, and the rotations by -i / +i ride on the op_sel / neg modifiers of the
+// addition that consumes them (written with scalar float2 arithmetic, hipcc's SLP vectoriser found
+// the packed adds too, but paid for them with ~25 register moves per 16-point transform).
+__device__ __forceinline__ v2f pk_add_negi(v2f a, v2f b)      // a + (-i) b = (ax + by, ay - bx)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_sub_negi(v2f a, v2f b)      // a - (-i) b = (ax - by, ay + bx)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a * (c - i s) for a constant twiddle: c a + s (-i a) = (c ax + s ay, c ay - s ax)
+__device__ __forceinline__ v2f pk_rot(v2f a, float c, float sn)
+{
+    const v2f cc = {c, c}, ss = {sn, sn};
+    v2f t = a * cc, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(ss), "v"(t));
+    return r;
+}
+
+__device__ __forceinline__ void dft4p(v2f &v0, v2f &v1, v2f &v2, v2f &v3)
+{
+    const v2f t0 = v0 + v2, t1 = v0 - v2, t2 = v1 + v3, d = v1 - v3;
+    v0 = t0 + t2; v2 = t0 - t2;
+    v1 = pk_add_negi(t1, d); v3 = pk_sub_negi(t1, d);
+}
+
+__device__ __forceinline__ void dft8p(v2f *v)                 // in place, natural order
+{
+    const float h = 0.70710678118654752440f;
+    const v2f hh = {h, h};
+    v2f e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    dft4p(e0, e1, e2, e3);
+    dft4p(o0, o1, o2, o3);
+    const v2f p1 = pk_add_negi(o1, o1) * hh;                  // o1 * W8^1 = h (o1 + (-i) o1)
+    const v2f p3 = pk_sub_negi(o3, o3) * hh;                  // o3 * W8^3 = -h (o3 - (-i) o3)
+    v[0] = e0 + o0; v[4] = e0 - o0;
+    v[1] = e1 + p1; v[5] = e1 - p1;
+    v[2] = pk_add_negi(e2, o2); v[6] = pk_sub_negi(e2, o2);   // o2 * W8^2 = -i o2
+    v[3] = e3 - p3; v[7] = e3 + p3;
+}
+
+__device__ __forceinline__ void dft16p(v2f *v)
+{
+    const float h = 0.70710678118654752440f;
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;   // cos, sin(pi/8)
+    const v2f hh = {h, h};
+    v2f e[8], o[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { e[k] = v[2 * k]; o[k] = v[2 * k + 1]; }
+    dft8p(e); dft8p(o);
+    const v2f q1 = pk_rot(o[1], c1, s1);                      // W16^1 = c1 - i s1
+    const v2f q2 = pk_add_negi(o[2], o[2]) * hh;              // W16^2 = W8^1
+    const v2f q3 = pk_rot(o[3], s1, c1);                      // W16^3 = s1 - i c1
+    const v2f q5 = pk_rot(o[5], -s1, c1);                     // W16^5 = -s1 - i c1
+    const v2f q6 = pk_sub_negi(o[6], o[6]) * hh;              // W16^6 = W8^3 = -h (1 + i): subtract below
+    const v2f q7 = pk_rot(o[7], -c1, s1);                     // W16^7 = -c1 - i s1
+    v[0] = e[0] + o[0]; v[8] = e[0] - o[0];
+    v[1] = e[1] + q1;   v[9] = e[1] - q1;
+    v[2] = e[2] + q2;   v[10] = e[2] - q2;
+    v[3] = e[3] + q3;   v[11] = e[3] - q3;
+    v[4] = pk_add_negi(e[4], o[4]); v[12] = pk_sub_negi(e[4], o[4]);   // W16^4 = -i
+    v[5] = e[5] + q5;   v[13] = e[5] - q5;
+    v[6] = e[6] - q6;   v[14] = e[6] + q6;
+    v[7] = e[7] + q7;   v[15] = e[7] - q7;
+}
+
 template <int R> __device__ __forceinline__ void dft(float2 *v);
 
 template <> __device__ __forceinline__ void dft<2>(float2 *v)
@@ -37,41 +113,29 @@ template <> __device__ __forceinline__ void dft<2>(float2 *v)
 
 template <> __device__ __forceinline__ void dft<4>(float2 *v)
 {
-    float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
-    float2 t2 = cadd(v[1], v[3]), t3 = mul_negi(csub(v[1], v[3]));
-    v[0] = cadd(t0, t2); v[2] = csub(t0, t2);
-    v[1] = cadd(t1, t3); v[3] = csub(t1, t3);
+    v2f a = as_v2f(v[0]), b = as_v2f(v[1]), c = as_v2f(v[2]), d = as_v2f(v[3]);
+    dft4p(a, b, c, d);
+    v[0] = as_f2(a); v[1] = as_f2(b); v[2] = as_f2(c); v[3] = as_f2(d);
 }
 
 template <> __device__ __forceinline__ void dft<8>(float2 *v)
 {
-    const float h = 0.70710678118654752440f;
-    float2 e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
-    dft<4>(e); dft<4>(o);
-    o[1] = make_float2((o[1].x + o[1].y) * h, (o[1].y - o[1].x) * h);      // * W8^1
-    o[2] = mul_negi(o[2]);                                                // * W8^2
-    o[3] = make_float2((o[3].y - o[3].x) * h, -(o[3].x + o[3].y) * h);     // * W8^3
+    v2f t[8];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { v[k] = cadd(e[k], o[k]); v[k + 4] = csub(e[k], o[k]); }
+    for (int k = 0; k < 8; k++) t[k] = as_v2f(v[k]);
+    dft8p(t);
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = as_f2(t[k]);
 }
 
 template <> __device__ __forceinline__ void dft<16>(float2 *v)
 {
-    const float h = 0.70710678118654752440f;
-    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;   // cos, sin(pi/8)
-    float2 e[8], o[8];
+    v2f t[16];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { e[k] = v[2 * k]; o[k] = v[2 * k + 1]; }
-    dft<8>(e); dft<8>(o);
-    o[1] = cmul(o[1], make_float2(c1, -s1));
-    o[2] = make_float2((o[2].x + o[2].y) * h, (o[2].y - o[2].x) * h);
-    o[3] = cmul(o[3], make_float2(s1, -c1));
-    o[4] = mul_negi(o[4]);
-    o[5] = cmul(o[5], make_float2(-s1, -c1));
-    o[6] = make_float2((o[6].y - o[6].x) * h, -(o[6].x + o[6].y) * h);
-    o[7] = cmul(o[7], make_float2(-c1, -s1));
+    for (int k = 0; k < 16; k++) t[k] = as_v2f(v[k]);
+    dft16p(t);
 #pragma unroll
-    for (int k = 0; k < 8; k++) { v[k] = cadd(e[k], o[k]); v[k + 8] = csub(e[k], o[k]); }
+    for (int k = 0; k < 16; k++) v[k] = as_f2(t[k]);
 }
 
 __device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
@@ -97,14 +161,10 @@ __device__ __forceinline__ float wave_sum(float v)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-typedef float v2f __attribute__((ext_vector_type(2)));
-
 // Packed-fp32 complex helpers (v_pk_*_f32 computes two lanes per instruction; op_sel picks the
 // low/high dword of a source pair for the low lane, op_sel_hi for the high lane, neg_lo/neg_hi
 // negate a source per lane).  hipcc's SLP vectoriser finds the packed form inside the small
 // in-register DFTs but not across the twiddle tables and the split step of the big kernel.
-__device__ __forceinline__ v2f as_v2f(float2 a) { v2f r = {a.x, a.y}; return r; }
-__device__ __forceinline__ float2 as_f2(v2f a) { return make_float2(a.x, a.y); }
 // a * b: same roundings as cmul() (product, then fma)
 __device__ __forceinline__ v2f pk_cmul(v2f a, v2f b)
 {
