@@ -21,7 +21,7 @@ def short(name):
     m = re.search(r'sos_ckpt_kernel<(\d), (\d)(?:, \w+)?>', name)
     if m:
         return ('sos_ckpt<S=%s+%s,filt+env_state>' if m.group(1) != '0' else 'sos_ckpt<S=%s+%s,env_state>') % m.groups()
-    m = re.search(r'chain_fwd_kernel<(\d), (\d), \d+(?:, \w+)?>', name)
+    m = re.search(r'chain_fwd_kernel<(\d), (\d), \d+(?:, \w+)*>', name)
     if m:
         return 'chain_fwd<S=%s+%s,filt+env_state+psd>' % m.groups()
     m = re.search(r'env_bwd_kernel<(\d)(?:, \w+)?>', name)
