@@ -67,11 +67,11 @@ def parse():
                     help='spectrogram on the main stream instead of a second stream next to the '
                          'envelope backward sweep')
     ap.add_argument('--no-fuse-spectrogram', action='store_true',
-                    help='N = 1 runs band-pass + envelope state sweep + spectrogram as ONE launch '
+                    help='by default band-pass + envelope state sweep + spectrogram run as ONE launch '
                          '(hipdsp_chain_forward: FFT waves take the filtered tiles from LDS, 20 instead of '
                          '24 B/sample for the step) whenever the shape allows it (nfft 2048 / hop 1024, plans of '
-                         '<= 2 sections); this flag keeps the separate launches.  N > 1 always uses them: the '
-                         'fused kernel wants a whole CU per workgroup, which RCCL\'s resident kernels deny')
+                         '<= 2 sections); this flag keeps the separate launches.  At N > 1 the fused kernel, which '
+                         'wants a whole CU per workgroup, waits for the previous all-gather to leave the device')
     ap.add_argument('--force-dist', action='store_true',
                     help='rehearsal: take the multi-rank code path even with one rank')
     return ap.parse_args()
@@ -206,7 +206,7 @@ def main():
     if args.max_segments:
         ctx.set_max_segments(args.max_segments)
     # The spectrogram and the envelope backward sweep both only read the filtered trace: they run next to each other on two streams, ordered by events.
-    fuse3 = (not args.no_fuse_spectrogram and not args.no_fuse and not (world > 1 or args.force_dist)
+    fuse3 = (not args.no_fuse_spectrogram and not args.no_fuse
              and args.nfft == 2048 and args.hop == 1024 and args.order <= 2
              and args.seconds*args.rate >= 8192)
     overlap = not args.no_overlap and not fuse3      # nothing left to run next to the backward sweep
@@ -274,6 +274,15 @@ def main():
         ev = events[i] if i >= 0 else None
         if ev:
             ctx.record(ev[0])
+        if fuse3 and multi:
+            # the fused forward sweep wants every CU to itself (one 1024-thread workgroup per CU):
+            # it starts only when the previous step's all-gather has left the device, so that gather
+            # overlaps the backward sweep of its own step and nothing else
+            with torch.cuda.stream(cstream):
+                for b in range(2):
+                    if works[b] is not None:
+                        works[b].wait()
+                        works[b] = None
         if fuse3:
             hipdsp.chain_forward(ctx, plan, eplan, dx, T, df, T, C, T, args.nfft, args.hop, args.rate, ds, nd,
                                  rectify=True, gain=np.pi/2)
@@ -458,8 +467,10 @@ def main():
                             f'+ envelope {args.env:g} Hz',
                 'channels_per_gpu': C, 'frames': T, 'spectrogram_frames': nd,
                 'parallelism': f'channel shard x{world}' +
-                               (f', pipelined all-gather of the {args.tile_seconds:g} s spectrogram tile '
-                                f'({4*C*tile_frames*F/1e9:.2f} GB per rank)' if multi else ''),
+                               (f', all-gather of the {args.tile_seconds:g} s spectrogram tile '
+                                f'({4*C*tile_frames*F/1e9:.2f} GB per rank) under the ' +
+                                ('backward sweep of its step' if fuse3 else 'kernels of this and the next step')
+                                if multi else ''),
                 'iir_warmup_samples': {'bandpass': warm_f, 'envelope': warm_e},
                 'streams': ('spectrogram on a second stream next to the envelope backward sweep '
                             '(their event-bracketed times overlap)' if overlap else 'one stream'),
