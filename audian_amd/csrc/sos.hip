@@ -823,6 +823,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
         rprev[lane] = 0.f;
         v4f nx[8];
         bool pre = false;
+        int pending = 0;
         const long long top_full = (T / TILE - 1) * TILE;            // host guarantees >= 0
         auto fetch = [&](long long t0) {
 #pragma unroll
@@ -837,6 +838,10 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
         for (int it = 0; it < a.n_iter; it++) {
             const long long tile = base + (long long)it * TILE;
             const bool active = tile >= start && tile < loop_end;
+            if (FLAGS && pending) {                            // H2 of the previous (quiet) tile
+                CHAIN_WAIT_FOR(taken, pending);
+                pending = 0;
+            }
             if (active) {
                 if (pre) {
 #pragma unroll
@@ -903,9 +908,40 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            if (FLAGS) { if (active) CHAIN_WAIT_FOR(taken, it + 1); }
-            else __syncthreads();                              // B2: the FFT wave has its copy
-            if (active && tile >= env_start && !(a.debug & 2)) {
+            // An interior tile of the envelope sweep (neither it nor the next one touches T, no left
+            // extension) is not modified any more: the rectification rides on the cascade's input
+            // and, with the flags, H2 is only needed before the NEXT tile goes into LDS.
+            const bool quiet = active && tile >= env_start && a.c.rectify && tile + 2 * TILE <= T &&
+                               !(env_true && tile == 0) && tile + TILE < loop_end && !(a.debug & 2);
+            if (FLAGS) {
+                if (active) {
+                    if (quiet) pending = it + 1;
+                    else CHAIN_WAIT_FOR(taken, it + 1);
+                }
+            } else {
+                __syncthreads();                               // B2: the FFT wave has its copy
+            }
+            if (quiet) {
+                if (tile >= lo && lane == 0) {
+#pragma unroll
+                    for (int r = 0; r < DE; r++) ckpt[(tile / TILE) * DE + r] = ce_[r];
+                }
+                const float rgain = a.c.gain;
+#define CASC_S SE
+#define CASC_PLAN() PLAN_OF(PE0)
+#define CASC_CARRY ce_
+#define CASC_IN(v) (rgain * fabsf(v))
+#define CASC_NO_OUTPUT
+#define CASC_ROLLED_GROUPS
+#include "sos_cascade.inc"
+#undef CASC_ROLLED_GROUPS
+#undef CASC_NO_OUTPUT
+#undef CASC_S
+#undef CASC_PLAN
+#undef CASC_CARRY
+#undef CASC_IN
+                WAVE_SYNC();
+            } else if (active && tile >= env_start && !(a.debug & 2)) {
                 // ---- envelope input in place: r = gain*|y|, then the odd extension past T
                 if (a.c.rectify) {
 #pragma unroll
