@@ -300,17 +300,20 @@ template <> __device__ __forceinline__ void dft<32>(float2 *v)
                           0.98078528040323044913f, 1.f, 0.98078528040323044913f, 0.92387953251128675613f,
                           0.83146961230254523708f, 0.70710678118654752440f, 0.55557023301960222474f,
                           0.38268343236508977173f, 0.19509032201612826785f};
-    float2 e[16], o[16];
+    v2f e[16], o[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) { e[k] = v[2 * k]; o[k] = v[2 * k + 1]; }
-    dft<16>(e); dft<16>(o);
+    for (int k = 0; k < 16; k++) { e[k] = as_v2f(v[2 * k]); o[k] = as_v2f(v[2 * k + 1]); }
+    dft16p(e); dft16p(o);
+    v[0] = as_f2(e[0] + o[0]); v[16] = as_f2(e[0] - o[0]);
 #pragma unroll
     for (int k = 1; k < 16; k++) {
-        if (k == 8) o[k] = mul_negi(o[k]);
-        else o[k] = cmul(o[k], make_float2(c[k], -sn[k]));
+        if (k == 8) {                                              // W32^8 = -i
+            v[k] = as_f2(pk_add_negi(e[k], o[k])); v[k + 16] = as_f2(pk_sub_negi(e[k], o[k]));
+        } else {
+            const v2f q = pk_rot(o[k], c[k], sn[k]);               // o * (c - i s)
+            v[k] = as_f2(e[k] + q); v[k + 16] = as_f2(e[k] - q);
+        }
     }
-#pragma unroll
-    for (int k = 0; k < 16; k++) { v[k] = cadd(e[k], o[k]); v[k + 16] = csub(e[k], o[k]); }
 }
 
 
