@@ -101,6 +101,16 @@ __device__ __forceinline__ void store_four(float *out, long long p, float4 v, lo
 // next to its use.
 #define PLAN_OF(ptr) (reinterpret_cast<const SosPlanDev *>(reinterpret_cast<const char *>(ptr) + opaque_zero()))
 
+// The value of the lane below (lane 0: zero): a full-wave shift by one as a DPP move inside the VALU
+// (wave_shr:1, bound_ctrl) instead of a trip through the LDS crossbar (ds_bpermute) plus a select.
+__device__ __forceinline__ double casc_wave_shr1(double x)
+{
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x138, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x138, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
 // ---- sosfilt: BufferedFilter.process ------------------------------------------------------
 template <int S>
 __global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *__restrict__ P0, SeqArgs a)
