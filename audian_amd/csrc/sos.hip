@@ -111,6 +111,16 @@ __device__ __forceinline__ double casc_wave_shr1(double x)
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
+// Shift by 32 lanes with zero fill: v_permlane32_swap (gfx950) exchanges the upper half of its first
+// operand with the lower half of its second; first operand 0, second x -> (0..0, x[0..31]).
+__device__ __forceinline__ double casc_wave_shr32(double x)
+{
+    const long long b = __builtin_bit_cast(long long, x);
+    const auto lo = __builtin_amdgcn_permlane32_swap(0, (int)b, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(0, (int)(b >> 32), false, false);
+    return __builtin_bit_cast(double, ((long long)hi[0] << 32) | (unsigned int)lo[0]);
+}
+
 // ---- sosfilt: BufferedFilter.process ------------------------------------------------------
 template <int S>
 __global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *__restrict__ P0, SeqArgs a)
