@@ -10,10 +10,12 @@ from conftest import rel_err
 pytestmark = pytest.mark.gpu
 
 
-def test_graph_replay_under_cutoff_sweep(oracle):
+@pytest.mark.parametrize('fused', [False, True])
+def test_graph_replay_under_cutoff_sweep(oracle, fused):
     from audian_amd import hipdsp
     from audian_amd.design import butter_sos
-    rate, C, T, nfft, hop = 192000.0, 4, 192000*2, 1024, 512
+    rate, C, T = 192000.0, 4, 192000*2
+    nfft, hop = (2048, 1024) if fused else (1024, 512)     # fused: hipdsp_chain_forward + backward sweep
     ctx = hipdsp.Context(0)
     stream = ctx.create_stream()
     ctx.set_stream(stream)
@@ -30,9 +32,13 @@ def test_graph_replay_under_cutoff_sweep(oracle):
 
     def chain():
         plan.upload()
-        hipdsp.sosfilt(ctx, plan, dx, T, df, T, C, T, 0)
-        hipdsp.spectrogram(ctx, df, T, C, T, nfft, hop, rate, ds, nd)
-        hipdsp.envelope(ctx, eplan, df, T, de, T, C, T, 0)
+        if fused:
+            hipdsp.chain_forward(ctx, plan, eplan, dx, T, df, T, C, T, nfft, hop, rate, ds, nd)
+            hipdsp.sosfilt_envelope(ctx, plan, eplan, dx, T, df, T, de, T, C, T, phase=2)
+        else:
+            hipdsp.sosfilt(ctx, plan, dx, T, df, T, C, T, 0)
+            hipdsp.spectrogram(ctx, df, T, C, T, nfft, hop, rate, ds, nd)
+            hipdsp.envelope(ctx, eplan, df, T, de, T, C, T, 0)
 
     chain()                       # warm: FFT tables, envelope scratch
     ctx.synchronize()
