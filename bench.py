@@ -264,6 +264,18 @@ def main():
     ctx.record(cb)
     copy_gbps = 3*8.0*C*T/(ctx.elapsed_ms(ca, cb)*1e-3)/1e9
 
+    if fuse3:
+        # one untimed trial of the fused forward sweep: whatever it cannot do (shape, plan) or the
+        # device refuses falls back to the separate launches instead of ending the run without a number
+        try:
+            hipdsp.chain_forward(ctx, plan, eplan, dx, T, df, T, C, T, args.nfft, args.hop, args.rate, ds, nd,
+                                 rectify=True, gain=np.pi/2)
+            ctx.synchronize()
+        except (NotImplementedError, RuntimeError, ValueError, MemoryError) as err:
+            print(f'bench.py: fused forward sweep not used ({err}); separate launches on one stream',
+                  file=sys.stderr)
+            fuse3 = False
+
     n_ev = 7
     events = [[ctx.event() for _ in range(n_ev)] for _ in range(args.steps)]
     mids = [ctx.event() for _ in range(args.steps)]
