@@ -117,3 +117,22 @@ def test_segment_planner_bench_configuration():
     assert count*length >= 200_000 and length >= TILE
     with pytest.raises(ValueError):
         segments(0, 10, 1, 0)
+
+
+@pytest.mark.parametrize('btype,order,wn,rate', [
+    ('bandpass', 2, (300.0, 3000.0), 96000.0), ('bandpass', 4, (300.0, 3000.0), 48000.0),
+    ('lowpass', 7, 500.0, 48000.0), ('highpass', 5, 100.0, 192000.0)])
+def test_transition_powers_are_block_lower_triangular(btype, order, wn, rate):
+    """The scan kernels skip the entries of A^(32*2^k) above the 2 x 2 block diagonal
+    (csrc/sos_cascade.inc): a section's state never depends on the sections behind it, and powers
+    computed by repeated squaring of such a matrix keep EXACT zeros there."""
+    sos = butter_sos(order, wn, btype, rate)
+    A = transition_matrix(sos)
+    D = len(A)
+    P = np.linalg.matrix_power(A, 32)
+    for k in range(6):
+        for r in range(D):
+            for c in range(D):
+                if c//2 > r//2:
+                    assert A[r, c] == 0.0 and P[r, c] == 0.0, (k, r, c)
+        P = P @ P
