@@ -26,7 +26,21 @@ struct hipdsp_ctx {
     int spec_fpw, spec_kernel;   // experiments (tools/), 0 = defaults
     int chain_debug;       // experiments: ablation bits of the fused forward kernel
     struct hd_pool *pool;  // stream-ordered cache of freed device blocks (ctx.hip)
+    // Device-side fault report: four ints in pinned host memory that kernels can write
+    // (word 0 = fault code, 1..3 = detail).  A kernel whose bounded wait runs out stores here instead of
+    // carrying on silently; hd_device_fault() turns a non-zero word into HIPDSP_ERR_HIP.
+    volatile int *fault_host;
+    int *fault_dev;        // the same words as the kernels address them
+    int graphs_alive;      // hipGraphs captured on this context that have not been destroyed
 };
+
+// fault codes a kernel may leave in hipdsp_ctx::fault_host[0]
+#define HD_FAULT_CHAIN_HANDOVER 1   // chain_fwd_kernel: a wave waited in vain for its partner's LDS flag
+
+// Reports (and clears) a fault word left by a kernel of this context: HIPDSP_ERR_HIP with a message,
+// HIPDSP_OK when there is none.  Called after every synchronisation of the context's stream and at
+// the top of the calls that launch such kernels.
+int hd_device_fault(hipdsp_ctx *ctx);
 
 struct hipdsp_graph {
     hipGraph_t graph;

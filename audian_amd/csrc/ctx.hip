@@ -2,18 +2,27 @@
 #include "common.h"
 #include <map>
 #include <unordered_map>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
 // Stream-ordered cache of freed device blocks.  hipMalloc/hipFree synchronise the device, which
 // stalls an interactive loop that needs a temporary per redraw (a screen-resolution image, a
 // min/max trace); blocks up to `max_block` bytes go back into a size-ordered free list instead
-// and are handed out again for requests they fit without wasting more than a quarter.  Safe
-// because every kernel and copy of a context runs on the context's one stream: whatever still
-// uses a freed block is ahead of its next user in that stream.
+// and are handed out again for requests they fit without wasting more than a quarter.  A freed
+// block carries an event recorded on the stream it was freed on; reuse on the same stream needs
+// nothing (whatever still uses the block is ahead of its next user in that stream), reuse after
+// hipdsp_ctx_set_stream makes the new stream wait for that event first.
+struct hd_block {
+    void *ptr;
+    hipStream_t stream;        // the context's stream when the block was freed
+    hipEvent_t freed;          // recorded on that stream at the free (NULL: freed during capture)
+};
+
 struct hd_pool {
-    std::multimap<size_t, void *> cached;            // size -> block
+    std::multimap<size_t, hd_block> cached;          // size -> block
     std::unordered_map<void *, size_t> live;         // handed out by hipdsp_malloc
+    std::vector<hipEvent_t> spare_events;
     size_t cached_bytes = 0;
     size_t limit = (size_t)1 << 30;                  // bytes kept at most ("pool_limit_mb")
     size_t max_block = (size_t)256 << 20;            // larger blocks are never cached
@@ -22,9 +31,18 @@ struct hd_pool {
 
 static void pool_trim(hd_pool *p)
 {
-    for (auto &kv : p->cached) (void)hipFree(kv.second);
+    for (auto &kv : p->cached) {
+        (void)hipFree(kv.second.ptr);
+        if (kv.second.freed) p->spare_events.push_back(kv.second.freed);
+    }
     p->cached.clear();
     p->cached_bytes = 0;
+}
+
+static void pool_destroy_events(hd_pool *p)
+{
+    for (hipEvent_t e : p->spare_events) (void)hipEventDestroy(e);
+    p->spare_events.clear();
 }
 
 void hipdsp_set_error(const char *fmt, ...)
@@ -80,6 +98,25 @@ int hipdsp_ctx_create(int device, void *stream, hipdsp_ctx **out)
     ctx->pool = new hd_pool();
     ctx->sos_prefetch = 1;
     for (int i = 0; i < 20; i++) ctx->fft_tables2[i] = nullptr;
+    ctx->fault_host = nullptr;
+    ctx->fault_dev = nullptr;
+    ctx->graphs_alive = 0;
+    {
+        void *h = nullptr, *d = nullptr;
+        hipError_t e = hipHostMalloc(&h, 64, hipHostMallocMapped);
+        if (e == hipSuccess) {
+            memset(h, 0, 64);
+            e = hipHostGetDevicePointer(&d, h, 0);
+        }
+        if (e != hipSuccess) {
+            if (h) (void)hipHostFree(h);
+            delete ctx->pool;
+            delete ctx;
+            HD_CHECK_HIP(e);
+        }
+        ctx->fault_host = (volatile int *)h;
+        ctx->fault_dev = (int *)d;
+    }
     *out = ctx;
     return HIPDSP_OK;
 }
@@ -89,9 +126,11 @@ int hipdsp_ctx_destroy(hipdsp_ctx *ctx)
     if (!ctx) return HIPDSP_OK;
     if (ctx->pool) {
         pool_trim(ctx->pool);
+        pool_destroy_events(ctx->pool);
         delete ctx->pool;
     }
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->fault_host) (void)hipHostFree((void *)ctx->fault_host);
     for (int i = 0; i < 20; i++)
         if (ctx->fft_tables[i]) (void)hipFree(ctx->fft_tables[i]);
     for (int i = 0; i < 20; i++)
@@ -111,7 +150,7 @@ int hipdsp_ctx_synchronize(hipdsp_ctx *ctx)
 {
     HD_REQUIRE(ctx != nullptr, "ctx is NULL");
     HD_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    return HIPDSP_OK;
+    return hd_device_fault(ctx);
 }
 
 int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments)
@@ -169,7 +208,13 @@ int hipdsp_malloc(hipdsp_ctx *ctx, size_t bytes, void **dptr)
     const size_t want = (bytes + 511) & ~(size_t)511;
     auto it = p->cached.lower_bound(want);
     if (it != p->cached.end() && it->first <= want + want / 4 + 4096) {
-        *dptr = it->second;
+        const hd_block b = it->second;
+        if (b.freed) {
+            // freed on another stream than the one that will use it now: order the two
+            if (b.stream != ctx->stream) HD_CHECK_HIP(hipStreamWaitEvent(ctx->stream, b.freed, 0));
+            p->spare_events.push_back(b.freed);
+        }
+        *dptr = b.ptr;
         p->live[*dptr] = it->first;
         p->cached_bytes -= it->first;
         p->cached.erase(it);
@@ -206,7 +251,19 @@ int hipdsp_free(hipdsp_ctx *ctx, void *dptr)
     const size_t size = it->second;
     p->live.erase(it);
     if (size <= p->max_block && p->cached_bytes + size <= p->limit) {
-        p->cached.emplace(size, dptr);
+        hd_block b{dptr, ctx->stream, nullptr};
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (ctx->stream) (void)hipStreamIsCapturing(ctx->stream, &st);
+        if (st == hipStreamCaptureStatusNone) {
+            if (!p->spare_events.empty()) {
+                b.freed = p->spare_events.back();
+                p->spare_events.pop_back();
+            } else {
+                HD_CHECK_HIP(hipEventCreateWithFlags(&b.freed, hipEventDisableTiming));
+            }
+            HD_CHECK_HIP(hipEventRecord(b.freed, ctx->stream));
+        }
+        p->cached.emplace(size, b);
         p->cached_bytes += size;
         return HIPDSP_OK;
     }
@@ -255,6 +312,7 @@ int hipdsp_memcpy_d2h(hipdsp_ctx *ctx, void *host_dst, const void *src, size_t b
     if (bytes) {
         HD_CHECK_HIP(hipMemcpyAsync(host_dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
         HD_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        return hd_device_fault(ctx);      // what was copied may come from a kernel that gave up
     }
     return HIPDSP_OK;
 }
@@ -323,6 +381,7 @@ int hipdsp_graph_end(hipdsp_ctx *ctx, hipdsp_graph **out)
     hipdsp_graph *h = new hipdsp_graph();
     h->graph = g;
     h->exec = exec;
+    ctx->graphs_alive++;
     *out = h;
     return HIPDSP_OK;
 }
@@ -341,6 +400,7 @@ int hipdsp_graph_destroy(hipdsp_ctx *ctx, hipdsp_graph *graph)
         (void)hipGraphExecDestroy(graph->exec);
         (void)hipGraphDestroy(graph->graph);
         delete graph;
+        if (ctx->graphs_alive > 0) ctx->graphs_alive--;
     }
     return HIPDSP_OK;
 }
@@ -380,10 +440,25 @@ int hipdsp_event_elapsed_ms(hipdsp_ctx *ctx, void *start, void *stop, float *ms)
     HD_REQUIRE(ctx != nullptr && start && stop && ms, "NULL argument");
     HD_CHECK_HIP(hipEventSynchronize((hipEvent_t)stop));
     HD_CHECK_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
-    return HIPDSP_OK;
+    return hd_device_fault(ctx);
 }
 
 }  // extern "C"
+
+int hd_device_fault(hipdsp_ctx *ctx)
+{
+    if (!ctx || !ctx->fault_host) return HIPDSP_OK;
+    const int code = ctx->fault_host[0];
+    if (code == 0) return HIPDSP_OK;
+    const int a = ctx->fault_host[1], b = ctx->fault_host[2], c = ctx->fault_host[3];
+    ctx->fault_host[0] = 0;                       // reported once
+    if (code == HD_FAULT_CHAIN_HANDOVER)
+        hipdsp_set_error("chain_fwd_kernel: a wave of workgroup %d (pair %d) gave up waiting for its partner's "
+                         "LDS hand-over in iteration %d; the outputs of that launch are invalid", a, b, c);
+    else
+        hipdsp_set_error("a kernel reported device fault %d (%d, %d, %d)", code, a, b, c);
+    return HIPDSP_ERR_HIP;
+}
 
 int hipdsp_scratch(hipdsp_ctx *ctx, size_t bytes, void **out)
 {
@@ -394,6 +469,13 @@ int hipdsp_scratch(hipdsp_ctx *ctx, size_t bytes, void **out)
         if (st != hipStreamCaptureStatusNone) {
             hipdsp_set_error("scratch of %zu bytes needed during stream capture; call "
                              "hipdsp_ctx_reserve() before capturing", bytes);
+            return HIPDSP_ERR_INVALID;
+        }
+        if (ctx->scratch && ctx->graphs_alive > 0) {
+            // a captured launch holds the old scratch pointer (envelope checkpoints, FFT work area)
+            hipdsp_set_error("scratch would have to grow from %zu to %zu bytes while %d captured graph(s) of this "
+                             "context still point into it; hipdsp_ctx_reserve() the largest size before capturing",
+                             ctx->scratch_bytes, bytes, ctx->graphs_alive);
             return HIPDSP_ERR_INVALID;
         }
         HD_CHECK_HIP(hipStreamSynchronize(ctx->stream));

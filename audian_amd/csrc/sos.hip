@@ -684,7 +684,9 @@ struct ChainArgs {
     long long warm_total;     // band-pass + envelope warm-up samples
     long long units;          // channels * n_seg
     int debug;                // experiments: 1 = FFT waves only copy, 2 = IIR waves skip the cascades
-                              // (bit 4, host side: workgroup barriers instead of the pairwise flags)
+                              // (bit 4, host side: workgroup barriers instead of the pairwise flags;
+                              // bit 8: FFT wave 0 of workgroup 0 withholds one hand-over -- fault-path test)
+    int *fault;               // hipdsp_ctx::fault_dev: where a wave that gave up waiting says so
 };
 
 #define WAVE_SYNC()                                          \
@@ -782,17 +784,38 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int pair = wave < NP ? wave : wave - NP;
-    // bounded polling (a logic error must not hang the GPU: after 2^23 naps, a third of a second, the wave moves
-    // on -- far beyond anything a partner wave of the same workgroup can be late by);
-    // macros, not lambdas: through a pointer parameter the flags would be accessed with flat
-    // instructions, whose wait also drains the prefetch of the IIR role
-#define CHAIN_WAIT_FOR(arr, want)                                                   \
+    // Bounded polling: a logic error must not hang the GPU.  After 2^23 naps (a third of a second, far
+    // beyond anything a partner wave of the same workgroup can be late by) the wave GIVES UP: it
+    // reports the fault through the context's fault word (the host turns it into HIPDSP_ERR_HIP at the
+    // next synchronisation), raises the workgroup's abort word so that its partner stops waiting too,
+    // and walks the rest of its iterations without waiting for anything -- the launch ends quickly
+    // and its outputs are declared invalid, instead of being silently wrong.
+    // Macros, not lambdas: through a pointer parameter the flags would be accessed with flat
+    // instructions, whose wait also drains the prefetch of the IIR role.
+    __shared__ int abort_wg;
+    if (threadIdx.x == 0) abort_wg = 0;
+    bool gave_up = false;
+#define CHAIN_WAIT_FOR(arr, want, iter)                                             \
     do {                                                                            \
-        for (int spin_ = 0; spin_ < (1 << 23); spin_++) {                           \
-            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&arr[pair], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= (want)) break; \
-            __builtin_amdgcn_s_sleep(1);                                            \
+        if (!gave_up) {                                                             \
+            for (int spin_ = 0;; spin_++) {                                         \
+                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&arr[pair], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= (want)) break; \
+                if ((spin_ & 1023) == 1023) {                                       \
+                    const bool told = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&abort_wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0; \
+                    if (told || spin_ >= (1 << 23) - 1) {                           \
+                        gave_up = true;                                             \
+                        if (!told && lane == 0) {                                   \
+                            __hip_atomic_store(&abort_wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                            a.fault[1] = (int)blockIdx.x; a.fault[2] = pair; a.fault[3] = (iter); \
+                            __hip_atomic_store(&a.fault[0], HD_FAULT_CHAIN_HANDOVER, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); \
+                        }                                                           \
+                        break;                                                      \
+                    }                                                               \
+                }                                                                   \
+                __builtin_amdgcn_s_sleep(1);                                        \
+            }                                                                       \
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");        \
         }                                                                           \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");            \
     } while (0)
 #define CHAIN_POST(arr, value)                                                      \
     do {                                                                            \
@@ -859,7 +882,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             const long long tile = base + (long long)it * TILE;
             const bool active = tile >= start && tile < loop_end;
             if (FLAGS && pending) {                            // H2 of the previous (quiet) tile
-                CHAIN_WAIT_FOR(taken, pending);
+                CHAIN_WAIT_FOR(taken, pending, it);
                 pending = 0;
             }
             if (active) {
@@ -936,7 +959,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             if (FLAGS) {
                 if (active) {
                     if (quiet) pending = it + 1;
-                    else CHAIN_WAIT_FOR(taken, it + 1);
+                    else CHAIN_WAIT_FOR(taken, it + 1, it);
                 }
             } else {
                 __syncthreads();                               // B2: the FFT wave has its copy
@@ -1054,7 +1077,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
         for (int it = 0; it < a.n_iter; it++) {
             const long long tile = base + (long long)it * TILE;
             const bool active = tile >= start && tile < loop_end;
-            if (FLAGS) { if (active) CHAIN_WAIT_FOR(ready, it + 1); }
+            if (FLAGS) { if (active) CHAIN_WAIT_FOR(ready, it + 1, it); }
             else __syncthreads();                              // B1
             if (active) {
 #pragma unroll
@@ -1063,7 +1086,12 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                     hi_[j] = *reinterpret_cast<const v2f *>(tlf + lds_float_index(1024 + 2 * lane + 128 * j));
                 }
             }
-            if (FLAGS) { if (active) CHAIN_POST(taken, it + 1); }   // (the release fence waits for the loads)
+            if (FLAGS) {                                        // (the release fence waits for the loads)
+                // "chain_debug" bit 8 (fault-path test): FFT wave 0 of workgroup 0 withholds the hand-over of
+                // its unit's first tile, so that IIR wave 0 runs into the timeout
+                const bool withhold = (a.debug & 8) && blockIdx.x == 0 && pair == 0 && tile == start;
+                if (active && !withhold) CHAIN_POST(taken, it + 1);
+            }
             else __syncthreads();                              // B2
             if (active) {
                 const long long t = tile / TILE;
@@ -1548,6 +1576,10 @@ int hipdsp_sosfilt_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const 
     HD_REQUIRE(channels >= 0 && frames >= 0, "negative size");
     HD_REQUIRE(fplan->host->n_sections > 0 && eplan->host->n_sections > 0, "plan has no coefficients");
     HD_CHECK_HIP(hipSetDevice(ctx->device));
+    {   // phase 2 consumes what a forward sweep left behind: not if that sweep reported a fault
+        const int frc = hd_device_fault(ctx);
+        if (frc != HIPDSP_OK) return frc;
+    }
     const int edge = eplan->host->edge;
     if (frames <= edge) {
         hipdsp_set_error("The length of the input vector x must be greater than padlen, which is %d.", edge);
@@ -1579,8 +1611,13 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
         return HIPDSP_ERR_UNSUPPORTED;
     }
     HD_CHECK_HIP(hipSetDevice(ctx->device));
+    {   // an earlier launch on this context may have reported a fault that nobody has looked at yet
+        const int frc = hd_device_fault(ctx);
+        if (frc != HIPDSP_OK) return frc;
+    }
     const int edge = eplan->host->edge;
     if (channels == 0) return HIPDSP_OK;
+    HD_REQUIRE(channels <= 65535, "more than 65535 channels");     // grid.y of the zero-tail launch
     HD_REQUIRE(x != nullptr && yf != nullptr && (psd != nullptr || frames_out == 0), "NULL data pointer");
     HD_REQUIRE(x_pitch >= frames && yf_pitch >= frames, "pitch smaller than row length");
     const long long F = TILE / 2 + 1;
@@ -1613,7 +1650,9 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     a.scale = (float)(1.0 / (fs * wss));
     a.warm_total = fplan->host->warm + eplan->host->warm;
     a.debug = ctx->chain_debug;
+    a.fault = ctx->fault_dev;
     constexpr int P = 8;                                           // IIR waves (and FFT waves) per workgroup, one per CU
+    // (hipdsp_chain_plan reports exactly this segmentation)
     plan_segments_for((long long)ctx->n_cus * P, ctx->max_segments, frames, channels, a.warm_total, &a.c.seg_len,
                       &a.c.n_seg);
     a.units = channels * a.c.n_seg;
@@ -1646,6 +1685,22 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     }
 #undef HD_CHAIN
     return hd_launch_status("chain_fwd_kernel");
+}
+
+int hipdsp_chain_plan(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hipdsp_sosplan *eplan,
+                      int64_t channels, int64_t frames, int64_t *segment_frames, int *n_segments)
+{
+    HD_REQUIRE(ctx != nullptr && fplan != nullptr && eplan != nullptr, "NULL argument");
+    HD_REQUIRE(segment_frames != nullptr && n_segments != nullptr, "NULL output");
+    HD_REQUIRE(channels >= 1 && frames >= 1, "bad size");
+    HD_REQUIRE(fplan->host->n_sections > 0 && eplan->host->n_sections > 0, "plan has no coefficients");
+    long long len = 0;
+    int n = 0;
+    plan_segments_for((long long)ctx->n_cus * 8, ctx->max_segments, frames, channels,
+                      fplan->host->warm + eplan->host->warm, &len, &n);
+    *segment_frames = len;
+    *n_segments = n;
+    return HIPDSP_OK;
 }
 
 int hipdsp_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const float *x, int64_t x_pitch,

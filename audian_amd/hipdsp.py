@@ -316,6 +316,14 @@ def chain_forward(ctx, fplan, eplan, x, x_pitch, yf, yf_pitch, channels, frames,
                                    int(frames_out), int(psd_pitch)))
 
 
+def chain_plan(ctx, fplan, eplan, channels, frames):
+    """(segment_frames, n_segments) of chain_forward for this shape (hipdsp_chain_plan)."""
+    seg, n = ctypes.c_int64(), ctypes.c_int()
+    check(lib.hipdsp_chain_plan(ctx.handle, fplan.handle, eplan.handle, int(channels), int(frames),
+                                ctypes.byref(seg), ctypes.byref(n)))
+    return int(seg.value), int(n.value)
+
+
 def spectrogram(ctx, x, x_pitch, channels, frames, nfft, hop, fs, out, frames_out, db_out=None,
                 out_pitch=0):
     check(lib.hipdsp_spectrogram(ctx.handle, _p(x), int(x_pitch), int(channels), int(frames),

@@ -72,11 +72,19 @@ int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
  *   "chain_debug"        measurements only (results become wrong): 1 = the FFT waves of
  *                        hipdsp_chain_forward only copy their tiles, 2 = its IIR waves skip the cascades;
  *                        4 (results unchanged) = workgroup barriers instead of pairwise LDS flags;
- *                        16 = clock counters of one wave into the first 16 bytes of the PSD */
+ *                        8 = one FFT wave withholds one hand-over (test of the fault report below);
+ *                        16 = clock counters of one wave into the first 16 bytes of the PSD
+ * Device-side faults: the waits between the waves of hipdsp_chain_forward's kernel are bounded; a wave
+ * whose wait runs out writes a fault word owned by the context and ends the launch early.
+ * hipdsp_ctx_synchronize, hipdsp_memcpy_d2h, hipdsp_event_elapsed_ms and the next
+ * hipdsp_chain_forward / hipdsp_sosfilt_envelope on the context then return HIPDSP_ERR_HIP (once,
+ * with a message): no path returns HIPDSP_OK for a launch that gave up. */
 int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value);
 /* Pre-size the internal scratch (envelope state checkpoints: 16 * n_sections bytes per
  * 2048-sample tile and channel; four-step FFT work area) so that later calls do not
- * allocate; required before stream capture into a hipGraph. */
+ * allocate; required before stream capture into a hipGraph.  While a graph captured on the context
+ * is alive the scratch cannot grow (the graph holds its address): a call that would need more returns
+ * HIPDSP_ERR_INVALID -- reserve the largest size before capturing. */
 int hipdsp_ctx_reserve(hipdsp_ctx *ctx, size_t bytes);
 
 /* ---- streams and hipGraph capture (interactive recompute, BASELINE configs[4]) ---- */
@@ -104,7 +112,9 @@ int hipdsp_graph_destroy(hipdsp_ctx *ctx, hipdsp_graph *graph);
  * default 1024; 0 turns it off) and hipdsp_malloc hands them out again, because hipMalloc /
  * hipFree synchronise the device and an interactive redraw needs temporaries.  The cache is
  * stream-ordered: free a block through a context whose stream is behind all work on it (order
- * other contexts' streams with hipdsp_event_record / hipdsp_event_wait first). */
+ * other contexts' streams with hipdsp_event_record / hipdsp_event_wait first).  A cached block
+ * remembers the stream it was freed on: handed out again after hipdsp_ctx_set_stream, the new
+ * stream first waits for an event recorded at the free. */
 int hipdsp_malloc(hipdsp_ctx *ctx, size_t bytes, void **dptr);
 int hipdsp_free(hipdsp_ctx *ctx, void *dptr);
 /* Cache statistics (any pointer may be NULL) / give every cached block back to the driver. */
@@ -244,6 +254,13 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan,
                          int64_t yf_pitch, int64_t channels, int64_t frames, int rectify,
                          double gain, int nfft, int hop, double fs, float *psd, float *db_out,
                          int64_t frames_out, int64_t psd_pitch);
+
+/* The time segmentation hipdsp_chain_forward uses for `channels` x `frames` with these plans
+ * (one IIR wave per channel and segment): segment s covers frames [s * segment_frames,
+ * (s + 1) * segment_frames).  For tests and integrators that want to look at the seams; the
+ * results do not depend on it beyond float32 rounding of the frames that straddle a border. */
+int hipdsp_chain_plan(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hipdsp_sosplan *eplan,
+                      int64_t channels, int64_t frames, int64_t *segment_frames, int *n_segments);
 
 /* BufferedSpectrogram.process (bufferedspectrogram.py:45-59) ==
  * scipy.signal.spectrogram(x, fs, 'hann', nperseg=nfft, noverlap=nfft-hop,
