@@ -118,6 +118,8 @@ _SIGNATURES = {
     'hipdsp_channel_mean': ([_vp, _vp, _i64, ctypes.POINTER(_int), _int, _i64, _i64, _dbl, _vp], _int),
     'hipdsp_stride_copy': ([_vp, _vp, _i64, _i64, _vp], _int),
     'hipdsp_max_nonneg': ([_vp, _vp, _i64, _vp], _int),
+    'hipdsp_band_order_stats': ([_vp, _vp, _i64, _i64, _i64, _i64, _vp], _int),
+    'hipdsp_unwrap': ([_vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _int, _int, _vp, _i64], _int),
     'hipdsp_pcm_unpack': ([_vp, _vp, _int, _i64, _i64, _dbl, _vp, _i64], _int),
     'hipdsp_minmax_decimate': ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64], _int),
     'hipdsp_mean_spectrum_db': ([_vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _dbl, _vp], _int),

@@ -38,9 +38,58 @@ class BufferedArray(object):
         self.verbose = verbose
         self.buffer_changed = np.zeros(0, dtype=bool)
         self.buffer = np.zeros((0, 0))
+        self.unwrap_thresh = 0.0
+        self.unwrap_clips = False
+        self.unwrap_down_scale = True
+        self.unwrap_ampl = 1.0
 
     def __len__(self):
         return self.frames
+
+    # -- unwrap of clipped recordings (audioio: BufferedArray.set_unwrap / unwrap()) -----------
+    def set_unwrap(self, thresh, clips=False, down_scale=True, unit=''):
+        """Arm audioio's unwrap() for every slab this loader reads from now on, as the reference does
+        right after opening the recording (``self.data.set_unwrap(unwrap, unwrap_clip, False, unit)``,
+        src/audian/data.py:180; CLI ``-u`` / ``-U``, src/audian/audian.py:1485-1512).  ``thresh`` <= 1e-3
+        turns it off.  Without clipping and down-scaling the amplitude range doubles.  audioio's source
+        is not available here: restated from its documentation (parity unpinned)."""
+        self.unwrap_ampl = float(self.ampl_max if self.unwrap_thresh <= 1e-3 else self.unwrap_ampl)
+        self.unwrap_thresh = float(thresh)
+        self.unwrap_clips = bool(clips)
+        self.unwrap_down_scale = bool(down_scale)
+        if self.unwrap_thresh > 1e-3:
+            grow = 1.0 if (self.unwrap_clips or self.unwrap_down_scale) else 2.0
+            self.ampl_min, self.ampl_max = -grow*self.unwrap_ampl, grow*self.unwrap_ampl
+            if getattr(self, 'view', False):
+                self.view = False              # the buffer must be this loader's own copy now
+                self.buffer = np.zeros((0, self.channels))
+                self.move_buffer(self.offset, self.bufferframes)
+                return
+        else:
+            self.ampl_min, self.ampl_max = -self.unwrap_ampl, self.unwrap_ampl
+        if len(self._buf()) > 0:
+            self.reload_buffer()
+
+    def _apply_unwrap(self, buffer):
+        """Unwrap a freshly loaded (frames, channels) slab in place (device kernels: hipdsp_unwrap);
+        like audioio, every slab starts again from zero offset."""
+        if self.unwrap_thresh <= 1e-3 or len(buffer) == 0:
+            return
+        from . import hipdsp
+        ctx = hipdsp.default_context()
+        n, nch = buffer.shape
+        host = np.ascontiguousarray(buffer, dtype=np.float32)
+        up = hipdsp.DeviceArray.from_host(ctx, host)
+        planar = hipdsp.DeviceArray(ctx, (nch, n), np.float32)
+        hipdsp.pack(ctx, up, planar, n, n, nch, src_dtype=np.float32)
+        out = hipdsp.DeviceArray(ctx, (nch, n), np.float32)
+        hipdsp.unwrap(ctx, planar, n, nch, n, self.unwrap_thresh, out, n, ampl_max=self.unwrap_ampl,
+                      clips=self.unwrap_clips, down_scale=self.unwrap_down_scale)
+        tmp = hipdsp.DeviceArray(ctx, (n, nch), np.float64)
+        hipdsp.unpack(ctx, out, n, tmp, n, nch)
+        buffer[:, :] = tmp.to_host()
+        for d in (up, planar, out, tmp):
+            d.free()
 
     # -- subclass hook ---------------------------------------------------------
     def load_buffer(self, offset, nframes, buffer):
@@ -188,6 +237,7 @@ class ArrayLoader(BufferedArray):
 
     def load_buffer(self, offset, nframes, buffer):
         buffer[:, :] = self.data[offset:offset + nframes, :]
+        self._apply_unwrap(buffer)
 
     def move_buffer(self, offset, nframes):
         if not self.view:
@@ -252,6 +302,7 @@ class WavLoader(BufferedArray):
             ints = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
             ints = np.where(ints >= 1 << 23, ints - (1 << 24), ints)
         buffer[:, :] = ints.reshape(-1, self.channels)*self.scale
+        self._apply_unwrap(buffer)
 
     def close(self):
         self._wav.close()

@@ -139,11 +139,64 @@ def _delegate(name):
     return method
 
 
+class _LazySource(object):
+    """The ``source`` argument of process() while the source trace's host copy of that span is stale
+    (its results live in the device mirror only): looks like ``source.buffer[first:first + count]`` of
+    the reference contract (buffereddata.py:91-109) and copies the span back from the mirror the
+    moment a subclass actually reads it; ``len()``, ``shape`` and ``dtype`` touch nothing, so the
+    built-in process() implementations, which take the mirror instead, never trigger the copy."""
+
+    def __init__(self, trace, first, count):
+        object.__setattr__(self, '_t', trace)
+        object.__setattr__(self, '_a', int(first))
+        object.__setattr__(self, '_b', int(first) + int(count))
+
+    def _real(self):
+        self._t._flush_range(self._a, self._b)
+        return self._t._hostbuf[self._a:self._b]
+
+    def __len__(self):
+        return self._b - self._a
+
+    @property
+    def shape(self):
+        return (self._b - self._a,) + tuple(self._t._hostbuf.shape[1:])
+
+    @property
+    def ndim(self):
+        return self._t._hostbuf.ndim
+
+    @property
+    def dtype(self):
+        return self._t._hostbuf.dtype
+
+    def __getitem__(self, key):
+        return self._real()[key]
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self._real(), dtype=dtype)
+
+    def __getattr__(self, name):
+        return getattr(self._real(), name)
+
+    def __iter__(self):
+        return iter(self._real())
+
+
+def _delegate_source(name):
+    def method(self, *args):
+        return getattr(self._real(), name)(*args)
+    method.__name__ = name
+    return method
+
+
 for _name in ('__eq__', '__ne__', '__lt__', '__le__', '__gt__', '__ge__', '__add__', '__radd__',
               '__sub__', '__rsub__', '__mul__', '__rmul__', '__truediv__', '__rtruediv__',
               '__pow__', '__neg__', '__abs__', '__matmul__'):
     setattr(_LazyBuffer, _name, _delegate(_name))
+    setattr(_LazySource, _name, _delegate_source(_name))
 _LazyBuffer.__hash__ = None
+_LazySource.__hash__ = None
 
 
 class BufferedData(BufferedArray):
@@ -347,7 +400,7 @@ class BufferedData(BufferedArray):
         if call is not None and isinstance(src, BufferedData) and src._stale:
             source = src.buffer[call.soffset:call.soffset + call.snframes]     # flushes
         n = len(source)
-        if call is not None and n > 0 and hasattr(src, 'pcm_slab'):
+        if call is not None and n > 0 and hasattr(src, 'pcm_slab') and getattr(src, 'unwrap_thresh', 0.0) <= 1e-3:
             # the loader can hand over the file's own integers: upload those (2-4 bytes per
             # sample instead of 8) and convert on the device
             # (an interactive cut-off sweep recomputes from the SAME raw slab: keep its device copy)
@@ -524,6 +577,9 @@ class BufferedData(BufferedArray):
             lead, count, first = lead + first, count + first, 0
         count = min(count, self._source_len() - first)
         source = self._source_buffer()[first:first + count]
+        if isinstance(src, BufferedData) and any(min(r1, first + count) > max(r0, first) for r0, r1 in src._stale):
+            # the raw host slice would show stale frames to a subclass that reads `source` itself
+            source = _LazySource(src, first, len(source))
         self._pending = _Call(first, len(source), offset - self.offset, len(buffer))
         try:
             self.process(source, buffer, lead)

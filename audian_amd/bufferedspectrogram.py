@@ -181,8 +181,9 @@ class BufferedSpectrogram(BufferedData):
     def estimate_noiselevels(self, channel):
         """Colour range for the spectrogram image (bufferedspectrogram.py:109-126): 95th
         percentile of the dB values in the top 1/16 of the band, and the maximum dB.  With a
-        valid device mirror only the top-band slab (a strided device gather) and one scalar
-        (device max reduction; dB is monotonic) cross PCIe instead of the whole slab."""
+        valid device mirror both are device reductions (radix select of the two order statistics the
+        percentile interpolates between, max reduction; dB is monotonic): three floats cross PCIe
+        instead of the whole slab."""
         if not self.init or len(self._hostbuf) == 0 or len(self._hostbuf.shape) < 3:
             return None, None
         from . import hipdsp
@@ -191,15 +192,20 @@ class BufferedSpectrogram(BufferedData):
         n = len(self._hostbuf)
         nf = max(F//16, 1)                       # top 1/16 of the band
         if self._dev is not None and _covers(self._dev_valid, 0, n) and self._stale:
+            # everything on the device: the two order statistics np.percentile(.., 95) interpolates between
+            # (radix select over the top band) and the maximum; three floats cross PCIe.  decibel() is
+            # monotonic, so the percentile of the dB values is the interpolation of their dB.
             base = self._dev.view(channel*n*F, (1,))
-            band = hipdsp.DeviceArray(self.ctx, (n, nf), np.float32)
-            hipdsp.memcpy2d(self.ctx, band, 4*nf, self._dev.view(channel*n*F + F - nf, (1,)), 4*F,
-                            4*nf, n)
-            top = hipdsp.DeviceArray(self.ctx, (1,), np.float32)
-            hipdsp.max_nonneg(self.ctx, base, n*F, top)
+            pos = 0.95*(n*nf - 1)                      # np.percentile, linear interpolation
+            k = int(np.floor(pos))
+            stats = hipdsp.DeviceArray(self.ctx, (3,), np.float32)
+            hipdsp.band_order_stats(self.ctx, self._dev.view(channel*n*F + F - nf, (1,)), n, nf, F, k, stats)
+            hipdsp.max_nonneg(self.ctx, base, n*F, stats.view(2, (1,)))
+            lo, hi, top = (float(v) for v in stats.to_host().astype(np.float64))
             with np.errstate(all='ignore'):
-                zmin = np.percentile(decibel(band.to_host()), 95)
-            zmax = decibel(float(top.to_host()[0]))
+                dlo, dhi = decibel(lo), decibel(hi)
+                zmin = dlo + (pos - k)*(dhi - dlo) if pos > k else dlo
+            zmax = decibel(top)
         else:
             with np.errstate(all='ignore'):
                 zmin = np.percentile(decibel(self.buffer[:, channel, -nf:]), 95)

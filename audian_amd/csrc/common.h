@@ -25,6 +25,7 @@ struct hipdsp_ctx {
     int spec_no_half;      // experiments/tests: do not reuse the overlapped half frame
     int spec_fpw, spec_kernel;   // experiments (tools/), 0 = defaults
     int chain_debug;       // experiments: ablation bits of the fused forward kernel
+    int sos_no_pin;        // experiments: scalar table loads left to hipcc's just-in-time placement (A/B of CASC_PIN_GROUPS)
     struct hd_pool *pool;  // stream-ordered cache of freed device blocks (ctx.hip)
     // Device-side fault report: four ints in pinned host memory that kernels can write
     // (word 0 = fault code, 1..3 = detail).  A kernel whose bounded wait runs out stores here instead of

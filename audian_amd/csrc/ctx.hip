@@ -93,6 +93,7 @@ int hipdsp_ctx_create(int device, void *stream, hipdsp_ctx **out)
     ctx->force_generic_fft = 0;
     ctx->spec_fpw = ctx->spec_kernel = 0;
     ctx->chain_debug = 0;
+    ctx->sos_no_pin = 0;
     ctx->sos_waves_per_cu = 0;
     ctx->spec_no_half = 0;
     ctx->pool = new hd_pool();
@@ -181,6 +182,7 @@ int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value)
     if (strcmp(name, "spec_no_half") == 0) { ctx->spec_no_half = value != 0; return HIPDSP_OK; }
     if (strcmp(name, "spec_kernel") == 0) { ctx->spec_kernel = (int)value; return HIPDSP_OK; }
     if (strcmp(name, "chain_debug") == 0) { ctx->chain_debug = (int)value; return HIPDSP_OK; }
+    if (strcmp(name, "sos_no_pin") == 0) { ctx->sos_no_pin = value != 0; return HIPDSP_OK; }
     hipdsp_set_error("unknown option '%s'", name);
     return HIPDSP_ERR_INVALID;
 }

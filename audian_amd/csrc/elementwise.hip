@@ -328,6 +328,171 @@ inline unsigned grid1d(long long n, int per_block, unsigned cap)
     return (unsigned)(b > cap ? cap : b);
 }
 
+// ---- unwrap of wrapped-around (clipped) PCM: audioio's unwrap(), which the reference applies to every raw
+// buffer it loads (Data.open -> set_unwrap, src/audian/data.py:180; CLI -u / -U, audian.py:1485-1512) ----------
+// A recording whose true signal left [-1, 1) wraps around in the file: a step between successive samples
+// larger than `thresh` is such a wrap, and from there on the samples are 2 (`step`) too high or too low.
+// y[i] = x[i] + step * k[i],  k[i] = k[i-1] + (x[i] - x[i-1] < -thresh) - (x[i] - x[i-1] > thresh),  k[0] = 0,
+// then clipped to +-1 (`clips`) or halved (`down_scale`).  A prefix sum of +-1 events along time per channel:
+// chunks of UW_CHUNK samples count their events, one workgroup per channel scans the counts, and the chunks
+// redo their events with the carried-in count (12 B/sample: the trace is read twice and written once).
+constexpr int UW_ROW = 1024;                 // samples a 256-thread workgroup covers per step (float4 each)
+constexpr int UW_ROWS = 16;
+constexpr int UW_CHUNK = UW_ROW * UW_ROWS;
+
+__device__ __forceinline__ int uw_event(float cur, float prev, float thresh)
+{
+    const float d = cur - prev;
+    return (d < -thresh ? 1 : 0) - (d > thresh ? 1 : 0);
+}
+
+// events of samples [p, p + 4) of a row of n samples; sample 0 of the channel has no predecessor
+__device__ __forceinline__ void uw_load(const float *x, long long p, long long n, float thresh, float v[4], int e[4])
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = p + k < n ? x[p + k] : 0.f;
+    float prev = p > 0 && p - 1 < n ? x[p - 1] : v[0];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        e[k] = (p + k < n && p + k > 0) ? uw_event(v[k], prev, thresh) : 0;
+        prev = v[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void unwrap_count_kernel(const float *__restrict__ x, long long pitch, long long n,
+                                                           float thresh, int *__restrict__ counts, long long n_chunks)
+{
+    __shared__ int red[4];
+    const long long chunk = blockIdx.x, ch = blockIdx.y;
+    const float *xc = x + ch * pitch;
+    int c = 0;
+    for (int r = 0; r < UW_ROWS; r++) {
+        const long long p = chunk * UW_CHUNK + (long long)r * UW_ROW + 4 * threadIdx.x;
+        float v[4]; int e[4];
+        uw_load(xc, p, n, thresh, v, e);
+        c += e[0] + e[1] + e[2] + e[3];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[ch * n_chunks + chunk] = red[0] + red[1] + red[2] + red[3];
+}
+
+// counts[ch][chunk] -> events before the chunk (exclusive scan along a channel), in place
+__global__ __launch_bounds__(256) void unwrap_scan_kernel(int *__restrict__ counts, long long n_chunks)
+{
+    __shared__ int part[256];
+    int *c = counts + (long long)blockIdx.x * n_chunks;
+    const long long per = (n_chunks + 255) / 256;
+    const long long a = per * threadIdx.x, b = a + per < n_chunks ? a + per : n_chunks;
+    int s = 0;
+    for (long long i = a; i < b; i++) s += c[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int t = 0; t < 256; t++) { const int v = part[t]; part[t] = run; run += v; }
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (long long i = a; i < b; i++) { const int v = c[i]; c[i] = run; run += v; }
+}
+
+__global__ __launch_bounds__(256) void unwrap_apply_kernel(const float *__restrict__ x, long long x_pitch, long long n,
+                                                           float thresh, float step, int clips, float scale,
+                                                           const int *__restrict__ counts, long long n_chunks,
+                                                           float *__restrict__ y, long long y_pitch)
+{
+    __shared__ int wsum[4];
+    const long long chunk = blockIdx.x, ch = blockIdx.y;
+    const float *xc = x + ch * x_pitch;
+    float *yc = y + ch * y_pitch;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int carry = counts[ch * n_chunks + chunk];
+    for (int r = 0; r < UW_ROWS; r++) {
+        const long long p = chunk * UW_CHUNK + (long long)r * UW_ROW + 4 * threadIdx.x;
+        float v[4]; int e[4];
+        uw_load(xc, p, n, thresh, v, e);
+        // inclusive prefix over the row: inside the thread, over the wave, over the four waves
+        e[1] += e[0]; e[2] += e[1]; e[3] += e[2];
+        int incl = e[3];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = carry + incl - e[3];
+        for (int w = 0; w < wave; w++) before += wsum[w];
+        const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+        carry += total;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (p + k < n) {
+                float o = v[k] + step * (float)(before + e[k]);
+                if (clips) o = fminf(fmaxf(o, -0.5f * step), 0.5f * step);
+                yc[p + k] = o * scale;
+            }
+        }
+    }
+}
+
+// Two adjacent order statistics (ranks k and k + 1, zero based, ascending) of the non-negative floats
+// x[i * row_stride + j], i < rows, j < cols -- the band BufferedSpectrogram.estimate_noiselevels takes its
+// 95th percentile of (bufferedspectrogram.py:115-117).  For floats >= 0 the IEEE bit pattern orders like the
+// value, so the rank is found by a radix select over the bits: three histogram passes (12 + 12 + 8 bits)
+// per rank, each over the whole band, with the histogram in LDS.  One workgroup: the band is small
+// (frames x F/16 values) and this runs once per trace.  NaNs sort above everything (as np.percentile puts
+// them last).
+__global__ __launch_bounds__(1024) void band_select_kernel(const float *__restrict__ x, long long rows, long long cols,
+                                                          long long row_stride, long long k0, float *__restrict__ out)
+{
+    __shared__ unsigned int hist[4096];
+    __shared__ unsigned int sel_prefix, sel_rank;
+    const int tid = threadIdx.x;
+    const long long n = rows * cols;
+    for (int which = 0; which < 2; which++) {
+        unsigned int prefix = 0;                       // the bits decided so far, right aligned
+        long long rank = k0 + which;
+        if (rank >= n) rank = n - 1;
+        int decided = 0;
+        for (int pass = 0; pass < 3; pass++) {
+            const int bits = pass < 2 ? 12 : 8;
+            const int shift = 32 - decided - bits;
+            for (int i = tid; i < 4096; i += 1024) hist[i] = 0;
+            __syncthreads();
+            for (long long i = tid; i < n; i += 1024) {
+                const float v = x[(i / cols) * row_stride + (i % cols)];
+                unsigned int key = __float_as_uint(v);
+                if (v != v) key = 0xffffffffu;
+                if (decided == 0 || (key >> (32 - decided)) == prefix)
+                    atomicAdd(&hist[(key >> shift) & ((1u << bits) - 1)], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long cum = 0;
+                unsigned int b = 0;
+                for (; b < (1u << bits); b++) {
+                    if (cum + hist[b] > (unsigned long long)rank) break;
+                    cum += hist[b];
+                }
+                if (b >= (1u << bits)) b = (1u << bits) - 1;
+                sel_prefix = (prefix << bits) | b;
+                sel_rank = (unsigned int)(rank - (long long)cum);
+            }
+            __syncthreads();
+            prefix = sel_prefix;
+            rank = sel_rank;
+            decided += bits;
+            __syncthreads();
+        }
+        if (tid == 0) out[which] = __uint_as_float(prefix);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -476,6 +641,47 @@ int hipdsp_stride_copy(hipdsp_ctx *ctx, const float *x, int64_t n, int64_t step,
     hipLaunchKernelGGL(stride_copy_kernel, dim3(grid1d(m, 256, 4096)), dim3(256), 0, ctx->stream, x,
                        (long long)step, m, out);
     return hd_launch_status("stride_copy_kernel");
+}
+
+int hipdsp_unwrap(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, int64_t channels, int64_t frames, double thresh,
+                  double ampl_max, int clips, int down_scale, float *y, int64_t y_pitch)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    HD_REQUIRE(channels >= 0 && frames >= 0, "negative size");
+    HD_REQUIRE(thresh > 0 && ampl_max > 0, "thresh and ampl_max must be positive");
+    if (channels == 0 || frames == 0) return HIPDSP_OK;
+    HD_REQUIRE(x != nullptr && y != nullptr, "NULL data pointer");
+    HD_REQUIRE(x_pitch >= frames && y_pitch >= frames, "pitch smaller than row length");
+    HD_REQUIRE(channels <= 65535, "more than 65535 channels");
+    HD_CHECK_HIP(hipSetDevice(ctx->device));
+    const long long n_chunks = (frames + UW_CHUNK - 1) / UW_CHUNK;
+    HD_REQUIRE(n_chunks <= 0x7fffffffLL, "too many frames");
+    void *work = nullptr;
+    int rc = hipdsp_scratch(ctx, sizeof(int) * (size_t)n_chunks * (size_t)channels, &work);
+    if (rc != HIPDSP_OK) return rc;
+    int *counts = (int *)work;
+    const dim3 grid((unsigned)n_chunks, (unsigned)channels);
+    hipLaunchKernelGGL(unwrap_count_kernel, grid, dim3(256), 0, ctx->stream, x, (long long)x_pitch, (long long)frames,
+                       (float)thresh, counts, n_chunks);
+    hipLaunchKernelGGL(unwrap_scan_kernel, dim3((unsigned)channels), dim3(256), 0, ctx->stream, counts, n_chunks);
+    hipLaunchKernelGGL(unwrap_apply_kernel, grid, dim3(256), 0, ctx->stream, x, (long long)x_pitch, (long long)frames,
+                       (float)thresh, (float)(2.0 * ampl_max), clips, (clips || !down_scale) ? 1.0f : 0.5f, counts,
+                       n_chunks, y, (long long)y_pitch);
+    return hd_launch_status("unwrap kernels");
+}
+
+int hipdsp_band_order_stats(hipdsp_ctx *ctx, const float *x, int64_t rows, int64_t cols, int64_t row_stride,
+                            int64_t rank, float *out2)
+{
+    HD_REQUIRE(ctx != nullptr, "ctx is NULL");
+    HD_REQUIRE(rows >= 1 && cols >= 1 && row_stride >= cols, "bad shape");
+    HD_REQUIRE(rank >= 0 && rank < rows * cols, "rank %lld not in [0, %lld)", (long long)rank, (long long)(rows * cols));
+    HD_REQUIRE(rows * cols < (1LL << 32), "band too large for the 32-bit rank counters");
+    HD_REQUIRE(x != nullptr && out2 != nullptr, "NULL data pointer");
+    HD_CHECK_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(band_select_kernel, dim3(1), dim3(1024), 0, ctx->stream, x, (long long)rows, (long long)cols,
+                       (long long)row_stride, (long long)rank, out2);
+    return hd_launch_status("band_select_kernel");
 }
 
 int hipdsp_max_nonneg(hipdsp_ctx *ctx, const float *x, int64_t n, float *out)

@@ -33,8 +33,10 @@ constexpr int MAXD = 2 * MAXS;      // state dimension
 
 struct SosPlanDev {
     double coef[MAXS][5];           // b0 b1 b2 a1 a2
-    double G[L][MAXD];              // A^(L-1-j) B
-    double M[6][MAXD][MAXD];        // A^(L*2^k)
+    // the two tables are PACKED for the plan's own state dimension D = 2 * n_sections, so that a group of
+    // consecutive entries is one run of memory (one batch of wide scalar loads, sos_cascade.inc)
+    double G[L * MAXD];             // G[j * D + r] = (A^(L-1-j) B)[r]
+    double M[6 * MAXD * MAXD];      // M[k * D * D + r * D + c] = (A^(L*2^k))[r][c]
     double zi[MAXD];                // scipy sosfilt_zi, flattened (z0,z1) per section
     long long warm;                 // warm-up samples, multiple of TILE
     int n_sections;
@@ -435,7 +437,7 @@ struct BwdArgs {
     float gain;
 };
 
-template <int SE, bool PREFETCH>
+template <int SE, bool PREFETCH, bool PIN = true>
 __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restrict__ P0, BwdArgs a)
 {
     constexpr int DE = 2 * SE;
@@ -591,6 +593,7 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
 #define CASC_PLAN() PLAN_OF(P0)
 #define CASC_CARRY cfw_
 #define CASC_IN(v) (v)
+#define CASC_PIN_GROUPS PIN
 #include "sos_cascade.inc"
 #undef CASC_CARRY
         __syncthreads();
@@ -610,6 +613,7 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
 #define CASC_REVERSED
 #include "sos_cascade.inc"
 #undef CASC_REVERSED
+#undef CASC_PIN_GROUPS
 #undef CASC_S
 #undef CASC_PLAN
 #undef CASC_CARRY
@@ -961,7 +965,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
     do {                                                                                \
         if (((j) & 3) == 0) PEt = PLAN_OF(PE0);                                         \
         const double rd_ = (double)(tgain * fabsf(e));                                  \
-        _Pragma("unroll") for (int r_ = 0; r_ < DE; r_++) etap[r_] = fma(PEt->G[(j)][r_], rd_, etap[r_]); \
+        _Pragma("unroll") for (int r_ = 0; r_ < DE; r_++) etap[r_] = fma(PEt->G[(j) * DE + r_], rd_, etap[r_]); \
     } while (0)
 #include "sos_cascade.inc"
 #undef CASC_TAP
@@ -1112,6 +1116,10 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
         }
     } else {
         // ================= FFT role ===================================================================
+        // The FFT wave is the critical path of its pair (tools/chain_stamps.py: 94 % of its clocks inside the two
+        // FFTs of a tile, while the IIR wave waits 44 % of its own for the hand-over): it asks for the SIMD's
+        // issue slots first, the IIR waves fill the gaps (-2.2 % for the launch; "chain_debug" bit 64 = off)
+        if (!(a.debug & 64)) __builtin_amdgcn_s_setprio(3);
         float2 *fb = fbs[pair];
         const float *tlf = reinterpret_cast<const float *>(tiles[pair]);
         const float2 *tw2 = tab, *tw3 = tab + TW2, *twn = tab + TW2 + TW3, *win = tab + TW2 + TW3 + TWN;
@@ -1269,7 +1277,7 @@ int fill_plan(SosPlanDev *p, const double *sos, int S)
         double g[MAXD];
         for (int r = 0; r < D; r++) g[r] = B[r];
         for (int j = L - 1; j >= 0; j--) {
-            for (int r = 0; r < D; r++) p->G[j][r] = g[r];
+            for (int r = 0; r < D; r++) p->G[j * D + r] = g[r];
             double t[MAXD] = {0};
             for (int r = 0; r < D; r++)
                 for (int c = 0; c < D; c++) t[r] += A.v[r][c] * g[c];
@@ -1282,7 +1290,7 @@ int fill_plan(SosPlanDev *p, const double *sos, int S)
     static_assert(L == 32, "plan assumes L == 32");
     for (int k = 0; k < 6; k++) {
         for (int r = 0; r < D; r++)
-            for (int c = 0; c < D; c++) p->M[k][r][c] = pw.v[r][c];
+            for (int c = 0; c < D; c++) p->M[k * D * D + r * D + c] = pw.v[r][c];
         pw = mat_mul(pw, pw);
     }
     // pw == A^(L*64) == A^TILE.  warm = TILE * (smallest m with ||A^(TILE*m)|| < 2^-60)
@@ -1457,8 +1465,10 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
     dim3 grid((unsigned)blocks), block(64);
     switch (SE) {
     case 1:
-        if (ctx->sos_prefetch && frames >= 4 * TILE) hipLaunchKernelGGL((env_bwd_kernel<1, true>), grid, block, 0, ctx->stream, edev, b);
-        else hipLaunchKernelGGL((env_bwd_kernel<1, false>), grid, block, 0, ctx->stream, edev, b);
+        if (ctx->sos_prefetch && frames >= 4 * TILE) {
+            if (ctx->sos_no_pin) hipLaunchKernelGGL((env_bwd_kernel<1, true, false>), grid, block, 0, ctx->stream, edev, b);
+            else hipLaunchKernelGGL((env_bwd_kernel<1, true>), grid, block, 0, ctx->stream, edev, b);
+        } else hipLaunchKernelGGL((env_bwd_kernel<1, false>), grid, block, 0, ctx->stream, edev, b);
         break;
     case 2:
         if (ctx->sos_prefetch && frames >= 4 * TILE) hipLaunchKernelGGL((env_bwd_kernel<2, true>), grid, block, 0, ctx->stream, edev, b);

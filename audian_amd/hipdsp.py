@@ -377,6 +377,16 @@ def max_nonneg(ctx, x, n, out):
     check(lib.hipdsp_max_nonneg(ctx.handle, _p(x), int(n), _p(out)))
 
 
+def band_order_stats(ctx, x, rows, cols, row_stride, rank, out2):
+    check(lib.hipdsp_band_order_stats(ctx.handle, _p(x), int(rows), int(cols), int(row_stride), int(rank),
+                                      _p(out2)))
+
+
+def unwrap(ctx, x, x_pitch, channels, frames, thresh, y, y_pitch, ampl_max=1.0, clips=False, down_scale=True):
+    check(lib.hipdsp_unwrap(ctx.handle, _p(x), int(x_pitch), int(channels), int(frames), float(thresh),
+                            float(ampl_max), int(bool(clips)), int(bool(down_scale)), _p(y), int(y_pitch)))
+
+
 def pcm_unpack(ctx, pcm_tc, sample_bytes, frames, channels, scale, dst, dst_pitch):
     check(lib.hipdsp_pcm_unpack(ctx.handle, _p(pcm_tc), int(sample_bytes), int(frames), int(channels),
                                 float(scale), _p(dst), int(dst_pitch)))

@@ -65,6 +65,7 @@ int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
  *   "sos_waves_per_cu"   resident waves per CU the IIR segment planner aims for (16)
  *   "pool_limit_mb"      bytes (MiB) hipdsp_free may keep cached for hipdsp_malloc (1024)
  *   "sos_prefetch"       0: envelope sweeps without the register prefetch of the next tile (1)
+ *   "sos_no_pin"         non-zero: plan tables fetched by just-in-time scalar loads (A/B, tools/pin_ab.py)
  *   "force_generic_fft"  non-zero: every nfft takes the generic radix-2 / four-step kernels
  *   "spec_kernel"        0 = default per size, 2 = two-stage, 3 = three-stage FFT kernel
  *   "spec_fpw"           consecutive frames per wave (0 = automatic)
@@ -73,7 +74,9 @@ int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
  *                        hipdsp_chain_forward only copy their tiles, 2 = its IIR waves skip the cascades;
  *                        4 (results unchanged) = workgroup barriers instead of pairwise LDS flags;
  *                        8 = one FFT wave withholds one hand-over (test of the fault report below);
- *                        16 = clock counters of one wave into the first 16 bytes of the PSD
+ *                        16 = clock counters of one wave into the first 16 bytes of the PSD;
+ *                        32 = diagnostic build: db_out receives 16 clock sums per wave (tools/chain_stamps.py);
+ *                        64 = FFT waves without their raised issue priority
  * Device-side faults: the waits between the waves of hipdsp_chain_forward's kernel are bounded; a wave
  * whose wait runs out writes a fault word owned by the context and ends the launch early.
  * hipdsp_ctx_synchronize, hipdsp_memcpy_d2h, hipdsp_event_elapsed_ms and the next
@@ -326,6 +329,28 @@ int hipdsp_stride_copy(hipdsp_ctx *ctx, const float *x, int64_t n, int64_t step,
  * hipdsp_memcpy2d_d2d it serves BufferedSpectrogram.estimate_noiselevels
  * (bufferedspectrogram.py:109-126: max dB = decibel(max power), P95 of the top 1/16 band). */
 int hipdsp_max_nonneg(hipdsp_ctx *ctx, const float *x, int64_t n, float *out);
+
+/* out2[0], out2[1] = the order statistics of rank `rank` and `rank + 1` (zero based, ascending; the second
+ * clamped to the last) of the rows x cols non-negative floats x[i * row_stride + j] -- what
+ * np.percentile(..., 95) interpolates between in BufferedSpectrogram.estimate_noiselevels
+ * (bufferedspectrogram.py:115-117: the top F/16 bins of one channel's (frames, F) slab; decibel is
+ * monotonic, so the percentile of the dB values is the interpolation of the dB of these two).  Exact
+ * (radix select on the float bits), one workgroup, nothing but two floats leaves the device. */
+int hipdsp_band_order_stats(hipdsp_ctx *ctx, const float *x, int64_t rows, int64_t cols, int64_t row_stride,
+                            int64_t rank, float *out2);
+
+/* audioio's unwrap() of clipped recordings, which the reference arms on its raw loader for every buffer
+ * it loads (Data.open -> self.data.set_unwrap(unwrap, unwrap_clip, False, unit), src/audian/data.py:180;
+ * CLI -u / -U, src/audian/audian.py:1485-1512, default threshold 1.5): a step between successive samples
+ * beyond `thresh` is a wrap-around of a signal that left [-ampl_max, ampl_max); from there on 2 * ampl_max
+ * is subtracted (step up) or added (step down), cumulatively along time, per channel, starting from
+ * zero at the first frame of the slab.  Then `clips`: clip to +-ampl_max; else `down_scale`: halve.
+ * Planar float32 in and out; x and y must not overlap (a chunk reads the last sample of the chunk
+ * before it while that one is being written).  audioio's source is neither in the reference tree nor
+ * in this image: restated from its documentation and the reference's call sites, parity unpinned.
+ * Uses the context scratch (4 bytes per 16384 frames and channel). */
+int hipdsp_unwrap(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, int64_t channels, int64_t frames,
+                  double thresh, double ampl_max, int clips, int down_scale, float *y, int64_t y_pitch);
 
 /* PCM ingest: interleaved little-endian signed PCM (frames, channels) of 2, 3 or 4 bytes per
  * sample -> planar float32 times `scale` (1/2^(bits-1) reproduces the [-1, 1) floats that

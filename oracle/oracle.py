@@ -296,3 +296,22 @@ def play_data(data, rate, i0, i1, show_channels, heterodyne_freq=None, sos=None)
         playdata = sosfiltfilt(sos, playdata)[::nstep]
         rate /= nstep
     return playdata, rate
+
+
+def unwrap(data, thresh, ampl_max=1.0, clips=False, down_scale=True):
+    """audioio's unwrap() as the reference arms it on its raw loader (src/audian/data.py:180,
+    src/audian/audian.py:1485-1512), restated from its documentation (source absent: parity unpinned):
+    a step between successive samples beyond `thresh` is a wrap-around; from there on 2*ampl_max is
+    subtracted (step up) or added (step down), cumulatively along axis 0.  float32 arithmetic like the
+    device path (the raw buffer it is applied to holds the file's float32/PCM samples)."""
+    x = np.asarray(data, dtype=np.float32)
+    d = np.diff(x, axis=0)
+    ev = (d < -np.float32(thresh)).astype(np.int64) - (d > np.float32(thresh)).astype(np.int64)
+    k = np.zeros(x.shape, dtype=np.int64)
+    k[1:] = np.cumsum(ev, axis=0)
+    y = x + np.float32(2.0*ampl_max)*k.astype(np.float32)
+    if clips:
+        y = np.clip(y, -np.float32(ampl_max), np.float32(ampl_max))
+    elif down_scale:
+        y = y*np.float32(0.5)
+    return y.astype(np.float32)

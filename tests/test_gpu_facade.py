@@ -448,3 +448,61 @@ def test_playback_chain_matches_reference_arithmetic(oracle):
         for k in range(want.shape[1]):
             assert rel_err(got[:, k], want[:, k]) < TOL, (chans, het, k)
     assert grate == rate/5                      # round(192000 / 40000) = 5
+
+
+def test_loader_unwrap_and_lazy_source(oracle):
+    """Two contract points of the raw side of the chain:
+    * Data.open arms audioio's unwrap() on the loader (src/audian/data.py:180): every slab the loader reads
+      is unwrapped (device kernels) before anything else sees it -- "restated from documentation, unpinned";
+    * a BufferedData subclass may read the `source` argument of process() itself
+      (src/audian/buffereddata.py:91-109): it must see the source trace's current values although these
+      live in the device mirror only (the host copy is stale until somebody reads it)."""
+    from audian_amd.bufferedarray import ArrayLoader
+    from audian_amd.buffereddata import BufferedData
+    from audian_amd.bufferedfilter import BufferedFilter
+    rate, seconds, C = 48000.0, 3.0, 2
+    n = int(rate*seconds)
+    t = np.arange(n)/rate
+    true = np.stack([1.8*np.sin(2*np.pi*30.0*t), 2.2*np.sin(2*np.pi*45.0*t)], axis=1)     # starts inside the range
+    wrapped = ((true + 1.0) % 2.0 - 1.0).astype(np.float32).astype(np.float64)
+    data = ArrayLoader(wrapped, rate, buffer_time=2.0, back_time=0.5, view=True)
+    assert np.array_equal(data.buffer, wrapped[:len(data.buffer)])
+    data.set_unwrap(1.5, False, False, data.unit)                       # the reference's call
+    assert (data.ampl_min, data.ampl_max) == (-2.0, 2.0)
+    want = oracle.unwrap(wrapped[:len(data.buffer)], 1.5, clips=False, down_scale=False)
+    assert np.array_equal(data.buffer, want.astype(np.float64))
+    assert np.max(np.abs(data.buffer - true[:len(data.buffer)])) < 1e-5
+    data.set_unwrap(1.5, True, False, data.unit)                        # -U: clip instead
+    assert (data.ampl_min, data.ampl_max) == (-1.0, 1.0)
+    assert np.array_equal(data.buffer, np.clip(want, -1, 1).astype(np.float64))
+    data.set_unwrap(0.0)
+    assert np.array_equal(data.buffer, wrapped[:len(data.buffer)])
+
+    # a trace that reads `source` on the host, downstream of a device-resident filter
+    class Doubler(BufferedData):
+        def __init__(self):
+            BufferedData.__init__(self, 'double', 'filtered', panel='trace')
+
+        def process(self, source, dest, nbefore):
+            self._pending = None
+            dest[:, :] = 2.0*np.asarray(source)[nbefore:nbefore + len(dest)]
+
+    x = recording(rate, seconds, C)
+    raw = ArrayLoader(x, rate, buffer_time=2.0, back_time=0.5)
+    filt = BufferedFilter()
+    filt.open(raw)
+    filt.highpass_cutoff, filt.lowpass_cutoff = 300.0, 3000.0
+    filt.need_update = True
+    filt.update()
+    filt.align_buffer()
+    assert filt._stale                                                   # results are on the device only
+    dbl = Doubler()
+    dbl.open(filt)
+    dbl.need_update = True
+    dbl.align_buffer()
+    got = np.asarray(dbl.buffer)
+    ref = np.zeros((len(raw.buffer), C))
+    oracle.filter_process(filt.sos, raw.buffer, ref, 0)
+    assert len(got) == len(ref)
+    for c in range(C):
+        assert rel_err(got[:, c], 2.0*ref[:, c]) < TOL

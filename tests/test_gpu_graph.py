@@ -211,3 +211,98 @@ def test_live_sliding_window_in_captured_graphs(oracle):
         assert rel_err(gf[ch], wf[:, ch]) < 1e-4 and rel_err(ge[ch], we[:, ch]) < 1e-4
     for g in graphs:
         ctx.graph_destroy(g)
+
+
+def test_configs4_full_size_cutoff_sweep(oracle):
+    """BASELINE configs[4] at its stated size: 16 ch x 192 kHz, 80 s resident window (buffer_time 60 s +
+    10 s pre-roll + 10 s post-roll, data.py:17,168), the recompute that DataBrowser.update_filter triggers
+    (filter -> spectrogram + dB image -> envelope, databrowser.py:1264-1288) captured ONCE into a hipGraph
+    and replayed 300 times while hp sweeps 100 -> 2000 Hz and lp 20 kHz -> 4 kHz.  The 30 FPS
+    claim is asserted here (median replay, host wall clock incl. the plan update, < 33 ms) and the results
+    of the first, a middle and the last replay are compared with the oracle on windows of every array."""
+    import time
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rate, C, seconds, nfft, hop = 192000.0, 16, 80.0, 2048, 1024
+    T = int(rate*seconds)
+    F = nfft//2 + 1
+    nd = (T + hop - 1)//hop
+    ctx = hipdsp.Context(0)
+    stream = ctx.create_stream()
+    ctx.set_stream(stream)
+    dx = hipdsp.DeviceArray(ctx, (C, T), np.float32)
+    df = hipdsp.DeviceArray(ctx, (C, T), np.float32)
+    de = hipdsp.DeviceArray(ctx, (C, T), np.float32)
+    ds = hipdsp.DeviceArray(ctx, (C, nd, F), np.float32)
+    db = hipdsp.DeviceArray(ctx, (C, nd, F), np.float32)
+    hipdsp.synth(ctx, dx, T, C, T, rate, 1234 + 4)
+    esos = butter_sos(2, 500.0, 'lowpass', rate)           # BufferedEnvelope defaults (bufferedenvelope.py:15-16)
+    n_replays = 300
+    hps = np.linspace(100.0, 2000.0, n_replays)
+    lps = np.linspace(20000.0, 4000.0, n_replays)
+    plan = hipdsp.SosPlan(ctx, butter_sos(2, (hps[0], lps[0]), 'bandpass', rate))
+    eplan = hipdsp.SosPlan(ctx, esos)
+
+    def chain():
+        plan.upload()
+        hipdsp.chain_forward(ctx, plan, eplan, dx, T, df, T, C, T, nfft, hop, rate, ds, nd, db_out=db)
+        hipdsp.sosfilt_envelope(ctx, plan, eplan, dx, T, df, T, de, T, C, T, phase=2)
+
+    chain()                                                 # warm: FFT tables, envelope scratch
+    ctx.synchronize()
+    ctx.graph_begin()
+    chain()
+    graph = ctx.graph_end()
+
+    def window(arr, ch, off, n):
+        return arr.view(ch*T + off, (n,)).to_host().astype(np.float64)
+
+    def check(i):
+        sos = butter_sos(2, (hps[i], lps[i]), 'bandpass', rate)
+        rng = np.random.default_rng(i)
+        lead_f, lead_e, n = 120000, 20000, 8192             # hp 100 Hz at 192 kHz forgets slowly
+        for _ in range(3):
+            ch = int(rng.integers(0, C))
+            off = int(rng.integers(lead_f + lead_e, T - n - lead_e))
+            x = window(dx, ch, off - lead_e - lead_f, lead_f + n + 2*lead_e)
+            filt = oracle.sosfilt(sos, x)[lead_f:]                   # [off - lead_e, off + n + lead_e)
+            assert rel_err(window(df, ch, off, n), filt[lead_e:lead_e + n]) < 1e-4, (i, ch, off)
+            env = np.zeros((len(filt), 1))
+            oracle.envelope_process(esos, filt[:, None], env, 0)
+            assert rel_err(window(de, ch, off, n), env[lead_e:lead_e + n, 0]) < 1e-4, (i, ch, off)
+            k = (off + hop - 1)//hop
+            seg = window(df, ch, k*hop, nfft)
+            want = np.zeros((1, 1, F))
+            oracle.spectrogram_process(seg[:, None], want, rate, nfft, hop)
+            row = ds.view((ch*nd + k)*F, (F,)).to_host().astype(np.float64)
+            assert rel_err(row, want[0, 0]) < 1e-4, (i, ch, k)
+            drow = db.view((ch*nd + k)*F, (F,)).to_host().astype(np.float64)
+            wdb = oracle.decibel(row)
+            fin = np.isfinite(wdb)
+            assert np.array_equal(np.isfinite(drow), fin) and np.max(np.abs(drow[fin] - wdb[fin])) < 1e-3
+        # both ends of a channel: true start (zero state, odd extension) and the end
+        x = window(dx, 0, 0, n + lead_e)
+        filt = oracle.sosfilt(sos, x)
+        assert rel_err(window(df, 0, 0, n), filt[:n]) < 1e-4
+        env = np.zeros((len(filt), 1))
+        oracle.envelope_process(esos, filt[:, None], env, 0)
+        assert rel_err(window(de, 0, 0, n), env[:n, 0]) < 1e-4
+
+    times = []
+    for i in range(n_replays):
+        t0 = time.perf_counter()
+        plan.set_host(butter_sos(2, (hps[i], lps[i]), 'bandpass', rate))   # host only: the captured upload carries it
+        ctx.graph_launch(graph)
+        ctx.synchronize()
+        times.append(time.perf_counter() - t0)
+        if i in (0, n_replays//2, n_replays - 1):
+            check(i)
+    med = float(np.median(times))*1e3
+    worst = float(np.max(times))*1e3
+    print(f'configs[4]: {n_replays} replays, median {med:.2f} ms, worst {worst:.2f} ms per recompute')
+    assert med < 33.0, f'median replay {med:.2f} ms misses 30 FPS'
+    ctx.graph_destroy(graph)
+    ctx.set_stream(None)
+    ctx.destroy_stream(stream)
+    for a in (dx, df, de, ds, db):
+        a.free()

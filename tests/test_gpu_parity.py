@@ -528,3 +528,65 @@ def test_chain_forward_equals_separate_calls(oracle, T, max_segments, handover):
     finally:
         c.set_max_segments(0)
         c.set_option('chain_debug', 0)
+
+
+@pytest.mark.parametrize('rows,cols,stride', [(1, 1, 1), (7, 3, 5), (938, 64, 1025), (5000, 8, 129), (40000, 64, 1025)])
+def test_band_order_stats_bit_exact(rows, cols, stride):
+    """hipdsp_band_order_stats: the two order statistics np.percentile(.., 95) interpolates between, for the
+    top-band slab of BufferedSpectrogram.estimate_noiselevels (bufferedspectrogram.py:115-117) -- exact,
+    including ties, exact zeros (decibel -> -inf) and a rank that is the last element."""
+    from audian_amd import hipdsp
+    c = gh.ctx()
+    rng = np.random.default_rng(rows*cols)
+    full = (rng.standard_normal((rows, stride))**2).astype(np.float32)
+    full[rng.random((rows, stride)) < 0.05] = 0.0                      # exact zeros
+    full[:, :2] = full[0, 0]                                           # ties
+    band = full[:, stride - cols:]
+    d = hipdsp.DeviceArray.from_host(c, full)
+    out = hipdsp.DeviceArray(c, (2,), np.float32)
+    srt = np.sort(band.ravel())
+    n = rows*cols
+    for rank in sorted({0, int(np.floor(0.95*(n - 1))), n//2, n - 1}):
+        hipdsp.band_order_stats(c, d.view(stride - cols, (1,)), rows, cols, stride, rank, out)
+        got = out.to_host()
+        assert got[0] == srt[rank] and got[1] == srt[min(rank + 1, n - 1)], (rank, got, srt[rank])
+    # np.percentile itself from the two statistics
+    pos = 0.95*(n - 1)
+    k = int(np.floor(pos))
+    hipdsp.band_order_stats(c, d.view(stride - cols, (1,)), rows, cols, stride, k, out)
+    lo, hi = out.to_host().astype(np.float64)
+    assert abs((lo + (pos - k)*(hi - lo)) - np.percentile(band.astype(np.float64), 95)) <= 1e-12*max(1.0, hi)
+    with pytest.raises(ValueError):
+        hipdsp.band_order_stats(c, d, rows, cols, stride, n, out)
+
+
+@pytest.mark.parametrize('T', [1, 5, 1023, 1024, 16384, 16385, 100000, 1200000])
+def test_unwrap_matches_the_restated_audioio_algorithm(oracle, T):
+    """hipdsp_unwrap (src/audian/data.py:180 -> audioio's unwrap() on the raw loader's buffers): a signal
+    that left [-1, 1) and wrapped around in the file is put back together.  audioio's source is not in
+    the reference tree nor in this image, so the oracle is restated from its documentation -- "restated
+    from documentation, unpinned" -- and the device path is held to that restatement bit for bit; in
+    addition the true (unwrapped) signal must come back exactly wherever it can be represented."""
+    from audian_amd import hipdsp
+    c = gh.ctx()
+    rate, C = 48000.0, 3
+    t = np.arange(T)/rate
+    rng = np.random.default_rng(T)
+    # (every channel starts inside the range: a slab that begins wrapped cannot be told from one that does not)
+    true = np.stack([2.6*np.sin(2*np.pi*(40.0 + 13*ch)*t) + 0.05*rng.standard_normal(T) for ch in range(C)], axis=1)
+    wrapped = ((true + 1.0) % 2.0 - 1.0).astype(np.float32)          # what the 16-bit file would hold
+    dx = gh.to_planar(c, wrapped)
+    for thresh, clips, down in [(1.5, False, True), (1.5, True, False), (1.5, False, False), (1.0, False, True)]:
+        dy = hipdsp.DeviceArray(c, (C, T), np.float32)
+        hipdsp.unwrap(c, dx, T, C, T, thresh, dy, T, clips=clips, down_scale=down)
+        got = dy.to_host().T
+        want = oracle.unwrap(wrapped, thresh, clips=clips, down_scale=down)
+        assert np.array_equal(got, want), (T, thresh, clips, down)
+    if T > 1:
+        # with neither clipping nor down-scaling the original comes back (steps of the true signal stay
+        # far below the threshold at these frequencies)
+        dy = hipdsp.DeviceArray(c, (C, T), np.float32)
+        hipdsp.unwrap(c, dx, T, C, T, 1.5, dy, T, clips=False, down_scale=False)
+        assert np.max(np.abs(dy.to_host().T - true)) < 1e-5
+    with pytest.raises(ValueError):
+        hipdsp.unwrap(c, dx, T, C, T, 0.0, dx, T)

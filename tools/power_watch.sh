@@ -4,9 +4,9 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/power; mkdir -p $O
 rocm-smi --showpower --showclocks --showmaxpower --showperflevel > $O/idle.txt 2>&1
-LOOP=400 python3 $R/tools/chain_loop.py > $O/loop.log 2>&1 &
+LOOP=${LOOP:-400} WHICH=${WHICH:-fwd} python3 $R/tools/chain_loop.py > $O/loop.log 2>&1 &
 PID=$!
-sleep 4
+sleep ${SLEEP:-4}
 for i in 1 2 3 4 5 6; do
   rocm-smi --showpower --showclocks -t > $O/busy_$i.txt 2>&1
   sleep 0.7
