@@ -21,6 +21,7 @@ class BufferedEnvelope(BufferedData):
         self.envelope_cutoff, self.highpass_cutoff = envelope_cutoff, highpass_cutoff
         self.filter_order, self.sos = filter_order, None
         self._plan = None
+        self._plans = []           # cascades longer than one plan: chained plans (hipdsp_envelope_multi)
 
     def open(self, source):
         BufferedData.open(self, source)
@@ -46,9 +47,15 @@ class BufferedEnvelope(BufferedData):
                             len(dest), 0)
         else:
             dsrc, spitch, keep = self._device_source(source, call)
-            hipdsp.envelope(self.ctx, self._plan, dsrc, spitch, ddst, dpitch, self.channels,
-                            len(source), nbefore, rectify=True, gain=np.pi/2,
-                            clamp=self.highpass_cutoff == 0)
+            if self._plans:
+                # more sections than one plan holds: sosfiltfilt step by step over the chained plans
+                hipdsp.envelope_multi(self.ctx, self._plans, dsrc, spitch, ddst, dpitch, self.channels,
+                                      len(source), nbefore, rectify=True, gain=np.pi/2,
+                                      clamp=self.highpass_cutoff == 0)
+            else:
+                hipdsp.envelope(self.ctx, self._plan, dsrc, spitch, ddst, dpitch, self.channels,
+                                len(source), nbefore, rectify=True, gain=np.pi/2,
+                                clamp=self.highpass_cutoff == 0)
         self._finish_dest(dest, ddst, dpitch, is_mirror, call)
         if keep is not None or not is_mirror:
             self.ctx.synchronize()
@@ -64,11 +71,13 @@ class BufferedEnvelope(BufferedData):
             self.sos = butter_sos(self.filter_order, wn, 'bandpass' if band else 'lowpass', self.rate)
         except ValueError:
             self.sos = None
-        if self.sos is not None:
-            if len(self.sos) > _lib.MAX_SECTIONS:
-                raise NotImplementedError(
-                    f'envelope filters with more than {_lib.MAX_SECTIONS} second-order sections '
-                    '(the zi-scaled forward-backward pass is not split over plans)')
+        self._plans = []
+        if self.sos is not None and len(self.sos) > _lib.MAX_SECTIONS:
+            # any filter_order is legal in the reference (bufferedenvelope.py:13-16): cascades that do not
+            # fit one plan run as chained plans (hipdsp_envelope_multi)
+            chunk = _lib.MAX_SECTIONS
+            self._plans = [hipdsp.SosPlan(self.ctx, self.sos[i:i + chunk]) for i in range(0, len(self.sos), chunk)]
+        elif self.sos is not None:
             if self._plan is None:
                 self._plan = hipdsp.SosPlan(self.ctx, self.sos)
             else:

@@ -53,6 +53,11 @@ struct SeqArgs {
     long long seg_len;      // multiple of TILE
     int n_seg;
     long long skip;         // nbefore: the first `skip` outputs are dropped
+    // optional initial state of the cascade at sample 0 (scipy: sosfilt(..., zi = sosfilt_zi * x0)):
+    // plan zi * zi_scale * zi_ref[channel * zi_ref_pitch]; NULL = zero state
+    const float *zi_ref;
+    long long zi_ref_pitch;
+    double zi_scale;
 };
 
 __device__ __forceinline__ long long opaque_zero()
@@ -153,6 +158,13 @@ __global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *__restri
     double carry[D];
 #pragma unroll
     for (int r = 0; r < D; r++) carry[r] = 0.0;
+    if (a.zi_ref != nullptr && start == 0) {
+        // the true state at sample 0 (every other segment forgets it within its warm-up)
+        const SosPlanDev *P = PLAN_OF(P0);
+        const double x0 = a.zi_scale * (double)a.zi_ref[ch * a.zi_ref_pitch];
+#pragma unroll
+        for (int r = 0; r < D; r++) carry[r] = P->zi[r] * x0;
+    }
 
     for (long long tile = start; tile < hi; tile += TILE) {
         // ---- HBM -> LDS (coalesced 16 B per lane), LDS -> registers (row per lane)
@@ -651,6 +663,47 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
         }
         __syncthreads();
     }
+}
+
+// ---- building blocks of sosfiltfilt for cascades longer than one plan (hipdsp_envelope_multi) -------
+// ext = odd extension of r = gain * |x| (or x) by `edge` samples on both sides (scipy odd_ext,
+// scipy/signal/_arraytools.py:99-107), float32 arithmetic like the fused kernels
+__global__ void odd_ext_kernel(const float *__restrict__ x, long long x_pitch, long long T, int edge, int rectify,
+                               float gain, float *__restrict__ out, long long out_pitch)
+{
+    const long long ch = blockIdx.y;
+    const float *xc = x + ch * x_pitch;
+    float *oc = out + ch * out_pitch;
+    const long long N = T + 2LL * edge;
+    auto r = [&](long long k) { const float v = xc[k]; return rectify ? gain * fabsf(v) : v; };
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
+        float v;
+        if (i < edge) v = 2.f * r(0) - r(edge - i);
+        else if (i < edge + T) v = r(i - edge);
+        else v = 2.f * r(T - 1) - r(T - 2 - (i - edge - T));
+        oc[i] = v;
+    }
+}
+
+// y[c][i] = x[c][N - 1 - (first + i)], i < n, optionally clamped at zero: time reversal (and the final trim)
+__global__ void flip_kernel(const float *__restrict__ x, long long x_pitch, long long N, long long first, long long n,
+                            int clamp, float *__restrict__ y, long long y_pitch)
+{
+    const long long ch = blockIdx.y;
+    const float *xc = x + ch * x_pitch;
+    float *yc = y + ch * y_pitch;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = xc[N - 1 - (first + i)];
+        if (clamp) v = fmaxf(v, 0.f);
+        yc[i] = v;
+    }
+}
+
+// ref[c] = x[c][0]
+__global__ void first_sample_kernel(const float *__restrict__ x, long long x_pitch, long long channels, float *__restrict__ ref)
+{
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < channels) ref[c] = x[c * x_pitch];
 }
 
 // pass-through / zero fill for the sos-is-None branches
@@ -1757,6 +1810,87 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     }
 #undef HD_CHAIN
     return hd_launch_status("chain_fwd_kernel");
+}
+
+int hipdsp_envelope_multi(hipdsp_ctx *ctx, const hipdsp_sosplan *const *plans, int n_plans, const float *x,
+                          int64_t x_pitch, float *y, int64_t y_pitch, int64_t channels, int64_t frames, int64_t skip,
+                          int rectify, double gain, int clamp)
+{
+    HD_REQUIRE(ctx != nullptr && plans != nullptr, "NULL argument");
+    HD_REQUIRE(n_plans >= 1 && n_plans <= 16, "n_plans %d not in 1..16", n_plans);
+    HD_REQUIRE(channels >= 0 && frames >= 0, "negative size");
+    HD_REQUIRE(skip >= 0 && skip <= frames, "skip %lld not in [0, frames=%lld]", (long long)skip, (long long)frames);
+    HD_REQUIRE(channels <= 65535, "more than 65535 channels");
+    // pad length and the DC gain in front of every plan, from the whole cascade (scipy sosfiltfilt / sosfilt_zi)
+    int total = 0, nb = 0, na = 0;
+    double gain_before[16];
+    double g = 1.0;
+    for (int p = 0; p < n_plans; p++) {
+        HD_REQUIRE(plans[p] != nullptr && plans[p]->host->n_sections > 0, "plan %d has no coefficients", p);
+        gain_before[p] = g;
+        const SosPlanDev *h = plans[p]->host;
+        for (int sct = 0; sct < h->n_sections; sct++) {
+            const double b0 = h->coef[sct][0], b1 = h->coef[sct][1], b2 = h->coef[sct][2];
+            const double a1 = h->coef[sct][3], a2 = h->coef[sct][4];
+            if (b2 == 0.0) nb++;
+            if (a2 == 0.0) na++;
+            g *= (b0 + b1 + b2) / (1.0 + a1 + a2);
+        }
+        total += h->n_sections;
+    }
+    const int edge = 3 * (2 * total + 1 - (nb < na ? nb : na));
+    HD_CHECK_HIP(hipSetDevice(ctx->device));
+    if (frames <= edge) {
+        hipdsp_set_error("The length of the input vector x must be greater than padlen, which is %d.", edge);
+        return HIPDSP_ERR_TOO_SHORT;
+    }
+    if (channels == 0 || frames - skip == 0) return HIPDSP_OK;
+    HD_REQUIRE(x != nullptr && y != nullptr, "NULL data pointer");
+    HD_REQUIRE(x_pitch >= frames && y_pitch >= frames - skip, "pitch smaller than row length");
+    const long long N = frames + 2LL * edge;
+    float *buf[2] = {nullptr, nullptr}, *ref = nullptr;
+    int rc = hipdsp_malloc(ctx, sizeof(float) * (size_t)N * (size_t)channels, (void **)&buf[0]);
+    if (rc == HIPDSP_OK) rc = hipdsp_malloc(ctx, sizeof(float) * (size_t)N * (size_t)channels, (void **)&buf[1]);
+    if (rc == HIPDSP_OK) rc = hipdsp_malloc(ctx, sizeof(float) * (size_t)channels, (void **)&ref);
+    auto cleanup = [&]() {
+        (void)hipdsp_free(ctx, buf[0]);
+        (void)hipdsp_free(ctx, buf[1]);
+        (void)hipdsp_free(ctx, ref);
+    };
+    if (rc != HIPDSP_OK) { cleanup(); return rc; }
+    const unsigned gx = (unsigned)((N + 1023) / 1024 > 4096 ? 4096 : (N + 1023) / 1024);
+    const dim3 grid(gx, (unsigned)channels);
+    hipLaunchKernelGGL(odd_ext_kernel, grid, dim3(256), 0, ctx->stream, x, (long long)x_pitch, (long long)frames, edge,
+                       rectify, (float)gain, buf[0], N);
+    int cur = 0;
+    for (int pass = 0; pass < 2 && rc == HIPDSP_OK; pass++) {
+        // initial state of every section: its zi times the first sample of what the whole cascade is fed
+        hipLaunchKernelGGL(first_sample_kernel, dim3((unsigned)((channels + 255) / 256)), dim3(256), 0, ctx->stream,
+                           buf[cur], N, (long long)channels, ref);
+        for (int p = 0; p < n_plans && rc == HIPDSP_OK; p++) {
+            SeqArgs a;
+            memset(&a, 0, sizeof(a));
+            a.in = buf[cur]; a.out = buf[cur ^ 1]; a.in_pitch = N; a.out_pitch = N;
+            a.N = N; a.skip = 0;
+            a.zi_ref = ref; a.zi_ref_pitch = 1; a.zi_scale = gain_before[p];
+            rc = launch_scan(ctx, plans[p]->dev, plans[p]->host->n_sections, a, channels, plans[p]->host->warm);
+            cur ^= 1;
+        }
+        if (rc != HIPDSP_OK) break;
+        if (pass == 0) {
+            hipLaunchKernelGGL(flip_kernel, grid, dim3(256), 0, ctx->stream, buf[cur], N, N, 0LL, N, 0, buf[cur ^ 1], N);
+            cur ^= 1;
+        } else {
+            // undo the reversal, drop the extensions and the first `skip` frames, clamp
+            const long long n = frames - skip;
+            const unsigned gy = (unsigned)((n + 1023) / 1024 > 4096 ? 4096 : (n + 1023) / 1024);
+            hipLaunchKernelGGL(flip_kernel, dim3(gy, (unsigned)channels), dim3(256), 0, ctx->stream, buf[cur], N, N,
+                               (long long)edge + (long long)skip, n, clamp, y, (long long)y_pitch);
+        }
+    }
+    if (rc == HIPDSP_OK) rc = hd_launch_status("envelope_multi kernels");
+    cleanup();
+    return rc;
 }
 
 int hipdsp_chain_plan(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hipdsp_sosplan *eplan,

@@ -297,6 +297,15 @@ def envelope(ctx, plan, x, x_pitch, y, y_pitch, channels, frames, skip=0, rectif
                               float(gain), int(bool(clamp))))
 
 
+def envelope_multi(ctx, plans, x, x_pitch, y, y_pitch, channels, frames, skip=0, rectify=True,
+                   gain=np.pi/2, clamp=True):
+    """sosfiltfilt envelope over a cascade split into several plans (hipdsp_envelope_multi)."""
+    arr = (ctypes.c_void_p*len(plans))(*[p.handle for p in plans])
+    check(lib.hipdsp_envelope_multi(ctx.handle, arr, len(plans), _p(x), int(x_pitch), _p(y), int(y_pitch),
+                                    int(channels), int(frames), int(skip), int(bool(rectify)), float(gain),
+                                    int(bool(clamp))))
+
+
 def sosfilt_envelope(ctx, fplan, eplan, x, x_pitch, yf, yf_pitch, env, env_pitch, channels, frames,
                      rectify=True, gain=np.pi/2, clamp=True, phase=0):
     check(lib.hipdsp_sosfilt_envelope(ctx.handle, fplan.handle, eplan.handle, _p(x), int(x_pitch),

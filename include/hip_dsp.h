@@ -241,6 +241,20 @@ int hipdsp_sosfilt_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan,
                             int64_t channels, int64_t frames, int rectify, double gain, int clamp,
                             int phase);
 
+/* BufferedEnvelope.process for cascades LONGER than HIPDSP_MAX_SECTIONS (the reference accepts any
+ * filter_order: bufferedenvelope.py:13-16,44-55; a band-pass envelope of order >= 5 or a low-pass of
+ * order >= 9 has more than four sections): the SOS table is split over `n_plans` plans (in cascade order,
+ * each <= HIPDSP_MAX_SECTIONS sections) and scipy's sosfiltfilt (scipy/signal/_signaltools.py:4807-4828) is
+ * run step by step -- odd extension by padlen of the WHOLE cascade, forward pass from zi * ext[0], time
+ * reversal, forward pass from zi * y[-1], reversal and trim -- where every plan starts from its own
+ * sosfilt_zi scaled by the DC gain of the sections in front of it, exactly as sosfilt_zi of the whole table
+ * would give.  The hand-over between plans is float32.  Same arguments and errors as hipdsp_envelope
+ * (HIPDSP_ERR_TOO_SHORT when frames <= padlen); 56 instead of 16 bytes per sample, two temporaries of
+ * (channels, frames + 2 padlen) floats from the context's block cache. */
+int hipdsp_envelope_multi(hipdsp_ctx *ctx, const hipdsp_sosplan *const *plans, int n_plans, const float *x,
+                          int64_t x_pitch, float *y, int64_t y_pitch, int64_t channels, int64_t frames,
+                          int64_t skip, int rectify, double gain, int clamp);
+
 /* The forward half of the batch chain in ONE pass over x: BufferedFilter.process
  * (bufferedfilter.py:31-36) writes yf, the envelope's forward sweep parks its tile states in the
  * context scratch exactly like hipdsp_sosfilt_envelope(..., phase = 1), and

@@ -506,3 +506,38 @@ def test_loader_unwrap_and_lazy_source(oracle):
     assert len(got) == len(ref)
     for c in range(C):
         assert rel_err(got[:, c], 2.0*ref[:, c]) < TOL
+
+
+def test_envelope_of_any_order_through_the_facade(oracle):
+    """BufferedEnvelope(filter_order=5, highpass_cutoff=10): five second-order sections, one more than a
+    device plan holds (src/audian/bufferedenvelope.py:13-16,44-55 accept any order) -- must match the
+    oracle, not raise."""
+    from audian_amd.bufferedarray import ArrayLoader
+    from audian_amd.bufferedfilter import BufferedFilter
+    from audian_amd.bufferedenvelope import BufferedEnvelope
+    rate, seconds, C = 48000.0, 4.0, 2
+    x = recording(rate, seconds, C)
+    raw = ArrayLoader(x, rate, buffer_time=3.0, back_time=0.5)
+    filt = BufferedFilter()
+    filt.open(raw)
+    filt.highpass_cutoff, filt.lowpass_cutoff = 300.0, 3000.0
+    filt.need_update = True
+    filt.update()
+    filt.align_buffer()
+    for order, hp, cut in [(5, 10.0, 500.0), (9, 0.0, 300.0)]:
+        env = BufferedEnvelope(envelope_cutoff=cut, filter_order=order, highpass_cutoff=hp)
+        env.open(filt)
+        assert len(env.sos) > 4
+        env.need_update = True
+        env.align_buffer()
+        got = np.asarray(env.buffer)
+        src = np.asarray(filt.buffer)
+        want = np.zeros_like(got)
+        nb = len(src) - len(got)
+        oracle.envelope_process(env.sos, src[:len(src)], want if nb == 0 else np.zeros((len(src), C)), 0, hp)
+        if nb != 0:      # the envelope trace trims its margins: recompute exactly what process() saw
+            full = np.zeros((len(src), C))
+            oracle.envelope_process(env.sos, src, full, 0, hp)
+            want = full[:len(got)]
+        for c in range(C):
+            assert rel_err(got[:, c], want[:, c]) < TOL, (order, c)

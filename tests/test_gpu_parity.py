@@ -590,3 +590,48 @@ def test_unwrap_matches_the_restated_audioio_algorithm(oracle, T):
         assert np.max(np.abs(dy.to_host().T - true)) < 1e-5
     with pytest.raises(ValueError):
         hipdsp.unwrap(c, dx, T, C, T, 0.0, dx, T)
+
+
+@pytest.mark.parametrize('T', [60, 2500, 70000, 400000])
+def test_envelope_cascades_longer_than_one_plan(oracle, T):
+    """hipdsp_envelope_multi: BufferedEnvelope accepts any filter_order (bufferedenvelope.py:13-16,44-55);
+    a band-pass envelope of order 5 has five sections, a low-pass of order 9 five, of order 12 six --
+    more than one plan holds.  sosfiltfilt is run over chained plans (pad length and sosfilt_zi of the
+    WHOLE cascade); against the oracle, against the single-plan kernel where the cascade fits one, and
+    scipy's ValueError for slabs not longer than the pad length."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rate, C = 48000.0, 3
+    rng = np.random.default_rng(T)
+    x = synth(rng, T, C, rate)
+    c = gh.ctx()
+    dx = gh.to_planar(c, x)
+    cases = [(butter_sos(5, (10.0, 500.0), 'bandpass', rate), 10.0, (4, 1)),
+             (butter_sos(5, (10.0, 500.0), 'bandpass', rate), 10.0, (2, 2, 1)),
+             (butter_sos(9, 800.0, 'lowpass', rate), 0.0, (4, 1)),
+             (butter_sos(12, 2000.0, 'lowpass', rate), 0.0, (3, 3)),
+             (butter_sos(8, (50.0, 4000.0), 'bandpass', rate), 50.0, (4, 4)),
+             (butter_sos(4, (100.0, 900.0), 'bandpass', rate), 100.0, (2, 2))]
+    for sos, ehp, split in cases:
+        assert sum(split) == len(sos)
+        plans, i = [], 0
+        for n in split:
+            plans.append(hipdsp.SosPlan(c, sos[i:i + n]))
+            i += n
+        edge = oracle.sosfiltfilt_edge(sos)
+        for skip in (0, 7) if T > 100 else (0,):
+            dy = hipdsp.DeviceArray(c, (C, max(T - skip, 1)), np.float32)
+            if T <= edge:
+                with pytest.raises(ValueError, match='padlen'):
+                    hipdsp.envelope_multi(c, plans, dx, T, dy, max(T - skip, 1), C, T, skip, clamp=ehp == 0)
+                continue
+            hipdsp.envelope_multi(c, plans, dx, T, dy, T - skip, C, T, skip, clamp=ehp == 0)
+            got = gh.from_planar(c, dy, T - skip, C, pitch=T - skip)
+            want = np.zeros((T - skip, C))
+            oracle.envelope_process(sos, x.astype(np.float64), want, skip, highpass_cutoff=ehp)
+            for ch in range(C):
+                assert rel_err(got[:, ch], want[:, ch]) < TOL, (T, len(sos), split, skip, ch)
+            if len(sos) <= 4 and skip == 0:
+                one = gh.gpu_envelope(sos, x, clamp=ehp == 0)
+                for ch in range(C):
+                    assert rel_err(got[:, ch], one[:, ch]) < 1e-5
