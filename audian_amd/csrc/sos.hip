@@ -1772,8 +1772,8 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     a.fault = ctx->fault_dev;
     constexpr int P = 8;                                           // IIR waves (and FFT waves) per workgroup, one per CU
     // (hipdsp_chain_plan reports exactly this segmentation)
-    plan_segments_for((long long)ctx->n_cus * P, ctx->max_segments, frames, channels, a.warm_total, &a.c.seg_len,
-                      &a.c.n_seg);
+    plan_segments_for((long long)(ctx->n_cus - ctx->chain_reserve_cus) * P, ctx->max_segments, frames, channels,
+                      a.warm_total, &a.c.seg_len, &a.c.n_seg);
     a.units = channels * a.c.n_seg;
     a.n_iter = (int)((a.warm_total + a.c.seg_len + edge + TILE - 1) / TILE) + 1;
     const long long blocks = (a.units + P - 1) / P;
@@ -1902,7 +1902,7 @@ int hipdsp_chain_plan(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hipdsp
     HD_REQUIRE(fplan->host->n_sections > 0 && eplan->host->n_sections > 0, "plan has no coefficients");
     long long len = 0;
     int n = 0;
-    plan_segments_for((long long)ctx->n_cus * 8, ctx->max_segments, frames, channels,
+    plan_segments_for((long long)(ctx->n_cus - ctx->chain_reserve_cus) * 8, ctx->max_segments, frames, channels,
                       fplan->host->warm + eplan->host->warm, &len, &n);
     *segment_frames = len;
     *n_segments = n;

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void spec_generic_kernel(
 
 // Three workgroups per CU (<= 168 VGPRs); the dB epilogue does not fit in that (it spilled 44
 // registers to scratch) and runs two per CU instead, which measured 15 % faster than spilling.
-template <int NFFT, int LPF, int R1, int R2, int R3, int WAVES, bool DB, bool HALF>
+template <int NFFT, int LPF, int R1, int R2, int R3, int WAVES, bool DB, int REUSE>
 __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? (DB ? 2 : 3) : 1) * WAVES / 4) void spec_fast_kernel(
     const float *__restrict__ x, long long x_pitch, long long n_valid, long long frames_out,
     long long out_pitch, int hop, float scale, const float *__restrict__ tables, float *__restrict__ out,
@@ -128,36 +128,42 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? (DB ? 2 : 3) : 1) * WAV
     // first frame of this wave; wave-uniform (scalar) when a frame takes the whole wave
     const long long first = ((long long)blockIdx.x * NW + wave) * (long long)frames_per_wave * G;
 
-    // Raw samples of one frame: the lane keeps z[n], n = l + LPF*u + t*M/R1, as two halves
-    // (t < R1/2 in `lo`, t >= R1/2 in `hi`).  The loads are inline asm so that the wait for
-    // them can be counted by hand: the next frame is fetched right after stage 3 (the
-    // registers are free until the next stage 1), i.e. BEFORE this frame's stores, and
-    // `s_waitcnt vmcnt(NST)` at the top of the next frame retires the loads while the NST
-    // younger stores stay in flight (hipcc would wait vmcnt(0), i.e. for every store
-    // acknowledgement).
-    // With 50 % overlap (HALF: hop == NFFT/2, one frame per wave) the upper half of frame f
-    // IS the lower half of frame f+1 in the same lane (n' = n - M/2 <=> t' = t - R1/2), so
-    // only the new half is fetched and the two register sets swap roles every frame: each
-    // sample is requested once instead of twice (PMC: 22.1 GB -> 14.8 GB read per launch).
+    // Raw samples of one frame: the lane keeps z[n], n = l + LPF*u + t*M/R1, as FOUR quarters of the frame
+    // (quarter k: R1/4 * k <= t < R1/4 * (k + 1), i.e. samples [k NFFT/4, (k + 1) NFFT/4)).  The loads are inline
+    // asm so that the wait for them can be counted by hand: the next frame is fetched as soon as the window has
+    // consumed this frame's raw registers, i.e. BEFORE this frame's stores, and `s_waitcnt vmcnt(NST)` at the
+    // top of the next frame retires the loads while the NST younger stores stay in flight (hipcc would wait
+    // vmcnt(0), i.e. for every store acknowledgement).
+    // REUSE = 2 (hop == NFFT/2, one frame per wave): the upper half of frame f IS the lower half of frame f + 1
+    // in the same lane (n' = n - M/2 <=> t' = t - R1/2), so only the new half is fetched and the register
+    // sets rotate by two quarters per frame: each sample is requested once instead of twice (PMC: 22.1 GB ->
+    // 14.8 GB read per launch).  REUSE = 4 (hop == NFFT/4, the 75 % overlap of BASELINE configs[1]): the sets
+    // rotate by one quarter and one quarter is fetched -- once instead of four times.
     constexpr bool EARLY_PF = !DB;             // the dB epilogue needs the registers (it would spill)
-    constexpr int HP = PPL / 2;                            // points per half
-    constexpr int R1H = R1 / 2;
-    v2f ra[HP], rb[HP];
+    static_assert(R1 % 4 == 0, "quarters of the first radix");
+    constexpr int R1Q = R1 / 4;
+    constexpr int QP = PPL / 4;                            // points per quarter
+    v2f rq0[QP], rq1[QP], rq2[QP], rq3[QP];
 #pragma unroll
-    for (int i = 0; i < HP; i++) { ra[i] = (v2f){0.f, 0.f}; rb[i] = (v2f){0.f, 0.f}; }
-    auto fetch_half = [&](long long frame, int upper, v2f *dst) {
+    for (int i = 0; i < QP; i++) {
+        rq0[i] = (v2f){0.f, 0.f}; rq1[i] = (v2f){0.f, 0.f}; rq2[i] = (v2f){0.f, 0.f}; rq3[i] = (v2f){0.f, 0.f};
+    }
+    auto fetch_quarter = [&](long long frame, auto which, v2f *dst) {
+        constexpr int K = decltype(which)::value;
         const float *seg = xc + frame * (long long)hop + 2 * l;
 #pragma unroll
         for (int u = 0; u < PPL / R1; u++)
 #pragma unroll
-            for (int t = 0; t < R1H; t++) {
+            for (int t = 0; t < R1Q; t++) {
                 constexpr int CH = 512;                    // float2 per 4096-byte window
-                const int n0 = LPF * u + t * (M / R1);     // compile-time after unrolling
-                const int n1 = n0 + R1H * (M / R1);
-                if (upper) asm_load8(dst[u * R1H + t], seg + 2 * (n1 / CH) * CH, (n1 % CH) * 8);
-                else asm_load8(dst[u * R1H + t], seg + 2 * (n0 / CH) * CH, (n0 % CH) * 8);
+                const int n0 = LPF * u + (K * R1Q + t) * (M / R1);     // compile-time after unrolling
+                asm_load8(dst[u * R1Q + t], seg + 2 * (n0 / CH) * CH, (n0 % CH) * 8);
             }
     };
+    using Q0 = std::integral_constant<int, 0>;
+    using Q1 = std::integral_constant<int, 1>;
+    using Q2 = std::integral_constant<int, 2>;
+    using Q3 = std::integral_constant<int, 3>;
     // stores behind a prefetch in the steady-state loop; one less than issued, so the wait
     // stays sufficient even if the compiler ever merged two of them
     constexpr int NST0 = (DB ? 2 : 1) * (PPL + 1) - 1;
@@ -168,9 +174,9 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? (DB ? 2 : 3) : 1) * WAV
 
     // One frame per lane group from the raw halves (lo, hi).  `keep` masks the stores of
     // lane groups whose frame is not valid (only in the one mixed iteration of a wave).
-    // With PF the next frame is prefetched (HALF: its new half, into `lo`); the steady-state
+    // With PF the next frame is prefetched (REUSE 2 / 4: only its new half / quarter); the steady-state
     // body has no divergent branch around its stores so that their count is exact.
-    auto body = [&](long long frame, bool keep, auto full, auto pf, auto waitn, v2f *lo, v2f *hi) {
+    auto body = [&](long long frame, bool keep, auto full, auto pf, auto waitn, v2f *qa, v2f *qb, v2f *qc, v2f *qd) {
         constexpr bool FULL = decltype(full)::value;
         constexpr bool PF = decltype(pf)::value;
         constexpr int WAITN = decltype(waitn)::value;
@@ -183,7 +189,8 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? (DB ? 2 : 3) : 1) * WAV
         for (int u = 0; u < PPL / R1; u++)
 #pragma unroll
             for (int t = 0; t < R1; t++) {
-                v2f &r = t < R1H ? lo[u * R1H + t] : hi[u * R1H + t - R1H];
+                v2f *const qs[4] = {qa, qb, qc, qd};
+                v2f &r = qs[t / R1Q][u * R1Q + t % R1Q];
                 asm volatile("" : "+v"(r));               // not before the counted wait
                 v[u * R1 + t] = make_float2(r.x, r.y);
                 acc += r;
@@ -210,11 +217,14 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? (DB ? 2 : 3) : 1) * WAV
         if (PF && EARLY_PF) {
             const long long nf = frame + G;
             const long long cf = nf < last_valid ? nf : last_valid;
-            if (HALF) {
-                fetch_half(cf, 1, lo);                    // hi stays: it is the next lower half
+            if (REUSE == 4) {
+                fetch_quarter(cf, Q3(), qa);              // qb, qc, qd stay: they are the next frame's first three quarters
+            } else if (REUSE == 2) {
+                fetch_quarter(cf, Q2(), qa);              // qc, qd stay: they are the next lower half
+                fetch_quarter(cf, Q3(), qb);
             } else {
-                fetch_half(cf, 0, lo);
-                fetch_half(cf, 1, hi);
+                fetch_quarter(cf, Q0(), qa); fetch_quarter(cf, Q1(), qb);
+                fetch_quarter(cf, Q2(), qc); fetch_quarter(cf, Q3(), qd);
             }
         }
         stockham_stage<R1, 1, M, LPF, false, true>(v, fb, tw2, l);
@@ -223,11 +233,14 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? (DB ? 2 : 3) : 1) * WAV
         if (PF && !EARLY_PF) {
             const long long nf = frame + G;
             const long long cf = nf < last_valid ? nf : last_valid;
-            if (HALF) {
-                fetch_half(cf, 1, lo);                    // hi stays: it is the next lower half
+            if (REUSE == 4) {
+                fetch_quarter(cf, Q3(), qa);              // qb, qc, qd stay: they are the next frame's first three quarters
+            } else if (REUSE == 2) {
+                fetch_quarter(cf, Q2(), qa);              // qc, qd stay: they are the next lower half
+                fetch_quarter(cf, Q3(), qb);
             } else {
-                fetch_half(cf, 0, lo);
-                fetch_half(cf, 1, hi);
+                fetch_quarter(cf, Q0(), qa); fetch_quarter(cf, Q1(), qb);
+                fetch_quarter(cf, Q2(), qc); fetch_quarter(cf, Q3(), qd);
             }
         }
         // Now v[u*R3 + t] = Z[k], k = l + LPF*m, m = u + NB3*t.  Split step for m < PPL/2
@@ -297,42 +310,54 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? (DB ? 2 : 3) : 1) * WAV
     {
         const long long f0 = first + g;
         const long long c0 = f0 < last_valid ? f0 : last_valid;
-        fetch_half(c0, 0, ra);
-        fetch_half(c0, 1, rb);
+        fetch_quarter(c0, Q0(), rq0); fetch_quarter(c0, Q1(), rq1);
+        fetch_quarter(c0, Q2(), rq2); fetch_quarter(c0, Q3(), rq3);
     }
     int it = 0;
     // (the steady-state loop sits inside this branch so that no path of the generated code can
     // reach a counted wait without the stores it counts: tools/check_prefetch_isa.py walks all
     // paths and knows nothing about n_main)
     if (n_main > 0) {
-        body(first + g, true, T_(), T_(), W0(), ra, rb);
+        body(first + g, true, T_(), T_(), W0(), rq0, rq1, rq2, rq3);
         it = 1;
-        if (HALF) {
-            // the register sets swap roles every frame: (lo, hi) = (rb, ra), (ra, rb), ...
-            for (; it + 1 < (int)n_main; it += 2) {
-                body(first + (long long)it * G + g, true, T_(), T_(), WN(), rb, ra);
-                body(first + (long long)(it + 1) * G + g, true, T_(), T_(), WN(), ra, rb);
+        const int nm = (int)n_main;
+        auto fr = [&](int i) { return first + (long long)i * G + g; };
+        if (REUSE == 4) {
+            // the register sets rotate by one quarter per frame: (a, b, c, d) -> (b, c, d, a) -> ...
+            for (; it + 3 < nm; it += 4) {
+                body(fr(it), true, T_(), T_(), WN(), rq1, rq2, rq3, rq0);
+                body(fr(it + 1), true, T_(), T_(), WN(), rq2, rq3, rq0, rq1);
+                body(fr(it + 2), true, T_(), T_(), WN(), rq3, rq0, rq1, rq2);
+                body(fr(it + 3), true, T_(), T_(), WN(), rq0, rq1, rq2, rq3);
             }
-            if (it < (int)n_main) {
-                body(first + (long long)it * G + g, true, T_(), T_(), WN(), rb, ra);
-                it++;
+            if (it < nm) { body(fr(it), true, T_(), T_(), WN(), rq1, rq2, rq3, rq0); it++; }
+            if (it < nm) { body(fr(it), true, T_(), T_(), WN(), rq2, rq3, rq0, rq1); it++; }
+            if (it < nm) { body(fr(it), true, T_(), T_(), WN(), rq3, rq0, rq1, rq2); it++; }
+        } else if (REUSE == 2) {
+            // ... by two quarters: (a, b, c, d) -> (c, d, a, b) -> (a, b, c, d)
+            for (; it + 1 < nm; it += 2) {
+                body(fr(it), true, T_(), T_(), WN(), rq2, rq3, rq0, rq1);
+                body(fr(it + 1), true, T_(), T_(), WN(), rq0, rq1, rq2, rq3);
             }
+            if (it < nm) { body(fr(it), true, T_(), T_(), WN(), rq2, rq3, rq0, rq1); it++; }
         } else {
-            for (; it < (int)n_main; it++)
-                body(first + (long long)it * G + g, true, T_(), T_(), WN(), ra, rb);
+            for (; it < nm; it++) body(fr(it), true, T_(), T_(), WN(), rq0, rq1, rq2, rq3);
         }
     }
     // retire the last prefetch before anything else may reuse its registers
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < HP; i++) { asm volatile("" : "+v"(ra[i])); asm volatile("" : "+v"(rb[i])); }
-    // at most one mixed iteration (G > 1 only, never HALF), then the zero tail
+    for (int i = 0; i < QP; i++) {
+        asm volatile("" : "+v"(rq0[i])); asm volatile("" : "+v"(rq1[i]));
+        asm volatile("" : "+v"(rq2[i])); asm volatile("" : "+v"(rq3[i]));
+    }
+    // at most one mixed iteration (G > 1 only, never with REUSE > 1), then the zero tail
     // (bufferedspectrogram.py:59)
     for (; it < frames_per_wave; it++) {
         const long long frame = first + (long long)it * G + g;
         if (first + (long long)it * G >= frames_out) break;
         if (G > 1 && it == (int)n_main && first + (long long)it * G < n_valid)
-            body(frame < last_valid ? frame : last_valid, frame < n_valid, F_(), F_(), WX(), ra, rb);
+            body(frame < last_valid ? frame : last_valid, frame < n_valid, F_(), F_(), WX(), rq0, rq1, rq2, rq3);
         if (frame >= n_valid && frame < frames_out) {
             float *o = oc + frame * (long long)F;
             for (int f = l; f < F; f += LPF) {
@@ -914,19 +939,26 @@ int launch_fast(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long ch
     const int fpw = frames_per_wave(ctx, channels, frames_out, G);
     long long per_block = (long long)WAVES * fpw * G;
     long long bx = (frames_out + per_block - 1) / per_block;
-    // 50 % overlap with one frame per wave: reuse the overlapped half from registers
-    const bool half = (LPF == 64) && hop * 2 == NFFT && !ctx->spec_no_half;
+    // 50 % / 75 % overlap with one frame per wave: reuse the overlapped half / three quarters from registers
+    // (measured, tools/spec_reuse_ab.py, 64 ch x 120 s: 1024/256 3.17 -> 3.92 TB/s, 2048/512 3.29 -> 3.66, 1024/512
+    // 4.28 -> 4.54, 2048/1024 equal; at nfft 4096 -- one workgroup per CU -- the rotating register sets cost
+    // more than the saved requests: 3.46 -> 2.75 TB/s at hop 2048, so that size fetches every frame whole)
+    const int reuse = (LPF != 64 || NFFT > 2048 || ctx->spec_no_half) ? 1
+                                                                      : (hop * 2 == NFFT ? 2 : (hop * 4 == NFFT ? 4 : 1));
     dim3 grid((unsigned)bx, (unsigned)channels), block(64 * WAVES);
-#define HD_SPEC_LAUNCH(DBV, HALFV)                                                                  \
-    hipLaunchKernelGGL((spec_fast_kernel<NFFT, LPF, R1, R2, R3, WAVES, DBV, HALFV>), grid, block, 0,  \
+#define HD_SPEC_LAUNCH(DBV, REUSEV)                                                                 \
+    hipLaunchKernelGGL((spec_fast_kernel<NFFT, LPF, R1, R2, R3, WAVES, DBV, REUSEV>), grid, block, 0, \
                        ctx->stream, x, x_pitch, n_valid, frames_out, out_pitch, hop, scale, tables,   \
                        out, db_out, fpw)
-    if (LPF == 64 && half) {
-        if (db_out) HD_SPEC_LAUNCH(true, (LPF == 64));
-        else HD_SPEC_LAUNCH(false, (LPF == 64));
+    if (LPF == 64 && reuse == 2) {
+        if (db_out) HD_SPEC_LAUNCH(true, (LPF == 64 ? 2 : 1));
+        else HD_SPEC_LAUNCH(false, (LPF == 64 ? 2 : 1));
+    } else if (LPF == 64 && reuse == 4) {
+        if (db_out) HD_SPEC_LAUNCH(true, (LPF == 64 ? 4 : 1));
+        else HD_SPEC_LAUNCH(false, (LPF == 64 ? 4 : 1));
     } else {
-        if (db_out) HD_SPEC_LAUNCH(true, false);
-        else HD_SPEC_LAUNCH(false, false);
+        if (db_out) HD_SPEC_LAUNCH(true, 1);
+        else HD_SPEC_LAUNCH(false, 1);
     }
 #undef HD_SPEC_LAUNCH
     return hd_launch_status("spec_fast_kernel");

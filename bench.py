@@ -4,15 +4,22 @@
 One "step" = one pass of the chain  data -> BufferedFilter (Butterworth band-pass)
 -> {BufferedSpectrogram (Hann STFT PSD), BufferedEnvelope (rectify + sosfiltfilt)}
 over one batch of synthetic multichannel float32 audio that is already resident in
-HBM (BASELINE.json configs[2]: 64 ch x 600 s x 96 kHz per GPU, nfft 2048 / hop 1024,
-band-pass 300-3000 Hz order 2, envelope low-pass 20 Hz).
+HBM.  --config picks the BASELINE.json workload:
+
+    2 (default)  configs[2]: 64 ch x 600 s x 96 kHz per GPU, nfft 2048 / hop 1024, band-pass 300-3000 Hz
+                 order 2, envelope low-pass 20 Hz -- the configuration the metric is quoted on
+    3            configs[3]: 256 ch x 600 s x 96 kHz sharded over 8 GPUs = 32 ch per GPU, same chain, plus the
+                 RCCL all-gather of the merged spectrogram tile (three tile sizes, see --tile)
+    1            configs[1]: 4 ch x 60 s x 48 kHz, nfft 1024 / hop 256, band-pass order 4 (four sections)
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line: whole-job Msamples/s, the HBM roofline of the dominant
 kernel (HIP-event timed inside the timed region) and, at N=1, the reference's scipy
-CPU path timed on this box's host cores on a bounded sample.
+CPU path timed on this box's host cores on a bounded sample.  At N > 1 the timed step includes the
+all-gather of the --tile spectrogram tile; after the timed region the same K steps are repeated without
+any gather and with each of the three tile sizes (`legs`: compute_ms / gather_ms separately).
 """
 
 import argparse
@@ -30,28 +37,46 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
+CONFIGS = {
+    1: dict(channels=4, seconds=60.0, rate=48000.0, nfft=1024, hop=256, order=4, env=20.0,
+            name='BASELINE configs[1]'),
+    2: dict(channels=64, seconds=600.0, rate=96000.0, nfft=2048, hop=1024, order=2, env=20.0,
+            name='BASELINE configs[2]'),
+    3: dict(channels=32, seconds=600.0, rate=96000.0, nfft=2048, hop=1024, order=2, env=20.0,
+            name='BASELINE configs[3] (256 ch over 8 GPUs = 32 ch/GPU)'),
+}
+# spectrogram tiles that are all-gathered at N > 1 (seconds of the recording)
+TILES = {'visible': 10.0,      # what the display shows (plotranges.py:141-144): "gather only the visible tile"
+         'window': 80.0,       # SURVEY 8e's interactive tile: the resident window (data.py:17,168), 0.98 GB/rank at 32 ch
+         'full': None}         # the whole spectrogram of the rank (7.4 GB at 32 ch): xGMI-bound by construction
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--channels', type=int, default=64, help='channels per GPU')
-    ap.add_argument('--seconds', type=float, default=600.0)
-    ap.add_argument('--rate', type=float, default=96000.0)
-    ap.add_argument('--nfft', type=int, default=2048)
-    ap.add_argument('--hop', type=int, default=1024)
+    ap.add_argument('--config', type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument('--channels', type=int, default=None, help='channels per GPU (default: the config\'s)')
+    ap.add_argument('--seconds', type=float, default=None)
+    ap.add_argument('--rate', type=float, default=None)
+    ap.add_argument('--nfft', type=int, default=None)
+    ap.add_argument('--hop', type=int, default=None)
     ap.add_argument('--hp', type=float, default=300.0)
     ap.add_argument('--lp', type=float, default=3000.0)
-    ap.add_argument('--order', type=int, default=2)
-    ap.add_argument('--env', type=float, default=20.0)
-    ap.add_argument('--tile-seconds', type=float, default=10.0,
-                    help='N>1: length of the spectrogram tile that is all-gathered every step: the visible '
-                         'window of the browser (10 s by default, plotranges.py:141-144) -- "gather only the '
-                         'visible tile when interactive" (SURVEY 7-6).  61 gathers the whole resident buffer '
-                         'of the spectrogram trace instead (buffer_time 60 s + 11 s + 10 s of raw pre/post-roll '
-                         'minus the 10 s + 10 s trimmed in align_buffer; data.py:17,168, buffereddata.py:75-88), '
-                         'which is xGMI-bound: 1.5 GB per rank and step')
+    ap.add_argument('--order', type=int, default=None)
+    ap.add_argument('--env', type=float, default=None)
+    ap.add_argument('--tile', default='visible', choices=sorted(TILES),
+                    help='N>1: the spectrogram tile all-gathered in every TIMED step (the legs after the timed '
+                         'region cover all three)')
+    ap.add_argument('--tile-seconds', type=float, default=None, help='N>1: override the length of --tile')
+    ap.add_argument('--gather', default='torch', choices=['torch', 'c-abi'],
+                    help="N>1: 'torch' = torch.distributed all_gather_into_tensor, 'c-abi' = hipdsp_allgather_f32 "
+                         '(the same RCCL call through libhip_dsp, on a second context/stream)')
+    ap.add_argument('--reserve-cus', type=int, default=None,
+                    help='CUs the fused forward sweep leaves free (default 8 at N>1, 0 at N=1): its workgroups take '
+                         'a whole CU each, RCCL\'s resident all-gather kernel needs some of its own')
+    ap.add_argument('--no-legs', action='store_true', help='N>1: skip the compute-only / per-tile legs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-seconds', type=float, default=60.0)
     ap.add_argument('--max-segments', type=int, default=0)
@@ -69,18 +94,23 @@ def parse():
     ap.add_argument('--no-fuse-spectrogram', action='store_true',
                     help='by default band-pass + envelope state sweep + spectrogram run as ONE launch '
                          '(hipdsp_chain_forward: FFT waves take the filtered tiles from LDS, 20 instead of '
-                         '24 B/sample for the step) whenever the shape allows it (nfft 2048 / hop 1024, plans of '
-                         '<= 2 sections); this flag keeps the separate launches.  At N > 1 the fused kernel, which '
-                         'wants a whole CU per workgroup, waits for the previous all-gather to leave the device')
+                         '24 B/sample for the step) whenever the library covers the shape; this flag keeps the '
+                         'separate launches')
     ap.add_argument('--force-dist', action='store_true',
                     help='rehearsal: take the multi-rank code path even with one rank')
-    return ap.parse_args()
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    for key in ('channels', 'seconds', 'rate', 'nfft', 'hop', 'order', 'env'):
+        if getattr(args, key) is None:
+            setattr(args, key, cfg[key])
+    args.config_name = cfg['name']
+    return args
 
 
 def cpu_baseline(args, sos, esos):
     """The reference's own CPU path (scipy call pattern, float64, one thread) on a
     bounded sample of the same workload; falls back to the C/NumPy oracle port."""
-    C, T = args.channels, int(args.cpu_sample_seconds*args.rate)
+    C, T = args.channels, int(min(args.cpu_sample_seconds, args.seconds)*args.rate)
     rng = np.random.default_rng(1234 + 2)
     t = np.arange(T)/args.rate
     x = rng.uniform(-1.0, 1.0, size=(T, C))
@@ -111,14 +141,14 @@ def cpu_baseline(args, sos, esos):
     out = {'value': C*T/dt/1e6, 'unit': 'Msamples/s', 'cores': 1,
            'kind': 'reference' if impl.startswith('scipy') else 'port',
            'host_cores': os.cpu_count(),
-           'sample': f'{C} ch x {args.cpu_sample_seconds:g} s x {args.rate/1000:g} kHz float64, '
+           'sample': f'{C} ch x {T/args.rate:g} s x {args.rate/1000:g} kHz float64, '
                      f'same chain, {dt:.1f} s wall; {impl}'}
     # for fairness also an all-cores figure: channels split over 16 worker processes (the
     # box's CPU share for one GPU), in a separate process tree that never touches the GPU
     try:
         import subprocess
         r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'scipy_path.py'), str(C),
-                            str(args.cpu_sample_seconds), str(args.rate), str(args.nfft), str(args.hop),
+                            str(T/args.rate), str(args.rate), str(args.nfft), str(args.hop),
                             str(args.hp), str(args.lp), str(args.order), str(args.env), '16'],
                            capture_output=True, text=True, timeout=180)
         if r.returncode == 0:
@@ -151,7 +181,7 @@ def parity_subset(args, hipdsp, ctx, dx, df, ds, de, T, nd, sos, esos, extra=())
         o = off - a0
         g = df.view(c*T + off, (n_cmp,)).to_host()
         worst = max(worst, np.max(np.abs(g - filt[o:o + n_cmp, 0]))/np.max(np.abs(filt[o:o + n_cmp, 0])))
-        # the envelope of the GPU's own filtered trace where the oracle's has not converged yet
+        # the envelope of the oracle's filtered trace, from where that one has converged
         e0 = 0 if a0 == 0 else lead_f
         env = np.zeros_like(filt[e0:])
         oracle.envelope_process(esos, filt[e0:], env, 0)
@@ -169,6 +199,139 @@ def parity_subset(args, hipdsp, ctx, dx, df, ds, de, T, nd, sos, esos, extra=())
             for k in range(nfr):
                 worst = max(worst, np.max(np.abs(g[k] - spec[k, 0]))/np.max(np.abs(spec[k, 0])))
     return float(worst)
+
+
+class TorchGather:
+    """All-gather of the spectrogram tile with torch.distributed (RCCL at backend 'nccl'): the tile is
+    copied out of the rank's spectrogram on a side stream (double-buffered) and gathered asynchronously."""
+
+    def __init__(self, torch, dist, hipdsp, ctx, tspec, tile_frames, world, backend, cstream):
+        self.torch, self.dist, self.ctx, self.tspec, self.tf = torch, dist, ctx, tspec, tile_frames
+        self.world, self.backend, self.cstream = world, backend, cstream
+        C, nd, F = tspec.shape
+        self.whole = tile_frames == nd
+        self.side = torch.cuda.Stream()
+        self.tile = [None, None] if self.whole else \
+            [torch.empty((C, tile_frames, F), dtype=torch.float32, device='cuda') for _ in range(2)]
+        self.merged = torch.empty((world*C, tile_frames, F), dtype=torch.float32,
+                                  device='cuda' if backend == 'nccl' else 'cpu')
+        self.work = None
+        self.n = 0
+        self.done = torch.cuda.Event()
+        self.done.record(cstream)
+
+    def before_forward(self):
+        """The forward sweep is about to overwrite the spectrogram: a gather that reads it in place
+        (whole spectrogram) must have finished; a tile copy only needs its copy to be done."""
+        if self.whole:
+            self.drain()
+        else:
+            self.cstream.wait_event(self.done)
+
+    def issue(self):
+        """After the forward sweep of a step (enqueued on the compute stream)."""
+        torch = self.torch
+        self.side.wait_stream(self.cstream)
+        with torch.cuda.stream(self.side):
+            if self.work is not None:
+                self.work.wait()                  # gathers run one after the other anyway
+                self.work = None
+            if self.whole:
+                src = self.tspec
+            else:
+                src = self.tile[self.n % 2]
+                src.copy_(self.tspec[:, :self.tf, :])
+                self.done.record(self.side)
+            self.n += 1
+            if self.backend == 'nccl':
+                self.work = self.dist.all_gather_into_tensor(self.merged, src, async_op=True)
+            else:
+                self.side.synchronize()
+                self.dist.all_gather_into_tensor(self.merged, src.cpu())
+
+    def drain(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        self.side.synchronize()
+
+    def alone(self, k):
+        """k gathers of the (already copied) tile with nothing else on the device: seconds per gather."""
+        torch = self.torch
+        src = self.tspec if self.whole else self.tile[0]
+        torch.cuda.synchronize()
+        self.dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            if self.backend == 'nccl':
+                self.dist.all_gather_into_tensor(self.merged, src)
+            else:
+                self.dist.all_gather_into_tensor(self.merged, src.cpu())
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0)/k
+
+
+class AbiGather:
+    """The same exchange step through the C ABI (hipdsp_comm_* / hipdsp_allgather_f32): a second context on
+    its own stream copies the tile (hipdsp_memcpy2d_d2d) and enqueues ncclAllGather there; ordered against
+    the compute context with hipdsp events.  The 128-byte unique id travels over torch.distributed."""
+
+    def __init__(self, torch, dist, hipdsp, ctx, ds, shape, tile_frames, world, rank, local_rank):
+        self.torch, self.dist, self.hipdsp, self.ctx, self.ds, self.tf = torch, dist, hipdsp, ctx, ds, tile_frames
+        C, nd, F = shape
+        self.C, self.nd, self.F, self.world = C, nd, F, world
+        self.whole = tile_frames == nd
+        self.gctx = hipdsp.Context(local_rank, ctx.create_stream())
+        ids = [hipdsp.Comm.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        self.comm = hipdsp.Comm(self.gctx, ids[0], rank, world)
+        self.tile = [None, None] if self.whole else \
+            [hipdsp.DeviceArray(self.gctx, (C, tile_frames, F), np.float32) for _ in range(2)]
+        self.merged = hipdsp.DeviceArray(self.gctx, (world*C, tile_frames, F), np.float32)
+        self.ev_fwd, self.ev_copied, self.ev_gathered = ctx.event(), ctx.event(), ctx.event()
+        self.n = 0
+        self.gctx.record(self.ev_copied)
+        self.gctx.record(self.ev_gathered)
+
+    def before_forward(self):
+        self.ctx.wait_event(self.ev_gathered if self.whole else self.ev_copied)
+
+    def issue(self):
+        h = self.hipdsp
+        self.ctx.record(self.ev_fwd)
+        self.gctx.wait_event(self.ev_fwd)
+        if self.whole:
+            src = self.ds
+        else:
+            src = self.tile[self.n % 2]
+            h.memcpy2d(self.gctx, src, 4*self.tf*self.F, self.ds, 4*self.nd*self.F, 4*self.tf*self.F, self.C)
+            self.gctx.record(self.ev_copied)
+        self.n += 1
+        self.comm.allgather(src, self.merged, self.C*self.tf*self.F)
+        self.gctx.record(self.ev_gathered)
+
+    def drain(self):
+        self.gctx.synchronize()
+
+    def alone(self, k):
+        src = self.ds if self.whole else self.tile[0]
+        self.ctx.synchronize()
+        self.gctx.synchronize()
+        self.dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            self.comm.allgather(src, self.merged, self.C*self.tf*self.F)
+        self.gctx.synchronize()
+        return (time.perf_counter() - t0)/k
+
+    def close(self):
+        self.gctx.synchronize()
+        self.comm.close()
+        for a in list(self.tile) + [self.merged]:
+            if a is not None:
+                a.free()
+        self.gctx.pool_trim()
 
 
 def main():
@@ -199,7 +362,7 @@ def main():
     from audian_amd.design import butter_sos
 
     if multi:
-        from audian_amd.dist import allgather_tiles, tile_frames as n_tile_frames
+        from audian_amd.dist import tile_frames as n_tile_frames
         if args.same_device:
             local_rank = 0
         torch.cuda.set_device(local_rank)
@@ -212,35 +375,19 @@ def main():
         else:
             dist.init_process_group('gloo')
         # compute on a non-default stream so that the RCCL gather (its own stream) can
-        # overlap the envelope kernels; the legacy default stream would serialise them
+        # overlap the kernels; the legacy default stream would serialise them
         cstream = torch.cuda.Stream()
         torch.cuda.set_stream(cstream)
         stream = cstream.cuda_stream
     else:
+        cstream = None
         stream = None
     ctx = hipdsp.Context(local_rank, stream)
     if args.max_segments:
         ctx.set_max_segments(args.max_segments)
-    # The spectrogram and the envelope backward sweep both only read the filtered trace: they run next to each other on two streams, ordered by events.
-    fuse3 = (not args.no_fuse_spectrogram and not args.no_fuse
-             and args.nfft == 2048 and args.hop == 1024 and args.order <= 2
-             and args.seconds*args.rate >= 8192)
-    overlap = not args.no_overlap and not fuse3      # nothing left to run next to the backward sweep
-    sctx, sstream = ctx, None
-    if overlap:
-        if multi:
-            sstream = torch.cuda.Stream()
-            sctx = hipdsp.Context(local_rank, sstream.cuda_stream)
-        else:
-            ctx.set_stream(ctx.create_stream())
-            sctx = hipdsp.Context(local_rank, ctx.create_stream())
-    ev_filtered, ev_spec = ctx.event(), ctx.event()
-    if multi:
-        # The IIR sweeps launch one wave per (channel, segment) and want all of them resident at
-        # once.  Next to RCCL's all-gather kernel a few would have to wait for a second round:
-        # 12 waves per CU (instead of 16) leave a wave slot per SIMD free and cost < 2 % alone
-        # (tools/coresidency_probe.hip: +9 % instead of +18 % next to a spinning kernel).
-        ctx.set_option('sos_waves_per_cu', 12)
+    reserve = args.reserve_cus if args.reserve_cus is not None else (8 if multi else 0)
+    if reserve:
+        ctx.set_option('chain_reserve_cus', reserve)
 
     C, T = args.channels, int(round(args.seconds*args.rate))
     F = args.nfft//2 + 1
@@ -257,17 +404,11 @@ def main():
     if multi:
         tspec = torch.empty((C, nd, F), dtype=torch.float32, device='cuda')
         ds = hipdsp.DeviceArray(ctx, (C, nd, F), np.float32, ptr=tspec.data_ptr(), owner=tspec)
-        tile_frames = n_tile_frames(nd, args.rate, args.hop, args.tile_seconds)
-        # two tiles in flight: the gather of step i runs under the kernels of step i + 1
-        tile_buf = [torch.empty((C, tile_frames, F), dtype=torch.float32, device='cuda') for _ in range(2)]
-        merged = [torch.empty((world*C, tile_frames, F), dtype=torch.float32,
-                              device='cuda' if args.backend == 'nccl' else 'cpu') for _ in range(2)]
-        works = [None, None]
-        counter = [0]
     else:
+        tspec = None
         ds = hipdsp.DeviceArray(ctx, (C, nd, F), np.float32)
     ctx.reserve(8*C*((T + edge + 2047)//2048)*2*len(esos))      # envelope state checkpoints
-    hipdsp.synth(ctx, dx, T, C, T, args.rate, 1234 + 2, c0=rank*C, c_total=world*C)
+    hipdsp.synth(ctx, dx, T, C, T, args.rate, 1234 + args.config, c0=rank*C, c_total=world*C)
     ctx.synchronize()
 
     # measured device-copy ceiling (read + write of one trace, hipMemcpy D2D), reported next
@@ -280,9 +421,10 @@ def main():
     ctx.record(cb)
     copy_gbps = 3*8.0*C*T/(ctx.elapsed_ms(ca, cb)*1e-3)/1e9
 
+    # The fused forward sweep (band-pass + envelope states + spectrogram in one launch) whenever the library
+    # covers the shape: one untimed trial decides.
+    fuse3 = not args.no_fuse_spectrogram and not args.no_fuse
     if fuse3:
-        # one untimed trial of the fused forward sweep: whatever it cannot do (shape, plan) or the
-        # device refuses falls back to the separate launches instead of ending the run without a number
         try:
             hipdsp.chain_forward(ctx, plan, eplan, dx, T, df, T, C, T, args.nfft, args.hop, args.rate, ds, nd,
                                  rectify=True, gain=np.pi/2)
@@ -291,29 +433,45 @@ def main():
             # HIPDSP_ERR_UNSUPPORTED only (a shape or plan the fused sweep does not cover).  Anything else --
             # a HIP error, a fault reported by the kernel -- ends the run: a number measured on a device
             # whose headline kernel has just failed would mask the failure.
-            print(f'bench.py: fused forward sweep not used ({err}); separate launches on one stream',
+            print(f'bench.py: fused forward sweep not used ({err}); separate launches',
                   file=sys.stderr)
             fuse3 = False
+    # The spectrogram and the envelope backward sweep both only read the filtered trace: with separate
+    # launches they run next to each other on two streams, ordered by events.
+    overlap = not args.no_overlap and not fuse3 and not multi
+    sctx = ctx
+    if overlap:
+        ctx.set_stream(ctx.create_stream())
+        sctx = hipdsp.Context(local_rank, ctx.create_stream())
+    ev_filtered, ev_spec = ctx.event(), ctx.event()
+    if multi:
+        # The IIR sweeps launch one wave per (channel, segment) and want all of them resident at
+        # once.  Next to RCCL's all-gather kernel a few would have to wait for a second round:
+        # 12 waves per CU (instead of 16) leave a wave slot per SIMD free and cost < 2 % alone
+        # (tools/coresidency_probe.hip: +9 % instead of +18 % next to a spinning kernel).
+        ctx.set_option('sos_waves_per_cu', 12)
+
+    def tile_frames_of(name):
+        secs = TILES[name] if not (name == args.tile and args.tile_seconds) else args.tile_seconds
+        return nd if secs is None else n_tile_frames(nd, args.rate, args.hop, secs)
+
+    def make_gatherer(name):
+        tf = tile_frames_of(name)
+        if args.gather == 'c-abi' and args.backend == 'nccl':
+            return AbiGather(torch, dist, hipdsp, ctx, ds, (C, nd, F), tf, world, rank, local_rank)
+        return TorchGather(torch, dist, hipdsp, ctx, tspec, tf, world, args.backend, cstream)
 
     n_ev = 7
     events = [[ctx.event() for _ in range(n_ev)] for _ in range(args.steps)]
     mids = [ctx.event() for _ in range(args.steps)]
-
     fused = not args.no_fuse
 
-    def step(i):
+    def step(i, gatherer):
         ev = events[i] if i >= 0 else None
+        if gatherer is not None:
+            gatherer.before_forward()
         if ev:
             ctx.record(ev[0])
-        if fuse3 and multi:
-            # the fused forward sweep wants every CU to itself (one 1024-thread workgroup per CU):
-            # it starts only when the previous step's all-gather has left the device, so that gather
-            # overlaps the backward sweep of its own step and nothing else
-            with torch.cuda.stream(cstream):
-                for b in range(2):
-                    if works[b] is not None:
-                        works[b].wait()
-                        works[b] = None
         if fuse3:
             hipdsp.chain_forward(ctx, plan, eplan, dx, T, df, T, C, T, args.nfft, args.hop, args.rate, ds, nd,
                                  rectify=True, gain=np.pi/2)
@@ -336,23 +494,13 @@ def main():
             hipdsp.spectrogram(sctx, df, T, C, T, args.nfft, args.hop, args.rate, ds, nd)
         if ev:
             sctx.record(ev[6])
-        if multi:
-            # merged spectrogram tile of the resident window on every rank: one RCCL all-gather
-            # over xGMI per step, double-buffered so that it overlaps the envelope backward
-            # sweep of this step and the kernels of the next one
-            with torch.cuda.stream(sstream if overlap else cstream):
-                b = counter[0] % 2
-                counter[0] += 1
-                if works[b] is not None:
-                    works[b].wait()              # tile b is about to be overwritten
-                    works[b] = None
-                tile_buf[b].copy_(tspec[:, :tile_frames, :])
-                if args.backend == 'nccl':
-                    _, works[b] = allgather_tiles(tile_buf[b], world*C, out=merged[b], async_op=True)
-                else:
-                    allgather_tiles(tile_buf[b].cpu(), world*C, out=merged[b])
+        if gatherer is not None:
+            # merged spectrogram tile on every rank: one RCCL all-gather over xGMI per step, issued right behind
+            # the spectrogram so that it runs under the backward sweep of this step and the forward sweep of the
+            # next one (which leaves `reserve` CUs to RCCL's kernel)
+            gatherer.issue()
         if ev and fused:
-            sctx.record(ev[2])            # end of tile copy + wait for the gather two steps back
+            sctx.record(ev[2])
         if overlap:
             sctx.record(ev_spec)
         if ev:
@@ -375,12 +523,9 @@ def main():
         if ev:
             ctx.record(ev[4])
 
-    def fence():
-        if multi:
-            for b in range(2):
-                if works[b] is not None:
-                    works[b].wait()          # every gather issued so far is part of the job
-                    works[b] = None
+    def fence(gatherer):
+        if gatherer is not None:
+            gatherer.drain()             # every gather issued so far is part of the job
         sctx.synchronize()
         ctx.synchronize()
         if multi:
@@ -388,25 +533,31 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(-1)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    fence()
-    dt = time.perf_counter() - t0
-    if multi:
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def timed_run(gatherer, record=True):
+        """W warm-up steps, then exactly K steps between barriers; seconds (max over ranks)."""
+        for _ in range(args.warmup):
+            step(-1, gatherer)
+        fence(gatherer)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i if record else -1, gatherer)
+        fence(gatherer)
+        dt = time.perf_counter() - t0
+        if multi:
+            tt = torch.tensor([dt], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    main_gather = make_gatherer(args.tile) if multi else None
+    dt = timed_run(main_gather)
 
     # per-kernel averages from the HIP events recorded inside the timed region
     if fuse3:
         names = ['chain_fwd<S=%d+%d,filt+env_state+psd>' % (len(sos), len(esos)), 'spectrogram(fused)',
-                 'tile_copy+gather_wait', 'env_bwd<S=%d>' % len(esos), 'unused']
+                 'gather_issue', 'env_bwd<S=%d>' % len(esos), 'unused']
     elif fused:
-        names = ['sos_ckpt<S=%d+%d,filt+env_state>' % (len(sos), len(esos)), 'spectrogram', 'tile_copy+gather_wait',
+        names = ['sos_ckpt<S=%d+%d,filt+env_state>' % (len(sos), len(esos)), 'spectrogram', 'gather_issue',
                  'env_bwd<S=%d>' % len(esos), 'unused']
     else:
         names = ['sos_scan<S=%d,filt>' % len(sos), 'spectrogram', 'sos_ckpt<S=0+%d,env_state>' % len(esos),
@@ -457,7 +608,7 @@ def main():
             traffic = pmc['kernels'][dom]['hbm_bytes']
     kernels = {k: {'ms': round(ms[k], 4),
                    'GBps': round(alg_bytes[k]/(ms[k]*1e-3)/1e9, 1) if k in alg_bytes and ms[k] > 0 else None}
-               for k in names if k in alg_bytes or (multi and k == 'tile_copy+gather_wait')}
+               for k in names if k in alg_bytes}
     if overlap:
         shared = [k for k in alg_bytes if k != names[0]]
         for k in shared:
@@ -470,6 +621,42 @@ def main():
     stage_gbps = None
     if fuse3:
         stage_gbps = round((12.0*C*T + 4.0*C*nd*F + ckpt_bytes)/(ms[names[0]]*1e-3)/1e9, 1)
+
+    # N > 1: the same K steps again without any gather and with each tile size, gathers alone as well
+    legs = None
+    if multi:
+        tile_gb = lambda name: 4.0*C*tile_frames_of(name)*F/1e9
+        legs = {'tile_in_timed_region': args.tile,
+                'step_ms': round(dt/args.steps*1e3, 4), 'tile_GB_per_rank': round(tile_gb(args.tile), 3)}
+        if not args.no_legs:
+            main_gather.drain()
+            compute_dt = timed_run(None, record=False)
+            legs['compute_ms'] = round(compute_dt/args.steps*1e3, 4)
+            legs['tiles'] = {}
+            for name in ('visible', 'window', 'full'):
+                g = None
+                try:
+                    g = main_gather if name == args.tile else make_gatherer(name)
+                    gdt = dt if name == args.tile else timed_run(g, record=False)
+                    alone_s = g.alone(max(2, min(args.steps, 5)))
+                    gb = tile_gb(name)
+                    legs['tiles'][name] = {
+                        'seconds_of_recording': TILES[name] if TILES[name] is not None else args.seconds,
+                        'GB_per_rank': round(gb, 3), 'GB_received_per_rank': round(gb*(world - 1), 3),
+                        'step_ms': round(gdt/args.steps*1e3, 4),                 # compute + gather, overlapped
+                        'gather_ms': round(alone_s*1e3, 4),                      # the gather alone on the device
+                        'gather_exposed_ms': round((gdt - compute_dt)/args.steps*1e3, 4),
+                        'gather_GBps_per_rank_in': round(gb*(world - 1)/alone_s, 1) if world > 1 else None}
+                except (MemoryError, RuntimeError) as err:
+                    if 'out of memory' not in str(err).lower():
+                        raise
+                    legs['tiles'][name] = {'skipped': 'does not fit next to the resident arrays on this box'}
+                if g is not None and g is not main_gather:
+                    g.drain()
+                    if hasattr(g, 'close'):
+                        g.close()
+                    del g
+                    torch.cuda.empty_cache()
 
     parity = None
     cpu = None
@@ -499,19 +686,18 @@ def main():
             'dtype': 'f32 I/O, f64 IIR state',
             'data': 'synthetic',
             'config': {
-                'workload': f'BASELINE configs[2]: synthetic {C} ch/GPU x {args.seconds:g} s x '
+                'workload': f'{args.config_name}: synthetic {C} ch/GPU x {args.seconds:g} s x '
                             f'{args.rate/1000:g} kHz float32; bandpass {args.hp:g}-{args.lp:g} Hz '
                             f'order {args.order} -> spectrogram nfft {args.nfft} hop {args.hop} '
                             f'+ envelope {args.env:g} Hz',
                 'channels_per_gpu': C, 'frames': T, 'spectrogram_frames': nd,
                 'parallelism': f'channel shard x{world}' +
-                               (f', all-gather of the {args.tile_seconds:g} s spectrogram tile '
-                                f'({4*C*tile_frames*F/1e9:.2f} GB per rank) under the ' +
-                                ('backward sweep of its step' if fuse3 else 'kernels of this and the next step')
-                                if multi else ''),
+                               (f', all-gather ({args.gather}) of the {args.tile} spectrogram tile '
+                                f'({4*C*tile_frames_of(args.tile)*F/1e9:.2f} GB per rank) behind the forward sweep, '
+                                f'{reserve} CUs left to RCCL' if multi else ''),
                 'iir_warmup_samples': {'bandpass': warm_f, 'envelope': warm_e},
                 'streams': ('spectrogram on a second stream next to the envelope backward sweep '
-                            '(their event-bracketed times overlap)' if overlap else 'one stream'),
+                            '(their event-bracketed times overlap)' if overlap else 'one compute stream'),
                 'envelope_forward': ('state checkpoints, ' + ('fused into the band-pass kernel' if fused else 'own launch')),
                 'spectrogram': ('FFT waves inside the forward sweep (filtered tiles from LDS)' if fuse3 else 'own launch'),
             },
@@ -526,6 +712,10 @@ def main():
             'parity_max_rel_err': parity,
             'cpu_baseline': cpu,
         }
+        if legs is not None:
+            line['legs'] = legs
+            line['compute_ms'] = legs.get('compute_ms')
+            line['gather_ms'] = (legs.get('tiles', {}).get(args.tile) or {}).get('gather_ms')
         if parity is None or not parity < 1e-4:
             line['invalid'] = 'parity gate failed'
         sys.stdout.flush()

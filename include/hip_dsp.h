@@ -65,6 +65,9 @@ int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
  *   "sos_waves_per_cu"   resident waves per CU the IIR segment planner aims for (16)
  *   "pool_limit_mb"      bytes (MiB) hipdsp_free may keep cached for hipdsp_malloc (1024)
  *   "sos_prefetch"       0: envelope sweeps without the register prefetch of the next tile (1)
+ *   "chain_reserve_cus"  CUs hipdsp_chain_forward plans no workgroup for (0): its 1024-thread workgroups want a
+ *                        whole CU each, so a kernel that stays resident next to it (RCCL's all-gather in the
+ *                        multi-GPU step) needs CUs of its own or a second round of workgroups forms
  *   "sos_no_pin"         non-zero: plan tables fetched by just-in-time scalar loads (A/B, tools/pin_ab.py)
  *   "force_generic_fft"  non-zero: every nfft takes the generic radix-2 / four-step kernels
  *   "spec_kernel"        0 = default per size, 2 = two-stage, 3 = three-stage FFT kernel

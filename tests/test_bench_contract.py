@@ -26,6 +26,20 @@ def test_flags_and_defaults():
     # BASELINE configs[2]
     assert (a.channels, a.seconds, a.rate, a.nfft, a.hop) == (64, 600.0, 96000.0, 2048, 1024)
     assert (a.hp, a.lp, a.order, a.env) == (300.0, 3000.0, 2, 20.0)
+    # BASELINE configs[3]: 256 channels over 8 GPUs = 32 per GPU; configs[1]: 4 ch x 60 s x 48 kHz, 1024/256, order 4
+    sys.argv = ['bench.py', '--config', '3']
+    try:
+        a3 = bench.parse()
+    finally:
+        sys.argv = argv
+    assert (a3.channels, a3.seconds, a3.rate, a3.nfft, a3.hop) == (32, 600.0, 96000.0, 2048, 1024)
+    assert 'configs[3]' in a3.config_name and a3.tile == 'visible'
+    sys.argv = ['bench.py', '--config', '1', '--channels', '8']
+    try:
+        a1 = bench.parse()
+    finally:
+        sys.argv = argv
+    assert (a1.channels, a1.seconds, a1.rate, a1.nfft, a1.hop, a1.order) == (8, 60.0, 48000.0, 1024, 256, 4)
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--help'], capture_output=True, text=True)
     for flag in ('--gpus', '--steps', '--warmup'):
         assert flag in out.stdout
@@ -84,4 +98,36 @@ def test_multi_rank_code_path_prints_only_the_json_line():
     assert len(lines) == 1, out.stdout[:2000]
     d = json.loads(lines[0])
     assert d['n_gpus'] == 1 and 'all-gather' in d['config']['parallelism']
+    assert d['parity_max_rel_err'] < 1e-4 and 'invalid' not in d
+    # compute and gather are reported separately, for the visible tile, the resident window and the whole spectrogram
+    legs = d['legs']
+    assert d['compute_ms'] == legs['compute_ms'] > 0 and d['gather_ms'] is not None
+    assert set(legs['tiles']) == {'visible', 'window', 'full'}
+    for t in legs['tiles'].values():
+        assert t['step_ms'] > 0 and t['gather_ms'] >= 0 and t['GB_per_rank'] > 0
+
+
+@pytest.mark.gpu
+def test_configs3_rehearsal_through_the_c_abi_gather():
+    """BASELINE configs[3]'s shard (32 channels per GPU) with the exchange step taken through the C ABI
+    (hipdsp_comm_* / hipdsp_allgather_f32 on a second context) instead of torch.distributed -- one rank here,
+    the driver runs the real thing; the fused forward sweep leaves CUs to RCCL's kernel."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--force-dist', '--config', '3', '--seconds',
+                          '60', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--gather', 'c-abi', '--tile',
+                          'window'], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29578'))
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.splitlines()[-1])
+    assert d['config']['channels_per_gpu'] == 32 and 'configs[3]' in d['config']['workload']
+    assert 'c-abi' in d['config']['parallelism'] and '8 CUs left to RCCL' in d['config']['parallelism']
+    assert d['legs']['tile_in_timed_region'] == 'window' and d['parity_max_rel_err'] < 1e-4 and 'invalid' not in d
+
+
+@pytest.mark.gpu
+def test_configs1_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', '1', '--steps', '3', '--warmup',
+                          '1', '--cpu-sample-seconds', '2'], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.splitlines()[-1])
+    assert 'configs[1]' in d['config']['workload'] and d['config']['channels_per_gpu'] == 4
     assert d['parity_max_rel_err'] < 1e-4 and 'invalid' not in d
