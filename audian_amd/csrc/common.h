@@ -78,5 +78,6 @@ static inline int hd_launch_status(const char *what)
 }
 
 int hipdsp_scratch(hipdsp_ctx *ctx, size_t bytes, void **out);
-// tw2 | tw3 | twn | window of the 2048-point PSD kernel (radix 16 x 16 x 4), device memory (spectrogram.hip)
-int hd_fft_tables_2048(hipdsp_ctx *ctx, const float **dev);
+// tw2 | tw3 | twn | window of the three-stage PSD kernel for nfft 2048 (radix 16 x 16 x 4) or 1024 (8 x 8 x 8),
+// device memory (spectrogram.hip)
+int hd_fft_tables(hipdsp_ctx *ctx, int nfft, const float **dev);

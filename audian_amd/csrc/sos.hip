@@ -760,22 +760,22 @@ struct ChainArgs {
         __builtin_amdgcn_wave_barrier();                     \
     } while (0)
 
-// One 2048-sample frame from its two register halves (lo: samples 2l + 128 t, t < 8; hi: the
-// same 1024 samples later) -> detrend, Hann, half-length complex FFT 16 x 16 x 4, split step, PSD.
-// Same arithmetic as spec_fast_kernel<2048, 64, 16, 16, 4, ...>.
-template <bool DB>
-__device__ __forceinline__ void psd_frame_2048(const v2f *lo, const v2f *hi, float2 *fb, const float2 *tw2,
-                                               const float2 *tw3, const float2 *twn, const float2 *win, int l,
-                                               float scale, float *__restrict__ o, float *__restrict__ od)
+// One frame of NFFT (2048: radix 16 x 16 x 4, 1024: 8 x 8 x 8) samples from its PPL = NFFT/128 registers
+// (register t: samples 2l + 128 t, 2l + 128 t + 1 of the frame) -> detrend, Hann, half-length complex FFT,
+// split step, PSD.  Same arithmetic as spec_fast_kernel<NFFT, 64, R1, R2, R3, ...>.
+template <int NFFT, int R1, int R2, int R3, bool DB>
+__device__ __forceinline__ void psd_frame(const v2f *w, float2 *fb, const float2 *tw2, const float2 *tw3,
+                                          const float2 *twn, const float2 *win, int l, float scale,
+                                          float *__restrict__ o, float *__restrict__ od)
 {
-    constexpr int NFFT = 2048, M = 1024, LPF = 64, PPL = 16, R1 = 16, R2 = 16, R3 = 4;
+    constexpr int M = NFFT / 2, LPF = 64, PPL = M / LPF;
+    static_assert(PPL == R1 && R1 * R2 * R3 == M, "one first-stage butterfly per lane");
     float2 v[PPL];
     v2f acc = {0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < R1; t++) {
-        const v2f r = t < R1 / 2 ? lo[t] : hi[t - R1 / 2];
-        v[t] = make_float2(r.x, r.y);
-        acc += r;
+        v[t] = make_float2(w[t].x, w[t].y);
+        acc += w[t];
     }
     const float mean = wave_sum(acc.x + acc.y) * (1.0f / (float)NFFT);
     const v2f mean2 = {mean, mean};
@@ -831,14 +831,22 @@ __device__ __forceinline__ void psd_frame_2048(const v2f *lo, const v2f *hi, flo
 
 // STAMP (diagnostic build, "chain_debug" bit 32; results stay valid): every wave adds up the shader clocks
 // it spends in each part of its loop body and leaves the 16 sums in a.db (which then is NOT a dB output).
-template <int SF, int SE, int NP, bool FLAGS, bool DB, bool STAMP = false>
+// NFFT / HOP: the window lengths whose frames are register windows of a tile -- 2048 or 1024 samples, hops
+// that divide the tile and are multiples of 128 samples (one register of the FFT wave's tile copy).
+template <int SF, int SE, int NP, bool FLAGS, bool DB, int NFFT = 2048, int HOP = 1024, bool STAMP = false>
 __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPlanDev *__restrict__ PF0,
                                                                    const SosPlanDev *__restrict__ PE0, ChainArgs a)
 {
     static_assert(SF > 0 && NP % 2 == 0, "band-pass in front; whole waves per SIMD");
     constexpr int DF = 2 * SF, DE = 2 * SE;
-    constexpr int M = TILE / 2, F = M + 1, MP = M + M / 16;
-    constexpr int TW2 = 15 * 16, TW3 = 256, TWN = M / 2 + 1, NTAB = TW2 + TW3 + TWN + M;
+    static_assert((NFFT == 2048 || NFFT == 1024) && TILE % HOP == 0 && HOP % 128 == 0 && HOP <= NFFT && NFFT <= TILE,
+                  "frames must be register windows of a tile");
+    constexpr int M = NFFT / 2, F = M + 1, MP = M + M / 16;
+    constexpr int R1 = NFFT == 2048 ? 16 : 8, R2 = R1, R3 = NFFT == 2048 ? 4 : 8;
+    constexpr int TW2 = (R2 - 1) * R1, TW3 = R1 * R2, TWN = M / 2 + 1, NTAB = TW2 + TW3 + TWN + M;
+    constexpr int PPL = NFFT / 128;             // registers (128 samples each) of one frame
+    constexpr int FPT = TILE / HOP;             // frames that END inside a tile
+    constexpr int PREV = (NFFT - HOP) / 128;    // registers of the previous tile a frame can reach back into
     __shared__ float4 tiles[NP][64 * 8];
     __shared__ float rprevs[NP][64];
     __shared__ float2 fbs[NP][MP];
@@ -1178,9 +1186,14 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
         const float2 *tw2 = tab, *tw3 = tab + TW2, *twn = tab + TW2 + TW3, *win = tab + TW2 + TW3 + TWN;
         float *oc = a.psd + ch * a.psd_pitch;
         float *dc = DB ? a.db + ch * a.psd_pitch : nullptr;
-        v2f lo_[8], hi_[8], hp_[8];
+        // the tile as 16 registers (register j: samples 128 j + 2 lane, + 1) and the last PREV registers of the
+        // tile before it: frame m of a tile (the one that ends (m + 1) HOP samples into it) is the window of
+        // PPL consecutive registers that starts at register ((m + 1) HOP - NFFT) / 128 of the two
+        v2f cur_[16], prv_[PREV > 0 ? PREV : 1];
 #pragma unroll
-        for (int j = 0; j < 8; j++) { lo_[j] = (v2f){0.f, 0.f}; hi_[j] = (v2f){0.f, 0.f}; hp_[j] = (v2f){0.f, 0.f}; }
+        for (int j = 0; j < 16; j++) cur_[j] = (v2f){0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < (PREV > 0 ? PREV : 1); j++) prv_[j] = (v2f){0.f, 0.f};
         bool have_prev = false;
         for (int it = 0; it < a.n_iter; it++) {
             const long long tile = base + (long long)it * TILE;
@@ -1190,10 +1203,8 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             STAMP_AT(8);                                       // waited for the IIR wave's tile
             if (active) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    lo_[j] = *reinterpret_cast<const v2f *>(tlf + lds_float_index(2 * lane + 128 * j));
-                    hi_[j] = *reinterpret_cast<const v2f *>(tlf + lds_float_index(1024 + 2 * lane + 128 * j));
-                }
+                for (int j = 0; j < 16; j++)
+                    cur_[j] = *reinterpret_cast<const v2f *>(tlf + lds_float_index(2 * lane + 128 * j));
             }
             if (FLAGS) {                                        // (the release fence waits for the loads)
                 // "chain_debug" bit 8 (fault-path test): FFT wave 0 of workgroup 0 withholds the hand-over of
@@ -1206,18 +1217,23 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             if (active) {
                 const long long t = tile / TILE;
                 if (tile >= lo && tile < hi) {                 // the unit that owns the tile writes its frames
-                    const long long f1 = 2 * t - 1;
                   if (!(a.debug & 1)) {
-                    if (have_prev && f1 >= 0 && f1 < a.n_valid)
-                        psd_frame_2048<DB>(hp_, lo_, fb, tw2, tw3, twn, win, lane, a.scale, oc + f1 * (long long)F,
-                                           dc + f1 * (long long)F);
-                    if (2 * t < a.n_valid)
-                        psd_frame_2048<DB>(lo_, hi_, fb, tw2, tw3, twn, win, lane, a.scale, oc + 2 * t * (long long)F,
-                                           dc + 2 * t * (long long)F);
-                  } else if (f1 == -12345) oc[lane] = lo_[0].x + hi_[1].y + hp_[2].x;
+#pragma unroll
+                    for (int m = 0; m < FPT; m++) {
+                        const int j0 = ((m + 1) * HOP - NFFT) / 128;          // compile-time after unrolling
+                        const long long f = t * FPT + m + 1 - NFFT / HOP;
+                        if ((j0 >= 0 || have_prev) && f >= 0 && f < a.n_valid) {
+                            v2f w[PPL];
+#pragma unroll
+                            for (int i = 0; i < PPL; i++) w[i] = (j0 + i < 0) ? prv_[(PREV + j0 + i) < 0 ? 0 : (PREV + j0 + i)] : cur_[(j0 + i) < 0 ? 0 : (j0 + i)];
+                            psd_frame<NFFT, R1, R2, R3, DB>(w, fb, tw2, tw3, twn, win, lane, a.scale, oc + f * (long long)F,
+                                                            dc + f * (long long)F);
+                        }
+                    }
+                  } else if (t == -12345) oc[lane] = cur_[0].x + cur_[9].y + prv_[0].x;
                 }
 #pragma unroll
-                for (int j = 0; j < 8; j++) hp_[j] = hi_[j];
+                for (int j = 0; j < PREV; j++) prv_[j] = cur_[16 - PREV + j];
                 have_prev = true;
             }
             STAMP_AT(10);                                      // the tile's (at most) two frames
@@ -1722,11 +1738,17 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     HD_REQUIRE(fs > 0, "fs must be positive");
     const int SF = fplan->host->n_sections, SE = eplan->host->n_sections;
     HD_REQUIRE(SF > 0 && SE > 0, "plan has no coefficients");
-    if (nfft != TILE || hop != TILE / 2 || SF > 2 || SE > 2 || frames < 4 * TILE ||
+    // shapes the kernel is built for: frames that are register windows of a 2048-sample tile
+    const bool shape_ok = (nfft == 2048 && (hop == 1024 || hop == 512)) || (nfft == 1024 && (hop == 512 || hop == 256));
+    if (!shape_ok || SF > 4 || SE > 2 || frames < 4 * TILE ||
         fplan->host->warm >= (1LL << 40) || eplan->host->warm >= (1LL << 40)) {
-        hipdsp_set_error("the fused forward sweep covers nfft %d / hop %d, plans of at most two sections that "
-                         "decay, and traces of at least %d frames: use hipdsp_sosfilt_envelope + "
-                         "hipdsp_spectrogram", TILE, TILE / 2, 4 * TILE);
+        hipdsp_set_error("the fused forward sweep covers nfft/hop 2048/1024, 2048/512, 1024/512 and 1024/256, a band-pass of "
+                         "at most four and an envelope of at most two sections that decay, and traces of at least %d "
+                         "frames: use hipdsp_sosfilt_envelope + hipdsp_spectrogram", 4 * TILE);
+        return HIPDSP_ERR_UNSUPPORTED;
+    }
+    if (db_out && !(nfft == 2048 && hop == 1024) && !(ctx->chain_debug & 32)) {
+        hipdsp_set_error("the fused dB output is built for nfft 2048 / hop 1024 only");
         return HIPDSP_ERR_UNSUPPORTED;
     }
     HD_CHECK_HIP(hipSetDevice(ctx->device));
@@ -1739,7 +1761,7 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     HD_REQUIRE(channels <= 65535, "more than 65535 channels");     // grid.y of the zero-tail launch
     HD_REQUIRE(x != nullptr && yf != nullptr && (psd != nullptr || frames_out == 0), "NULL data pointer");
     HD_REQUIRE(x_pitch >= frames && yf_pitch >= frames, "pitch smaller than row length");
-    const long long F = TILE / 2 + 1;
+    const long long F = nfft / 2 + 1;
     if (psd_pitch == 0) psd_pitch = frames_out * F;
     HD_REQUIRE(psd_pitch >= frames_out * F, "psd_pitch smaller than one channel");
     // frames inside the trace, as in hipdsp_spectrogram (bufferedspectrogram.py:46-49)
@@ -1755,7 +1777,7 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     }
     ChainArgs a;
     memset(&a, 0, sizeof(a));
-    int rc = hd_fft_tables_2048(ctx, &a.tables);
+    int rc = hd_fft_tables(ctx, nfft, &a.tables);
     if (rc != HIPDSP_OK) return rc;
     const long long n_tiles = (frames + edge + TILE - 1) / TILE;
     const long long ckpt_pitch = n_tiles * 2 * SE;                 // the layout the backward sweep expects
@@ -1789,7 +1811,15 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     }
     dim3 grid((unsigned)blocks), block(128 * P);
     const bool flags = (ctx->chain_debug & 4) == 0;       // bit 4: workgroup barriers instead of the pairwise flags
-#define HD_CHAIN(A, B)                                                                                              \
+    if ((ctx->chain_debug & 32) && db_out && SF == 2 && SE == 1 && flags && nfft == 2048 && hop == 1024) {
+        // diagnostic build: db_out receives 16 clock sums per wave (needs >= blocks * 16 * 16 * 8 bytes)
+        hipLaunchKernelGGL((chain_fwd_kernel<2, 1, P, true, false, 2048, 1024, true>), grid, block, 0, ctx->stream,
+                           fplan->dev, eplan->dev, a);
+        return hd_launch_status("chain_fwd_kernel");
+    }
+    // nfft 2048 / hop 1024 with plans of up to two sections: every variant (barriers for the tests, fused dB
+    // output for the display path); the other shapes and longer band-passes: pairwise flags, PSD only
+#define HD_CHAIN_FULL(A, B)                                                                                         \
     case (A) * 8 + (B):                                                                                            \
         if (db_out) {                                                                                              \
             if (flags) hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, true>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);  \
@@ -1799,16 +1829,40 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
             else hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, false, false>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);      \
         }                                                                                                          \
         break
-    if ((ctx->chain_debug & 32) && db_out && SF == 2 && SE == 1 && flags) {
-        // diagnostic build: db_out receives 16 clock sums per wave (needs >= blocks * 16 * 16 * 8 bytes)
-        hipLaunchKernelGGL((chain_fwd_kernel<2, 1, P, true, false, true>), grid, block, 0, ctx->stream, fplan->dev,
-                           eplan->dev, a);
-        return hd_launch_status("chain_fwd_kernel");
+#define HD_CHAIN_LONG(A, B)                                                                                         \
+    case (A) * 8 + (B):                                                                                            \
+        if (db_out) hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, true>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a); \
+        else hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, false>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);       \
+        break
+#define HD_CHAIN_SHAPE(A, B, N, H)                                                                                  \
+    case (A) * 8 + (B):                                                                                            \
+        hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, false, N, H>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a); \
+        break
+#define HD_CHAIN_ALL(N, H)                                                                                          \
+    switch (SF * 8 + SE) {                                                                                         \
+        HD_CHAIN_SHAPE(1, 1, N, H); HD_CHAIN_SHAPE(1, 2, N, H); HD_CHAIN_SHAPE(2, 1, N, H); HD_CHAIN_SHAPE(2, 2, N, H); \
+        HD_CHAIN_SHAPE(3, 1, N, H); HD_CHAIN_SHAPE(3, 2, N, H); HD_CHAIN_SHAPE(4, 1, N, H); HD_CHAIN_SHAPE(4, 2, N, H); \
     }
-    switch (SF * 8 + SE) {
-        HD_CHAIN(1, 1); HD_CHAIN(1, 2); HD_CHAIN(2, 1); HD_CHAIN(2, 2);
+    if (nfft == 2048 && hop == 1024) {
+        if ((!flags) && (SF > 2)) {
+            hipdsp_set_error("the barrier variant of the fused sweep is built for plans of at most two sections");
+            return HIPDSP_ERR_UNSUPPORTED;
+        }
+        switch (SF * 8 + SE) {
+            HD_CHAIN_FULL(1, 1); HD_CHAIN_FULL(1, 2); HD_CHAIN_FULL(2, 1); HD_CHAIN_FULL(2, 2);
+            HD_CHAIN_LONG(3, 1); HD_CHAIN_LONG(3, 2); HD_CHAIN_LONG(4, 1); HD_CHAIN_LONG(4, 2);
+        }
+    } else if (nfft == 2048 && hop == 512) {
+        HD_CHAIN_ALL(2048, 512)
+    } else if (nfft == 1024 && hop == 512) {
+        HD_CHAIN_ALL(1024, 512)
+    } else {
+        HD_CHAIN_ALL(1024, 256)
     }
-#undef HD_CHAIN
+#undef HD_CHAIN_FULL
+#undef HD_CHAIN_LONG
+#undef HD_CHAIN_SHAPE
+#undef HD_CHAIN_ALL
     return hd_launch_status("chain_fwd_kernel");
 }
 

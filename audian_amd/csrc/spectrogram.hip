@@ -1105,7 +1105,13 @@ int run_wg(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long channel
 
 }  // namespace
 
-int hd_fft_tables_2048(hipdsp_ctx *ctx, const float **dev) { return fft_tables(ctx, 2048, 16, 16, 4, dev); }
+int hd_fft_tables(hipdsp_ctx *ctx, int nfft, const float **dev)
+{
+    if (nfft == 2048) return fft_tables(ctx, 2048, 16, 16, 4, dev);
+    if (nfft == 1024) return fft_tables(ctx, 1024, 8, 8, 8, dev);
+    hipdsp_set_error("no three-stage table set for nfft %d", nfft);
+    return HIPDSP_ERR_UNSUPPORTED;
+}
 
 extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, int64_t channels,
                                   int64_t frames, int nfft, int hop, double fs, float *out,

@@ -524,7 +524,7 @@ def test_chain_forward_equals_separate_calls(oracle, T, max_segments, handover):
             assert np.array_equal(np.isfinite(gdb[:, :nf, :]), fin)
             assert np.max(np.abs(gdb[:, :nf, :][fin] - want_db[fin])) < 1e-3
         with pytest.raises(NotImplementedError):
-            hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, 1024, 512, rate, ps, nd)
+            hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, 512, 256, rate, ps, nd)
     finally:
         c.set_max_segments(0)
         c.set_option('chain_debug', 0)
@@ -635,3 +635,61 @@ def test_envelope_cascades_longer_than_one_plan(oracle, T):
                 one = gh.gpu_envelope(sos, x, clamp=ehp == 0)
                 for ch in range(C):
                     assert rel_err(got[:, ch], one[:, ch]) < 1e-5
+
+
+@pytest.mark.parametrize('nfft,hop', [(2048, 512), (1024, 512), (1024, 256), (2048, 1024)])
+@pytest.mark.parametrize('T,max_segments', [(8192, 0), (20481, 0), (70001, 0), (300000, 3), (1500000, 0)])
+def test_chain_forward_other_windows_and_longer_bandpasses(oracle, T, max_segments, nfft, hop):
+    """The fused forward sweep for every window the kernel is built for (frames are register windows of a
+    2048-sample tile: 50 % and 75 % overlap at nfft 2048 and 1024; BASELINE configs[1] is 1024/256 with a
+    four-section band-pass) and band-pass plans of three and four sections: against the separate calls and
+    the oracle, one and many segments, traces that end inside a tile, every frame written, zero tail."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rate, C = 48000.0, 3
+    rng = np.random.default_rng(T + max_segments + nfft + hop)
+    x = (synth(rng, T, C, rate) + np.float32(0.05)).astype(np.float32)
+    c = gh.ctx()
+    c.set_max_segments(max_segments)
+    try:
+        dx = gh.to_planar(c, x)
+        nd = (T + hop - 1)//hop
+        F = nfft//2 + 1
+        plans = [((300.0, 3000.0), 4, 20.0, 2), ((500.0, 9000.0), 3, 400.0, 4)]
+        if (nfft, hop) != (2048, 1024):
+            plans.append(((300.0, 3000.0), 2, 20.0, 2))
+        for band, order, env, eorder in plans:
+            sos = butter_sos(order, band, 'bandpass', rate)
+            esos = butter_sos(eorder, env, 'lowpass', rate)
+            fplan, eplan = hipdsp.SosPlan(c, sos), hipdsp.SosPlan(c, esos)
+            yf = hipdsp.DeviceArray(c, (C, T), np.float32)
+            ye = hipdsp.DeviceArray(c, (C, T), np.float32)
+            ps = hipdsp.DeviceArray(c, (C, nd + 2, F), np.float32)
+            hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(ps), 0x7f, 4*C*(nd + 2)*F)      # every bin must be written
+            hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, nfft, hop, rate, ps, nd + 2)
+            hipdsp.sosfilt_envelope(c, fplan, eplan, dx, T, yf, T, ye, T, C, T, phase=2)
+            f1 = hipdsp.DeviceArray(c, (C, T), np.float32)
+            e1 = hipdsp.DeviceArray(c, (C, T), np.float32)
+            s1 = hipdsp.DeviceArray(c, (C, nd + 2, F), np.float32)
+            hipdsp.sosfilt_envelope(c, fplan, eplan, dx, T, f1, T, e1, T, C, T)
+            hipdsp.spectrogram(c, f1, T, C, T, nfft, hop, rate, s1, nd + 2)
+            gf, ge, gs = yf.to_host(), ye.to_host(), ps.to_host()
+            sf, se, ss = f1.to_host(), e1.to_host(), s1.to_host()
+            want_f = oracle.sosfilt(sos, x.astype(np.float64))
+            want_e = np.zeros_like(want_f)
+            oracle.envelope_process(esos, sf.T.astype(np.float64), want_e, 0)
+            want_s = np.zeros((nd + 2, C, F))
+            oracle.spectrogram_process(sf.T.astype(np.float64), want_s, rate, nfft, hop)
+            for ch in range(C):
+                assert rel_err(gf[ch], sf[ch]) < 1e-6, (T, order, ch)
+                assert rel_err(ge[ch], se[ch]) < 2e-6, (T, env, ch)
+                assert rel_err(gf[ch], want_f[:, ch]) < TOL
+                assert rel_err(ge[ch], want_e[:, ch]) < TOL
+                for j in range(nd + 2):
+                    if np.max(np.abs(want_s[j, ch])) == 0:
+                        assert np.all(gs[ch, j] == 0) and np.all(ss[ch, j] == 0), (T, j, ch)
+                    else:
+                        assert rel_err(gs[ch, j], want_s[j, ch]) < TOL, (T, max_segments, j, ch)
+                        assert rel_err(gs[ch, j], ss[ch, j]) < 1e-5, (T, max_segments, j, ch)
+    finally:
+        c.set_max_segments(0)
