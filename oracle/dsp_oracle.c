@@ -4,9 +4,10 @@
  *
  * Plain-C float64 restatement of the arithmetic that audian's BufferedData hot
  * path delegates to scipy.signal (scipy 1.15.3; the reference pins no version,
- * pyproject.toml:9).  The reference itself holds no golden vectors for this
- * path (it has no tests), so this oracle is pinned against scipy-generated
- * fixtures committed under tests/golden/ (generator: tests/golden/make_golden.py).
+ * pyproject.toml:9).  PARITY UNPINNED by the reference: it holds no golden vectors
+ * for this path (it has no tests) and cannot be run here, so this oracle is pinned
+ * against scipy-generated fixtures committed under tests/golden/ instead
+ * (generator: tests/golden/make_golden.py; the reference's own call arguments).
  *
  * Reference call sites restated here (relative to /root/reference):
  *   src/audian/bufferedfilter.py:35-36     sosfilt(sos, source[:, c])[nbefore:]

@@ -14,8 +14,9 @@ delegates to third-party code that is *not* part of ``/root/reference``:
   ``src/audian/bufferedspectrogram.py:51-60`` and ``src/audian/specitem.py:36`` --
   "thunderlab-equivalence assumed").
 
-The reference has no tests and no golden vectors for this path, so the oracle is
-pinned by scipy-generated fixtures under ``tests/golden/`` (generator script
+PARITY UNPINNED by the reference: it has no tests and no golden vectors for this path and its
+package cannot be imported here (PyQt), so nothing the reference itself holds or produces pins this
+oracle.  What it is pinned by instead: scipy-generated fixtures under ``tests/golden/`` (generator script
 ``tests/golden/make_golden.py``, run in the build container where scipy 1.15.3 is
 installed).  The recursive filters live in ``dsp_oracle.c`` (plain C, gcc); the
 framed PSD exists both there and as a NumPy restatement below so the two check

@@ -24,7 +24,7 @@ def short(name):
     m = re.search(r'chain_fwd_kernel<(\d), (\d), \d+(?:, \w+)*>', name)
     if m:
         return 'chain_fwd<S=%s+%s,filt+env_state+psd>' % m.groups()
-    m = re.search(r'env_bwd_kernel<(\d)(?:, \w+)?>', name)
+    m = re.search(r'env_bwd_kernel<(\d)(?:, \w+)*>', name)
     if m:
         return 'env_bwd<S=%s>' % m.group(1)
     m = re.search(r'sos_scan_kernel<(\d)>', name)
