@@ -77,6 +77,10 @@ def parse():
                     help='CUs the fused forward sweep leaves free (default 8 at N>1, 0 at N=1): its workgroups take '
                          'a whole CU each, RCCL\'s resident all-gather kernel needs some of its own')
     ap.add_argument('--no-legs', action='store_true', help='N>1: skip the compute-only / per-tile legs')
+    ap.add_argument('--full-leg', action='store_true',
+                    help="N>1: also run the leg that gathers every rank's WHOLE spectrogram (7.4-14.8 GB per rank, "
+                         'merged on every rank: 59-118 GB at N=8, seconds per gather); by default only the visible '
+                         'and the window tile are rehearsed after the timed region')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-seconds', type=float, default=60.0)
     ap.add_argument('--max-segments', type=int, default=0)
@@ -634,6 +638,10 @@ def main():
             legs['compute_ms'] = round(compute_dt/args.steps*1e3, 4)
             legs['tiles'] = {}
             for name in ('visible', 'window', 'full'):
+                if name == 'full' and not (args.full_leg or args.tile == 'full'):
+                    legs['tiles'][name] = {'skipped': 'opt-in (--full-leg): %.1f GB per rank, %.1f GB merged on every rank'
+                                                      % (tile_gb(name), tile_gb(name)*world)}
+                    continue
                 g = None
                 try:
                     g = main_gather if name == args.tile else make_gatherer(name)
@@ -647,10 +655,8 @@ def main():
                         'gather_ms': round(alone_s*1e3, 4),                      # the gather alone on the device
                         'gather_exposed_ms': round((gdt - compute_dt)/args.steps*1e3, 4),
                         'gather_GBps_per_rank_in': round(gb*(world - 1)/alone_s, 1) if world > 1 else None}
-                except (MemoryError, RuntimeError) as err:
-                    if 'out of memory' not in str(err).lower():
-                        raise
-                    legs['tiles'][name] = {'skipped': 'does not fit next to the resident arrays on this box'}
+                except Exception as err:      # a leg must never cost the line of the timed region
+                    legs['tiles'][name] = {'failed': f'{type(err).__name__}: {err}'[:300]}
                 if g is not None and g is not main_gather:
                     g.drain()
                     if hasattr(g, 'close'):

@@ -103,7 +103,9 @@ def test_multi_rank_code_path_prints_only_the_json_line():
     legs = d['legs']
     assert d['compute_ms'] == legs['compute_ms'] > 0 and d['gather_ms'] is not None
     assert set(legs['tiles']) == {'visible', 'window', 'full'}
-    for t in legs['tiles'].values():
+    assert 'skipped' in legs['tiles']['full']                 # seconds per gather at N = 8: opt-in (--full-leg)
+    for name in ('visible', 'window'):
+        t = legs['tiles'][name]
         assert t['step_ms'] > 0 and t['gather_ms'] >= 0 and t['GB_per_rank'] > 0
 
 

@@ -306,3 +306,34 @@ def test_configs4_full_size_cutoff_sweep(oracle):
     ctx.destroy_stream(stream)
     for a in (dx, df, de, ds, db):
         a.free()
+
+
+def test_scratch_cannot_move_under_a_live_graph():
+    """A captured launch holds the address of the context scratch (the envelope's state checkpoints).  A later
+    call that would have to GROW the scratch must be refused while that graph is alive -- growing frees the
+    block the graph still points into -- and must work again once the graph is destroyed."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rate, C, T = 48000.0, 2, 48000
+    ctx = hipdsp.Context(0)
+    stream = ctx.create_stream()
+    ctx.set_stream(stream)
+    dx = hipdsp.DeviceArray(ctx, (C, 8*T), np.float32)
+    hipdsp.synth(ctx, dx, 8*T, C, 8*T, rate, 5)
+    dy = hipdsp.DeviceArray(ctx, (C, 8*T), np.float32)
+    eplan = hipdsp.SosPlan(ctx, butter_sos(2, 500.0, 'lowpass', rate))
+    hipdsp.envelope(ctx, eplan, dx, 8*T, dy, 8*T, C, T, 0)          # warm: scratch for T frames
+    ctx.synchronize()
+    ctx.graph_begin()
+    hipdsp.envelope(ctx, eplan, dx, 8*T, dy, 8*T, C, T, 0)
+    graph = ctx.graph_end()
+    ctx.graph_launch(graph)
+    with pytest.raises(ValueError, match='captured graph'):
+        hipdsp.envelope(ctx, eplan, dx, 8*T, dy, 8*T, C, 8*T, 0)      # eight times the checkpoints
+    ctx.graph_launch(graph)                                           # the graph is intact
+    ctx.synchronize()
+    ctx.graph_destroy(graph)
+    hipdsp.envelope(ctx, eplan, dx, 8*T, dy, 8*T, C, 8*T, 0)          # now the scratch may grow
+    ctx.synchronize()
+    ctx.set_stream(None)
+    ctx.destroy_stream(stream)
