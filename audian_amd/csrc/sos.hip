@@ -760,16 +760,18 @@ struct ChainArgs {
         __builtin_amdgcn_wave_barrier();                     \
     } while (0)
 
-// One frame of NFFT (2048: radix 16 x 16 x 4, 1024: 8 x 8 x 8) samples from its PPL = NFFT/128 registers
-// (register t: samples 2l + 128 t, 2l + 128 t + 1 of the frame) -> detrend, Hann, half-length complex FFT,
-// split step, PSD.  Same arithmetic as spec_fast_kernel<NFFT, 64, R1, R2, R3, ...>.
-template <int NFFT, int R1, int R2, int R3, bool DB>
+// One frame of NFFT samples per group of LPF lanes (2048: LPF 64, radix 16 x 16 x 4; 1024: 64, 8 x 8 x 8; 512: two
+// frames side by side in a wave, LPF 32, 8 x 8 x 4) from its PPL = NFFT / (2 LPF) values per lane (value t: samples
+// 2l + 2 LPF t, + 1 of the frame) -> detrend, Hann, half-length complex FFT, split step, PSD.  `keep` masks the
+// stores of a lane group whose frame does not exist.  Same arithmetic as spec_fast_kernel<NFFT, LPF, R1, R2, R3, ...>.
+template <int NFFT, int LPF, int R1, int R2, int R3, bool DB>
 __device__ __forceinline__ void psd_frame(const v2f *w, float2 *fb, const float2 *tw2, const float2 *tw3,
-                                          const float2 *twn, const float2 *win, int l, float scale,
+                                          const float2 *twn, const float2 *win, int lane, float scale, bool keep,
                                           float *__restrict__ o, float *__restrict__ od)
 {
-    constexpr int M = NFFT / 2, LPF = 64, PPL = M / LPF;
+    constexpr int M = NFFT / 2, PPL = M / LPF;
     static_assert(PPL == R1 && R1 * R2 * R3 == M, "one first-stage butterfly per lane");
+    const int l = lane % LPF, g0 = (lane / LPF) * LPF;
     float2 v[PPL];
     v2f acc = {0.f, 0.f};
 #pragma unroll
@@ -777,16 +779,23 @@ __device__ __forceinline__ void psd_frame(const v2f *w, float2 *fb, const float2
         v[t] = make_float2(w[t].x, w[t].y);
         acc += w[t];
     }
-    const float mean = wave_sum(acc.x + acc.y) * (1.0f / (float)NFFT);
+    float sum = acc.x + acc.y;
+    if (LPF == 64) {
+        sum = wave_sum(sum);
+    } else {
+#pragma unroll
+        for (int d = LPF / 2; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    }
+    const float mean = sum * (1.0f / (float)NFFT);
     const v2f mean2 = {mean, mean};
 #pragma unroll
     for (int t = 0; t < R1; t++) v[t] = as_f2((as_v2f(v[t]) - mean2) * as_v2f(win[l + LPF * t]));
     stockham_stage<R1, 1, M, LPF, false, true>(v, fb, tw2, l);
     stockham_stage<R2, R1, M, LPF, true, true>(v, fb, tw2, l);
     stockham_stage<R3, R1 * R2, M, LPF, true, false, true>(v, fb, tw3, l);
-    // v[u*R3 + t] = Z[k], k = l + LPF*m, m = u + NB3*t; partner bin Z[M-k] from lane 64-l
+    // v[u*R3 + t] = Z[k], k = l + LPF*m, m = u + NB3*t; partner bin Z[M-k] from lane LPF-l of the same group
     constexpr int NB3 = PPL / R3;
-    const int partner = (LPF - l) & (LPF - 1);
+    const int partner = g0 + ((LPF - l) & (LPF - 1));
     float pk_last = 0.f;
     const v2f hscale2 = {0.5f * scale, 0.5f * scale};
 #pragma unroll
@@ -813,9 +822,11 @@ __device__ __forceinline__ void psd_frame(const v2f *w, float2 *fb, const float2
             pk = (l == 0) ? dc0 * dc0 * scale : pk;
             pm = (l == 0) ? ny * ny * scale : pm;
         }
-        o[k] = pk;
-        o[M - k] = pm;
-        if (DB) { od[k] = to_db(pk); od[M - k] = to_db(pm); }
+        if (LPF == 64 || keep) {
+            o[k] = pk;
+            o[M - k] = pm;
+            if (DB) { od[k] = to_db(pk); od[M - k] = to_db(pm); }
+        }
         pk_last = pk;
     }
     {
@@ -824,13 +835,16 @@ __device__ __forceinline__ void psd_frame(const v2f *w, float2 *fb, const float2
         const float ph = 2.f * scale * (z.x * z.x + z.y * z.y);
         const int kk = (l == 0) ? M / 2 : l + LPF * (PPL / 2 - 1);
         const float pv = (l == 0) ? ph : pk_last;
-        o[kk] = pv;
-        if (DB) od[kk] = to_db(pv);
+        if (LPF == 64 || keep) {
+            o[kk] = pv;
+            if (DB) od[kk] = to_db(pv);
+        }
     }
 }
 
 // STAMP (diagnostic build, "chain_debug" bit 32; results stay valid): every wave adds up the shader clocks
 // it spends in each part of its loop body and leaves the 16 sums in a.db (which then is NOT a dB output).
+#define FPT_OK(hop, g) ((2048 / (hop)) % (g) == 0)
 // NFFT / HOP: the window lengths whose frames are register windows of a tile -- 2048 or 1024 samples, hops
 // that divide the tile and are multiples of 128 samples (one register of the FFT wave's tile copy).
 template <int SF, int SE, int NP, bool FLAGS, bool DB, int NFFT = 2048, int HOP = 1024, bool STAMP = false>
@@ -839,17 +853,20 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
 {
     static_assert(SF > 0 && NP % 2 == 0, "band-pass in front; whole waves per SIMD");
     constexpr int DF = 2 * SF, DE = 2 * SE;
-    static_assert((NFFT == 2048 || NFFT == 1024) && TILE % HOP == 0 && HOP % 128 == 0 && HOP <= NFFT && NFFT <= TILE,
-                  "frames must be register windows of a tile");
+    static_assert((NFFT == 2048 || NFFT == 1024 || NFFT == 512) && TILE % HOP == 0 && HOP % 128 == 0 && HOP <= NFFT &&
+                  NFFT <= TILE, "frames must be register windows of a tile");
     constexpr int M = NFFT / 2, F = M + 1, MP = M + M / 16;
-    constexpr int R1 = NFFT == 2048 ? 16 : 8, R2 = R1, R3 = NFFT == 2048 ? 4 : 8;
+    constexpr int LPF = NFFT >= 1024 ? 64 : 32;  // lanes per frame; G frames side by side in an FFT wave
+    constexpr int G = 64 / LPF;
+    constexpr int R1 = NFFT == 2048 ? 16 : 8, R2 = R1, R3 = NFFT == 1024 ? 8 : 4;
     constexpr int TW2 = (R2 - 1) * R1, TW3 = R1 * R2, TWN = M / 2 + 1, NTAB = TW2 + TW3 + TWN + M;
     constexpr int PPL = NFFT / 128;             // registers (128 samples each) of one frame
-    constexpr int FPT = TILE / HOP;             // frames that END inside a tile
+    static_assert(FPT_OK(HOP, G), "whole groups of frames per tile");
+    constexpr int FPT = TILE / HOP;             // frames that END inside a tile (a multiple of G)
     constexpr int PREV = (NFFT - HOP) / 128;    // registers of the previous tile a frame can reach back into
     __shared__ float4 tiles[NP][64 * 8];
     __shared__ float rprevs[NP][64];
-    __shared__ float2 fbs[NP][MP];
+    __shared__ float2 fbs[NP][G * MP];
     __shared__ float2 tab[NTAB];
     // FLAGS: pairwise hand-over instead of the two workgroup barriers -- ready[p] counts the tiles IIR
     // wave p has finished, taken[p] the tiles FFT wave p has copied (monotonic, one writer each)
@@ -1219,15 +1236,42 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                 if (tile >= lo && tile < hi) {                 // the unit that owns the tile writes its frames
                   if (!(a.debug & 1)) {
 #pragma unroll
-                    for (int m = 0; m < FPT; m++) {
+                    for (int m = 0; m < FPT; m += G) {
                         const int j0 = ((m + 1) * HOP - NFFT) / 128;          // compile-time after unrolling
-                        const long long f = t * FPT + m + 1 - NFFT / HOP;
-                        if ((j0 >= 0 || have_prev) && f >= 0 && f < a.n_valid) {
-                            v2f w[PPL];
+                        auto reg = [&](int j) -> v2f { return j < 0 ? prv_[(PREV + j) < 0 ? 0 : (PREV + j)] : cur_[j < 0 ? 0 : j]; };
+                        if (G == 1) {
+                            const long long f = t * FPT + m + 1 - NFFT / HOP;
+                            if ((j0 >= 0 || have_prev) && f >= 0 && f < a.n_valid) {
+                                v2f w[PPL];
 #pragma unroll
-                            for (int i = 0; i < PPL; i++) w[i] = (j0 + i < 0) ? prv_[(PREV + j0 + i) < 0 ? 0 : (PREV + j0 + i)] : cur_[(j0 + i) < 0 ? 0 : (j0 + i)];
-                            psd_frame<NFFT, R1, R2, R3, DB>(w, fb, tw2, tw3, twn, win, lane, a.scale, oc + f * (long long)F,
-                                                            dc + f * (long long)F);
+                                for (int i = 0; i < PPL; i++) w[i] = reg(j0 + i);
+                                psd_frame<NFFT, LPF, R1, R2, R3, DB>(w, fb, tw2, tw3, twn, win, lane, a.scale, true,
+                                                                     oc + f * (long long)F, dc + f * (long long)F);
+                            }
+                        } else {
+                            // two frames side by side: lanes 0-31 take frame m, lanes 32-63 frame m + 1 (HOP / 128 registers
+                            // further on).  Value t of a lane is samples 2l + 64 t of ITS frame, i.e. register t / 2 of that
+                            // frame, lower (t even) or upper (t odd) half of the wave: v_permlane32_swap of the two frames'
+                            // registers gives {X.lo | Y.lo} and {X.hi | Y.hi} in one instruction per dword.
+                            const int gq = lane / LPF;
+                            const long long f = t * FPT + m + gq + 1 - NFFT / HOP;
+                            const bool ok0 = (j0 >= 0 || have_prev), ok1 = (j0 + HOP / 128 >= 0 || have_prev);
+                            const bool keep = (gq == 0 ? ok0 : ok1) && f >= 0 && f < a.n_valid;
+                            const long long fa = t * FPT + m + 1 - NFFT / HOP;
+                            if ((ok0 && fa >= 0 && fa < a.n_valid) || (ok1 && fa + 1 >= 0 && fa + 1 < a.n_valid)) {
+                                v2f w[2 * PPL];
+#pragma unroll
+                                for (int u = 0; u < PPL; u++) {
+                                    const v2f X = reg(j0 + u), Y = reg(j0 + HOP / 128 + u);
+                                    const auto rx = __builtin_amdgcn_permlane32_swap(__float_as_int(X.x), __float_as_int(Y.x), false, false);
+                                    const auto ry = __builtin_amdgcn_permlane32_swap(__float_as_int(X.y), __float_as_int(Y.y), false, false);
+                                    w[2 * u] = (v2f){__int_as_float(rx[0]), __int_as_float(ry[0])};
+                                    w[2 * u + 1] = (v2f){__int_as_float(rx[1]), __int_as_float(ry[1])};
+                                }
+                                const long long fc = keep ? f : 0;            // a masked group still needs a legal address
+                                psd_frame<NFFT, LPF, R1, R2, R3, DB>(w, fb + gq * MP, tw2, tw3, twn, win, lane, a.scale, keep,
+                                                                     oc + fc * (long long)F, dc + fc * (long long)F);
+                            }
                         }
                     }
                   } else if (t == -12345) oc[lane] = cur_[0].x + cur_[9].y + prv_[0].x;
@@ -1739,10 +1783,11 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     const int SF = fplan->host->n_sections, SE = eplan->host->n_sections;
     HD_REQUIRE(SF > 0 && SE > 0, "plan has no coefficients");
     // shapes the kernel is built for: frames that are register windows of a 2048-sample tile
-    const bool shape_ok = (nfft == 2048 && (hop == 1024 || hop == 512)) || (nfft == 1024 && (hop == 512 || hop == 256));
+    const bool shape_ok = (nfft == 2048 && (hop == 1024 || hop == 512)) || (nfft == 1024 && (hop == 512 || hop == 256)) ||
+                          (nfft == 512 && hop == 256);
     if (!shape_ok || SF > 4 || SE > 2 || frames < 4 * TILE ||
         fplan->host->warm >= (1LL << 40) || eplan->host->warm >= (1LL << 40)) {
-        hipdsp_set_error("the fused forward sweep covers nfft/hop 2048/1024, 2048/512, 1024/512 and 1024/256, a band-pass of "
+        hipdsp_set_error("the fused forward sweep covers nfft/hop 2048/1024, 2048/512, 1024/512, 1024/256 and 512/256, a band-pass of "
                          "at most four and an envelope of at most two sections that decay, and traces of at least %d "
                          "frames: use hipdsp_sosfilt_envelope + hipdsp_spectrogram", 4 * TILE);
         return HIPDSP_ERR_UNSUPPORTED;
@@ -1856,8 +1901,10 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
         HD_CHAIN_ALL(2048, 512)
     } else if (nfft == 1024 && hop == 512) {
         HD_CHAIN_ALL(1024, 512)
-    } else {
+    } else if (nfft == 1024 && hop == 256) {
         HD_CHAIN_ALL(1024, 256)
+    } else {
+        HD_CHAIN_ALL(512, 256)
     }
 #undef HD_CHAIN_FULL
 #undef HD_CHAIN_LONG
