@@ -1023,10 +1023,13 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             }
             STAMP_AT(0);                                       // wait for H2 of the last tile, tile -> LDS, fetch issued
             // Phase 1 of the envelope cascade rides on phase 3 of the band-pass: every filtered sample is
-            // rectified and multiplied into the envelope's G table while it is still a register (the same
-            // float32 values, in the same order, as a pass over the tile in LDS would see), so that a quiet
-            // tile needs neither that pass nor its conversions.  Tiles that are not quiet (odd extension
-            // in reach, envelope warm-up not begun) ignore the result and take the path through LDS.
+            // multiplied into the envelope's G table while it is still a register -- |y| as a source modifier of
+            // the float64 multiply-add, the gain once per tile on the sums -- so that a quiet tile needs neither a
+            // pass over the tile in LDS nor a conversion or a multiplication per sample.  (The value is the
+            // band-pass output BEFORE its rounding to float32: the tile states then belong to inputs that differ
+            // from what the backward sweep recomputes from by 6e-8 relative, i.e. by less than the float32
+            // rounding of the filtered trace itself.)  Tiles that are not quiet (odd extension in reach,
+            // envelope warm-up not begun) ignore the result and take the path through LDS.
             double etap[DE];
 #pragma unroll
             for (int r = 0; r < DE; r++) etap[r] = 0.0;
@@ -1039,10 +1042,10 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
 #define CASC_IN(v) (v)
 #define CASC_ROLLED_GROUPS
 #define CASC_STAMP(n) STAMP_AT(1 + (n))
-#define CASC_TAP(j, e)                                                                  \
+#define CASC_TAP(j, e, y)                                                               \
     do {                                                                                \
         if (((j) & 3) == 0) PEt = PLAN_OF(PE0);                                         \
-        const double rd_ = (double)(tgain * fabsf(e));                                  \
+        const double rd_ = fabs(y);                                                      \
         _Pragma("unroll") for (int r_ = 0; r_ < DE; r_++) etap[r_] = fma(PEt->G[(j) * DE + r_], rd_, etap[r_]); \
     } while (0)
 #include "sos_cascade.inc"
@@ -1053,6 +1056,8 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
 #undef CASC_PLAN
 #undef CASC_CARRY
 #undef CASC_IN
+#pragma unroll
+                for (int r = 0; r < DE; r++) etap[r] *= (double)tgain;
             }
             WAVE_SYNC();
             if (FLAGS) { if (active) CHAIN_POST(ready, it + 1); }
