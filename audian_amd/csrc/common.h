@@ -25,6 +25,7 @@ struct hipdsp_ctx {
     int spec_no_half;      // experiments/tests: do not reuse the overlapped half frame
     int spec_fpw, spec_kernel;   // experiments (tools/), 0 = defaults
     int chain_debug;       // experiments: ablation bits of the fused forward kernel
+    int chain_split_frames; // hipdsp_chain_forward writes only the even frames (hipdsp_chain_backward the odd ones)
     int chain_reserve_cus; // CUs hipdsp_chain_forward leaves without a workgroup (room for a co-resident RCCL kernel)
     int sos_no_pin;        // experiments: scalar table loads left to hipcc's just-in-time placement (A/B of CASC_PIN_GROUPS)
     struct hd_pool *pool;  // stream-ordered cache of freed device blocks (ctx.hip)

@@ -95,6 +95,7 @@ int hipdsp_ctx_create(int device, void *stream, hipdsp_ctx **out)
     ctx->chain_debug = 0;
     ctx->sos_no_pin = 0;
     ctx->chain_reserve_cus = 0;
+    ctx->chain_split_frames = 0;
     ctx->sos_waves_per_cu = 0;
     ctx->spec_no_half = 0;
     ctx->pool = new hd_pool();
@@ -184,6 +185,7 @@ int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value)
     if (strcmp(name, "spec_kernel") == 0) { ctx->spec_kernel = (int)value; return HIPDSP_OK; }
     if (strcmp(name, "chain_debug") == 0) { ctx->chain_debug = (int)value; return HIPDSP_OK; }
     if (strcmp(name, "sos_no_pin") == 0) { ctx->sos_no_pin = value != 0; return HIPDSP_OK; }
+    if (strcmp(name, "chain_split_frames") == 0) { ctx->chain_split_frames = value != 0; return HIPDSP_OK; }
     if (strcmp(name, "chain_reserve_cus") == 0) {
         HD_REQUIRE(value >= 0 && value < ctx->n_cus, "chain_reserve_cus %lld not in [0, %d)", value, ctx->n_cus);
         ctx->chain_reserve_cus = (int)value;

@@ -325,6 +325,15 @@ def chain_forward(ctx, fplan, eplan, x, x_pitch, yf, yf_pitch, channels, frames,
                                    int(frames_out), int(psd_pitch)))
 
 
+def chain_backward(ctx, eplan, yf, yf_pitch, env, env_pitch, channels, frames, nfft, hop, fs, psd, frames_out,
+                   psd_pitch=0, rectify=True, gain=np.pi/2, clamp=True):
+    """Envelope backward sweep + the odd spectrogram frames (after chain_forward with the context option
+    "chain_split_frames"; hipdsp_chain_backward)."""
+    check(lib.hipdsp_chain_backward(ctx.handle, eplan.handle, _p(yf), int(yf_pitch), _p(env), int(env_pitch),
+                                    int(channels), int(frames), int(bool(rectify)), float(gain), int(bool(clamp)),
+                                    int(nfft), int(hop), float(fs), _p(psd), int(frames_out), int(psd_pitch)))
+
+
 def chain_plan(ctx, fplan, eplan, channels, frames):
     """(segment_frames, n_segments) of chain_forward for this shape (hipdsp_chain_plan)."""
     seg, n = ctypes.c_int64(), ctypes.c_int()

@@ -65,6 +65,7 @@ int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
  *   "sos_waves_per_cu"   resident waves per CU the IIR segment planner aims for (16)
  *   "pool_limit_mb"      bytes (MiB) hipdsp_free may keep cached for hipdsp_malloc (1024)
  *   "sos_prefetch"       0: envelope sweeps without the register prefetch of the next tile (1)
+ *   "chain_split_frames" non-zero: hipdsp_chain_forward (2048/1024, no db_out) leaves the odd frames to hipdsp_chain_backward
  *   "chain_reserve_cus"  CUs hipdsp_chain_forward plans no workgroup for (0): its 1024-thread workgroups want a
  *                        whole CU each, so a kernel that stays resident next to it (RCCL's all-gather in the
  *                        multi-GPU step) needs CUs of its own or a second round of workgroups forms
@@ -277,6 +278,21 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan,
                          int64_t yf_pitch, int64_t channels, int64_t frames, int rectify,
                          double gain, int nfft, int hop, double fs, float *psd, float *db_out,
                          int64_t frames_out, int64_t psd_pitch);
+
+/* Frame split of the batch chain (nfft 2048 / hop 1024): with the context option "chain_split_frames" set,
+ * hipdsp_chain_forward writes only the EVEN frames 2t of psd (frame 2t is tile t of its sweep) and this call,
+ * which replaces hipdsp_sosfilt_envelope(..., phase = 2) behind it, writes the envelope
+ * (BufferedEnvelope.process, bufferedenvelope.py:34-41: the backward half of sosfiltfilt from the tile states
+ * the forward sweep parked in the context scratch) AND the ODD frames 2t+1 (second half of tile t, first half
+ * of tile t+1) of BufferedSpectrogram.process (bufferedspectrogram.py:45-59) -- both launches then carry one
+ * FFT per tile instead of two in the forward sweep (which is bound by VALU issue) and none in the backward
+ * sweep (which is not), and move 10 bytes per sample each.  Same psd / frames_out / psd_pitch as the
+ * forward call; together the two calls write every frame below n_valid, the forward call the zero tail.
+ * Covers envelope plans of one or two decaying sections; HIPDSP_ERR_UNSUPPORTED otherwise. */
+int hipdsp_chain_backward(hipdsp_ctx *ctx, const hipdsp_sosplan *eplan, const float *yf, int64_t yf_pitch,
+                          float *env, int64_t env_pitch, int64_t channels, int64_t frames, int rectify,
+                          double gain, int clamp, int nfft, int hop, double fs, float *psd,
+                          int64_t frames_out, int64_t psd_pitch);
 
 /* The time segmentation hipdsp_chain_forward uses for `channels` x `frames` with these plans
  * (one IIR wave per channel and segment): segment s covers frames [s * segment_frames,

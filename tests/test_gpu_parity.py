@@ -693,3 +693,69 @@ def test_chain_forward_other_windows_and_longer_bandpasses(oracle, T, max_segmen
                         assert rel_err(gs[ch, j], ss[ch, j]) < 1e-5, (T, max_segments, j, ch)
     finally:
         c.set_max_segments(0)
+
+
+@pytest.mark.parametrize('T,max_segments', [(8192, 0), (20481, 0), (70001, 0), (300000, 0), (300000, 3), (1500000, 0),
+                                            (1500000, 1)])
+def test_chain_frame_split_forward_and_backward(oracle, T, max_segments):
+    """Frame split of the batch chain ("chain_split_frames"): hipdsp_chain_forward writes the even frames,
+    hipdsp_chain_backward the envelope AND the odd frames (second half of tile t + first half of tile t+1, walked
+    backwards).  Together they must equal the unsplit pair of calls bit for bit in the filtered trace, to
+    float32 rounding in envelope and PSD, and the oracle within 1e-4; every frame below n_valid written exactly
+    once (the PSD is pre-filled with a guard pattern), zero tail, one and many segments, traces that end
+    inside a tile."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rate, C, nfft, hop = 96000.0, 3, 2048, 1024
+    rng = np.random.default_rng(T + max_segments)
+    x = (synth(rng, T, C, rate) + np.float32(0.05)).astype(np.float32)
+    c = gh.ctx()
+    c.set_max_segments(max_segments)
+    try:
+        dx = gh.to_planar(c, x)
+        nd = (T + hop - 1)//hop
+        F = nfft//2 + 1
+        for band, order, env, eorder in (((300.0, 3000.0), 2, 20.0, 2), ((1000.0, 20000.0), 1, 500.0, 4),
+                                         ((300.0, 3000.0), 4, 100.0, 2)):
+            sos = butter_sos(order, band, 'bandpass', rate)
+            esos = butter_sos(eorder, env, 'lowpass', rate)
+            fplan, eplan = hipdsp.SosPlan(c, sos), hipdsp.SosPlan(c, esos)
+            yf = hipdsp.DeviceArray(c, (C, T), np.float32)
+            ye = hipdsp.DeviceArray(c, (C, T), np.float32)
+            ps = hipdsp.DeviceArray(c, (C, nd + 1, F), np.float32)
+            hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(ps), 0x7f, 4*C*(nd + 1)*F)
+            c.set_option('chain_split_frames', 1)
+            hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, nfft, hop, rate, ps, nd + 1)
+            guard = np.frombuffer(b'\x7f\x7f\x7f\x7f', dtype=np.float32)[0]
+            half = ps.to_host()
+            n_valid = (min(nd*hop + nfft, T) - (nfft - hop))//hop if T >= nfft else 0
+            for j in range(n_valid):
+                assert np.all(half[:, j] == guard) == (j % 2 == 1), (T, j)      # odd frames still untouched
+            hipdsp.chain_backward(c, eplan, yf, T, ye, T, C, T, nfft, hop, rate, ps, nd + 1)
+            c.set_option('chain_split_frames', 0)
+            f1 = hipdsp.DeviceArray(c, (C, T), np.float32)
+            e1 = hipdsp.DeviceArray(c, (C, T), np.float32)
+            s1 = hipdsp.DeviceArray(c, (C, nd + 1, F), np.float32)
+            hipdsp.chain_forward(c, fplan, eplan, dx, T, f1, T, C, T, nfft, hop, rate, s1, nd + 1)
+            hipdsp.sosfilt_envelope(c, fplan, eplan, dx, T, f1, T, e1, T, C, T, phase=2)
+            gf, ge, gs = yf.to_host(), ye.to_host(), ps.to_host()
+            sf, se, ss = f1.to_host(), e1.to_host(), s1.to_host()
+            assert np.array_equal(gf, sf)
+            want_e = np.zeros((T, C))
+            oracle.envelope_process(esos, sf.T.astype(np.float64), want_e, 0)
+            want_s = np.zeros((nd + 1, C, F))
+            oracle.spectrogram_process(sf.T.astype(np.float64), want_s, rate, nfft, hop)
+            for ch in range(C):
+                assert rel_err(ge[ch], se[ch]) < 2e-6, (T, env, ch)
+                assert rel_err(ge[ch], want_e[:, ch]) < TOL
+                for j in range(nd + 1):
+                    if np.max(np.abs(want_s[j, ch])) == 0:
+                        assert np.all(gs[ch, j] == 0), (T, j, ch)
+                    else:
+                        assert rel_err(gs[ch, j], want_s[j, ch]) < TOL, (T, max_segments, j, ch)
+                        assert rel_err(gs[ch, j], ss[ch, j]) < 1e-5, (T, max_segments, j, ch)
+        with pytest.raises(NotImplementedError):
+            hipdsp.chain_backward(c, eplan, yf, T, ye, T, C, T, 1024, 512, rate, ps, nd)
+    finally:
+        c.set_max_segments(0)
+        c.set_option('chain_split_frames', 0)

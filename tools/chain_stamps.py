@@ -23,6 +23,7 @@ blocks = (C*nseg + 7)//8
 stamps = hipdsp.DeviceArray(ctx, (blocks*16, 16), np.int64)
 stamps.zero_()
 ctx.set_option('chain_debug', 32)
+ctx.set_option('chain_split_frames', int(os.environ.get('SPLIT', '0')))
 for _ in range(3):
     hipdsp.chain_forward(ctx, fplan, eplan, dx, T, df, T, C, T, nfft, hop, rate, ds, nd, db_out=stamps)
 ctx.synchronize()
