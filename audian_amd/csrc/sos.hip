@@ -2353,6 +2353,25 @@ int hipdsp_chain_backward(hipdsp_ctx *ctx, const hipdsp_sosplan *eplan, const fl
     return hd_launch_status("chain_bwd_kernel");
 }
 
+int hipdsp_chain_backward_plan(hipdsp_ctx *ctx, const hipdsp_sosplan *eplan, int64_t channels, int64_t frames,
+                               int64_t *first_border, int64_t *segment_frames, int *n_segments)
+{
+    HD_REQUIRE(ctx != nullptr && eplan != nullptr, "NULL argument");
+    HD_REQUIRE(first_border != nullptr && segment_frames != nullptr && n_segments != nullptr, "NULL output");
+    HD_REQUIRE(channels >= 1 && frames >= 1, "bad size");
+    HD_REQUIRE(eplan->host->n_sections > 0, "plan has no coefficients");
+    const long long n_tiles = (frames + eplan->host->edge + TILE - 1) / TILE;
+    long long len = 0;
+    int n = 0;
+    plan_segments_for((long long)(ctx->n_cus - ctx->chain_reserve_cus) * 8, ctx->max_segments, n_tiles * TILE, channels,
+                      eplan->host->warm, &len, &n);
+    // segment s (walked from the END of the trace) covers frames [n_tiles*TILE - (s+1)*len, n_tiles*TILE - s*len)
+    *first_border = n_tiles * TILE - len;
+    *segment_frames = len;
+    *n_segments = n;
+    return HIPDSP_OK;
+}
+
 int hipdsp_chain_plan(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hipdsp_sosplan *eplan,
                       int64_t channels, int64_t frames, int64_t *segment_frames, int *n_segments)
 {

@@ -334,6 +334,15 @@ def chain_backward(ctx, eplan, yf, yf_pitch, env, env_pitch, channels, frames, n
                                     int(nfft), int(hop), float(fs), _p(psd), int(frames_out), int(psd_pitch)))
 
 
+def chain_backward_plan(ctx, eplan, channels, frames):
+    """(first_border, segment_frames, n_segments) of chain_backward: its internal borders are
+    first_border - s*segment_frames, s = 0 ... n_segments - 2 (hipdsp_chain_backward_plan)."""
+    fb, seg, n = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+    check(lib.hipdsp_chain_backward_plan(ctx.handle, eplan.handle, int(channels), int(frames), ctypes.byref(fb),
+                                         ctypes.byref(seg), ctypes.byref(n)))
+    return int(fb.value), int(seg.value), int(n.value)
+
+
 def chain_plan(ctx, fplan, eplan, channels, frames):
     """(segment_frames, n_segments) of chain_forward for this shape (hipdsp_chain_plan)."""
     seg, n = ctypes.c_int64(), ctypes.c_int()

@@ -301,6 +301,11 @@ int hipdsp_chain_backward(hipdsp_ctx *ctx, const hipdsp_sosplan *eplan, const fl
 int hipdsp_chain_plan(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hipdsp_sosplan *eplan,
                       int64_t channels, int64_t frames, int64_t *segment_frames, int *n_segments);
 
+/* The same for hipdsp_chain_backward, whose segments are counted from the END of the trace: segment s covers
+ * frames [first_border - s * segment_frames, first_border - (s - 1) * segment_frames), s = 0 the last one. */
+int hipdsp_chain_backward_plan(hipdsp_ctx *ctx, const hipdsp_sosplan *eplan, int64_t channels, int64_t frames,
+                               int64_t *first_border, int64_t *segment_frames, int *n_segments);
+
 /* BufferedSpectrogram.process (bufferedspectrogram.py:45-59) ==
  * scipy.signal.spectrogram(x, fs, 'hann', nperseg=nfft, noverlap=nfft-hop,
  * detrend='constant', scaling='density', mode='psd'):

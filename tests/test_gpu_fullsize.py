@@ -35,7 +35,7 @@ def base():
     dx.free()
 
 
-@pytest.fixture(scope='module', params=['separate', 'fused'])
+@pytest.fixture(scope='module', params=['separate', 'fused', 'fused-split'])
 def chain(request, base):
     from audian_amd import hipdsp
     ctx, dx, plan, eplan = base['ctx'], base['dx'], base['plan'], base['eplan']
@@ -46,12 +46,23 @@ def chain(request, base):
         hipdsp.sosfilt(ctx, plan, dx, T, df, T, C, T, 0)
         hipdsp.spectrogram(ctx, df, T, C, T, NFFT, HOP, RATE, ds, ND)
         hipdsp.envelope(ctx, eplan, df, T, de, T, C, T, 0)
-    else:
+    elif request.param == 'fused':
         # exactly bench.py's step: fused forward sweep, then the envelope's backward sweep
         hipdsp.chain_forward(ctx, plan, eplan, dx, T, df, T, C, T, NFFT, HOP, RATE, ds, ND,
                              rectify=True, gain=np.pi/2)
         hipdsp.sosfilt_envelope(ctx, plan, eplan, dx, T, df, T, de, T, C, T, rectify=True,
                                 gain=np.pi/2, clamp=True, phase=2)
+    else:
+        # the frame split: even frames from the forward, odd frames + envelope from the backward sweep
+        hipdsp.lib.hipdsp_memset(ctx.handle, hipdsp._p(ds), 0x7f, 4*C*ND*F)      # every frame must be written
+        ctx.set_option('chain_split_frames', 1)
+        try:
+            hipdsp.chain_forward(ctx, plan, eplan, dx, T, df, T, C, T, NFFT, HOP, RATE, ds, ND,
+                                 rectify=True, gain=np.pi/2)
+            hipdsp.chain_backward(ctx, eplan, df, T, de, T, C, T, NFFT, HOP, RATE, ds, ND,
+                                  rectify=True, gain=np.pi/2, clamp=True)
+        finally:
+            ctx.set_option('chain_split_frames', 0)
     ctx.synchronize()
     yield dict(base, df=df, de=de, ds=ds, path=request.param)
     for a in (df, de, ds):
@@ -163,7 +174,7 @@ def test_fused_segment_borders(chain, oracle):
     its first half from that unit's own warm-up.  Check, at EVERY internal border b of the plan, on a
     different channel each time: the filtered trace and the envelope across b, and the three frames
     that end at, straddle and start at b."""
-    if chain['path'] != 'fused':
+    if chain['path'] == 'separate':
         pytest.skip('borders of the fused plan')
     from audian_amd import hipdsp
     seg, nseg = hipdsp.chain_plan(chain['ctx'], chain['plan'], chain['eplan'], C, T)
@@ -186,6 +197,27 @@ def test_fused_segment_borders(chain, oracle):
             wpsd = np.zeros((1, 1, F))
             oracle.spectrogram_process(segx[:, None], wpsd, RATE, NFFT, HOP)
             assert rel_err(row, wpsd[0, 0]) < 1e-4, (s_, ch, k)
+    if chain['path'] == 'fused-split':
+        # the backward sweep of the frame split has borders of its own (counted from the end of the trace): the
+        # envelope across each, and the odd frame whose second half comes from the unit's own warm-up tile
+        fb, bseg, bn = hipdsp.chain_backward_plan(chain['ctx'], chain['eplan'], C, T)
+        assert bn >= 2 and bseg % NFFT == 0
+        for s_ in range(bn - 1):
+            b = fb - s_*bseg
+            if b + half + lead_e > T or b - half - lead_e < 0:
+                continue
+            ch = (11*s_ + 5) % C
+            f = window(chain['df'], ch, b - half - lead_e, 2*half + 2*lead_e)[:, None]
+            wenv = np.zeros_like(f)
+            oracle.envelope_process(chain['esos'], f, wenv, 0)
+            assert rel_err(window(chain['de'], ch, b - half, 2*half), wenv[lead_e:lead_e + 2*half, 0]) < 1e-4, (s_, ch)
+            k0 = b//HOP
+            for k in (k0 - 3, k0 - 2, k0 - 1, k0, k0 + 1):
+                segx = window(chain['df'], ch, k*HOP, NFFT)
+                row = chain['ds'].view((ch*ND + k)*F, (F,)).to_host().astype(np.float64)
+                wpsd = np.zeros((1, 1, F))
+                oracle.spectrogram_process(segx[:, None], wpsd, RATE, NFFT, HOP)
+                assert rel_err(row, wpsd[0, 0]) < 1e-4, (s_, ch, k)
     # the last unit of the last channel (highest addresses of every array)
     ch = C - 1
     b = (nseg - 1)*seg
