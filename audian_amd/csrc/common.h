@@ -27,6 +27,8 @@ struct hipdsp_ctx {
     int chain_debug;       // experiments: ablation bits of the fused forward kernel
     int chain_split_frames; // hipdsp_chain_forward writes only the even frames (hipdsp_chain_backward the odd ones)
     int chain_reserve_cus; // CUs hipdsp_chain_forward leaves without a workgroup (room for a co-resident RCCL kernel)
+    long long *sos_trace;  // diagnostics: device buffer (3 int64 per wave) the envelope's backward sweep reports into
+    int sos_fair;          // rotating issue priorities in the single-wave sweeps (sos.hip: rotate_issue_priority)
     int sos_no_pin;        // experiments: scalar table loads left to hipcc's just-in-time placement (A/B of CASC_PIN_GROUPS)
     struct hd_pool *pool;  // stream-ordered cache of freed device blocks (ctx.hip)
     // Device-side fault report: four ints in pinned host memory that kernels can write

@@ -94,6 +94,8 @@ int hipdsp_ctx_create(int device, void *stream, hipdsp_ctx **out)
     ctx->spec_fpw = ctx->spec_kernel = 0;
     ctx->chain_debug = 0;
     ctx->sos_no_pin = 0;
+    ctx->sos_trace = nullptr;
+    ctx->sos_fair = 0;
     ctx->chain_reserve_cus = 0;
     ctx->chain_split_frames = 0;
     ctx->sos_waves_per_cu = 0;
@@ -185,6 +187,8 @@ int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value)
     if (strcmp(name, "spec_kernel") == 0) { ctx->spec_kernel = (int)value; return HIPDSP_OK; }
     if (strcmp(name, "chain_debug") == 0) { ctx->chain_debug = (int)value; return HIPDSP_OK; }
     if (strcmp(name, "sos_no_pin") == 0) { ctx->sos_no_pin = value != 0; return HIPDSP_OK; }
+    if (strcmp(name, "sos_fair") == 0) { ctx->sos_fair = value != 0; return HIPDSP_OK; }
+    if (strcmp(name, "sos_trace") == 0) { ctx->sos_trace = reinterpret_cast<long long *>((uintptr_t)value); return HIPDSP_OK; }
     if (strcmp(name, "chain_split_frames") == 0) { ctx->chain_split_frames = value != 0; return HIPDSP_OK; }
     if (strcmp(name, "chain_reserve_cus") == 0) {
         HD_REQUIRE(value >= 0 && value < ctx->n_cus, "chain_reserve_cus %lld not in [0, %d)", value, ctx->n_cus);

@@ -437,6 +437,40 @@ __global__ __launch_bounds__(64) void sos_ckpt_kernel(const SosPlanDev *__restri
     }
 }
 
+// Fair shares of a SIMD for persistent waves that do not talk to each other.  The issue arbiters serve the
+// OLDEST wave first: of four waves of one SIMD that walk equal segments, the one in slot 0 gets whatever it
+// asks for and ends after 55 % of the launch, the one in slot 3 after 95 % (tools/sweep_trace.py), and the
+// tail with a quarter of the waves cannot keep the HBM pipes full.  Called once per tile, this gives the
+// four slots four DIFFERENT priorities that rotate with the shader clock (the same clock for all waves of
+// the SIMD, so the priorities stay distinct): every wave spends a quarter of the time at each level.
+__device__ __forceinline__ void rotate_issue_priority(unsigned slot)
+{
+    const unsigned p = (slot + (unsigned)(__builtin_readcyclecounter() >> 14)) & 3u;
+    if (p == 0) __builtin_amdgcn_s_setprio(0);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+// gain * |x| and max(x, 0) as single instructions (results as gain * fabsf(x) and fmaxf(x, 0.f))
+__device__ __forceinline__ float gain_abs(float gain, float x)
+{
+    float r;
+    asm("v_mul_f32_e64 %0, %1, |%2|" : "=v"(r) : "s"(gain), "v"(x));
+    return r;
+}
+__device__ __forceinline__ float max_zero(float x)
+{
+    float r;
+    asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ unsigned wave_slot_of_simd()
+{
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hw));
+    return hw;
+}
+
 struct BwdArgs {
     const float *in;         // the trace the envelope is taken of (before rectification)
     float *out;
@@ -447,11 +481,24 @@ struct BwdArgs {
     long long seg_tiles, warm_tiles;
     int n_seg, edge, rectify, clamp;
     float gain;
+    long long *trace;        // option "sos_trace": 9 words per wave (start, end in 100 MHz ticks, HW_ID, 6 clock sums)
+    int fair;                // rotate_issue_priority() per tile (option "sos_fair", default off: no gain measured)
 };
 
-template <int SE, bool PREFETCH, bool PIN = true>
+template <int SE, bool PREFETCH, bool PIN = true, bool TRACE = false>
 __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restrict__ P0, BwdArgs a)
 {
+    // TRACE (diagnostic build, option "sos_trace"): shader clocks per part of an iteration, summed per wave
+    long long tr_acc[6] = {0, 0, 0, 0, 0, 0};
+    long long tr_last = TRACE ? clock64() : 0;
+#define TRACE_AT(i)                                              \
+    do {                                                         \
+        if (TRACE) {                                             \
+            const long long t_ = clock64();                      \
+            tr_acc[(i)] += t_ - tr_last;                         \
+            tr_last = t_;                                        \
+        }                                                        \
+    } while (0)
     constexpr int DE = 2 * SE;
     __shared__ float4 lds[64 * 8];
     float *ldsf = reinterpret_cast<float *>(lds);
@@ -463,6 +510,8 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
     const double *ckpt = a.ckpt + ch * a.ckpt_pitch;
     const long long T = a.T;
     const int edge = a.edge;
+    const long long trace_t0 = a.trace ? wall_clock64() : 0;
+    const unsigned slot = wave_slot_of_simd();
 
     // reversed tile index rt = n_tiles-1 - (p / TILE): the wave owns rt in [rt_lo, rt_hi)
     const long long rt_lo = (long long)seg * a.seg_tiles;
@@ -507,18 +556,28 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
         const long long tidx = a.n_tiles - 1 - rt;
         const long long tile = tidx * TILE;
         if (tile + TILE <= a.skip) break;          // nothing below `skip` is kept
+        if (a.fair) rotate_issue_priority(slot);
         double cfw_[DE];
         // ---- trace tile -> LDS, rectified
         if (PREFETCH && pre) {
             // (the wait for this tile's prefetch sits at the end of the previous iteration, behind
             // the stores it is counted against)
+            // (one wave-uniform branch around the eight, and gain * |x| as ONE double-rate multiply with a source
+            // modifier: left to itself hipcc emits and + packed multiply + select per sample, 2.5 x the issue time)
+            if (a.rectify) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                asm volatile("" : "+v"(nx[k]));
-                float4 v = make_float4(nx[k].x, nx[k].y, nx[k].z, nx[k].w);
-                if (a.rectify)
-                    v = make_float4(a.gain * fabsf(v.x), a.gain * fabsf(v.y), a.gain * fabsf(v.z), a.gain * fabsf(v.w));
-                lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = v;
+                for (int k = 0; k < 8; k++) {
+                    asm volatile("" : "+v"(nx[k]));
+                    lds[lds_slot(8 * k + (lane >> 3), lane & 7)] =
+                        make_float4(gain_abs(a.gain, nx[k].x), gain_abs(a.gain, nx[k].y), gain_abs(a.gain, nx[k].z),
+                                    gain_abs(a.gain, nx[k].w));
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    asm volatile("" : "+v"(nx[k]));
+                    lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = make_float4(nx[k].x, nx[k].y, nx[k].z, nx[k].w);
+                }
             }
 #pragma unroll
             for (int i = 0; i < SE; i++) {
@@ -596,10 +655,12 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
             __syncthreads();
         }
         if (PREFETCH) __syncthreads();
+        TRACE_AT(0);                               // tile from the prefetch registers into LDS
         if (PREFETCH) {
             pre = rt + 1 < rt_hi && prefetchable(tidx - 1);
             fetch(pre ? tidx - 1 : top_full);
         }
+        TRACE_AT(1);                               // prefetch of the next tile issued
         // ---- forward cascade again, from the state that entered this tile
 #define CASC_S SE
 #define CASC_PLAN() PLAN_OF(P0)
@@ -609,6 +670,7 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
 #include "sos_cascade.inc"
 #undef CASC_CARRY
         __syncthreads();
+        TRACE_AT(2);                               // forward cascade
         if (rt == 0) {
             // scipy: backward pass starts from zi * y_fwd[-1]; pad the rest of the tile with it
             const int last = (int)(T + edge - 1 - tile);
@@ -631,18 +693,27 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
 #undef CASC_CARRY
 #undef CASC_IN
         __syncthreads();
+        TRACE_AT(3);                               // backward cascade
         if (rt >= rt_lo) {
             if (tile >= a.skip && tile + TILE <= T) {
-                // interior tile: exactly 8 vector stores
+                // interior tile: exactly 8 vector stores (max(x, 0) as one instruction: fmaxf() costs a second one
+                // that only quiets signalling NaNs)
+                if (a.clamp) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    float4 v = lds[lds_slot(8 * k + (lane >> 3), lane & 7)];
-                    if (a.clamp) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    for (int k = 0; k < 8; k++) {
+                        const float4 v = lds[lds_slot(8 * k + (lane >> 3), lane & 7)];
+                        f4u t; t.x = max_zero(v.x); t.y = max_zero(v.y); t.z = max_zero(v.z); t.w = max_zero(v.w);
+                        *reinterpret_cast<f4u *>(out + (tile + 256 * k + 4 * lane - a.skip)) = t;
                     }
-                    f4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
-                    *reinterpret_cast<f4u *>(out + (tile + 256 * k + 4 * lane - a.skip)) = t;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const float4 v = lds[lds_slot(8 * k + (lane >> 3), lane & 7)];
+                        f4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+                        *reinterpret_cast<f4u *>(out + (tile + 256 * k + 4 * lane - a.skip)) = t;
+                    }
                 }
+                TRACE_AT(4);                       // 8 stores issued
                 // the prefetch issued above is older than these 8 stores: all but 7 operations done
                 // means every load has landed (one less than 8, so a merged store could not make
                 // the wait too weak; tools/check_prefetch_isa.py re-checks the ISA)
@@ -662,6 +733,18 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // warm-up tile: no stores to count
         }
         __syncthreads();
+        TRACE_AT(5);                               // wait for the prefetch
+    }
+#undef TRACE_AT
+    if (a.trace && lane == 0) {                       // tools/sweep_trace.py: do the waves of a SIMD progress alike?
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        long long *tr = a.trace + 9 * (long long)blockIdx.x;
+        tr[0] = trace_t0;
+        tr[1] = wall_clock64();
+        tr[2] = hw;
+#pragma unroll
+        for (int i = 0; i < 6; i++) tr[3 + i] = tr_acc[i];
     }
 }
 
@@ -765,10 +848,12 @@ struct ChainArgs {
 // frames side by side in a wave, LPF 32, 8 x 8 x 4) from its PPL = NFFT / (2 LPF) values per lane (value t: samples
 // 2l + 2 LPF t, + 1 of the frame) -> detrend, Hann, half-length complex FFT, split step, PSD.  `keep` masks the
 // stores of a lane group whose frame does not exist.  Same arithmetic as spec_fast_kernel<NFFT, LPF, R1, R2, R3, ...>.
-template <int NFFT, int LPF, int R1, int R2, int R3, bool DB>
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+
+template <int NFFT, int LPF, int R1, int R2, int R3, bool DB, class Hook = NoHook>
 __device__ __forceinline__ void psd_frame(const v2f *w, float2 *fb, const float2 *tw2, const float2 *tw3,
                                           const float2 *twn, const float2 *win, int lane, float scale, bool keep,
-                                          float *__restrict__ o, float *__restrict__ od)
+                                          float *__restrict__ o, float *__restrict__ od, Hook hook = Hook())
 {
     constexpr int M = NFFT / 2, PPL = M / LPF;
     static_assert(PPL == R1 && R1 * R2 * R3 == M, "one first-stage butterfly per lane");
@@ -791,9 +876,13 @@ __device__ __forceinline__ void psd_frame(const v2f *w, float2 *fb, const float2
     const v2f mean2 = {mean, mean};
 #pragma unroll
     for (int t = 0; t < R1; t++) v[t] = as_f2((as_v2f(v[t]) - mean2) * as_v2f(win[l + LPF * t]));
+    hook(0);                                   // mean and window
     stockham_stage<R1, 1, M, LPF, false, true>(v, fb, tw2, l);
+    hook(1);                                   // first butterflies, values on their way through LDS
     stockham_stage<R2, R1, M, LPF, true, true>(v, fb, tw2, l);
+    hook(2);
     stockham_stage<R3, R1 * R2, M, LPF, true, false, true>(v, fb, tw3, l);
+    hook(3);
     // v[u*R3 + t] = Z[k], k = l + LPF*m, m = u + NB3*t; partner bin Z[M-k] from lane LPF-l of the same group
     constexpr int NB3 = PPL / R3;
     const int partner = g0 + ((LPF - l) & (LPF - 1));
@@ -872,11 +961,29 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
     // FLAGS: pairwise hand-over instead of the two workgroup barriers -- ready[p] counts the tiles IIR
     // wave p has finished, taken[p] the tiles FFT wave p has copied (monotonic, one writer each)
     __shared__ int ready[NP], taken[NP];
+    // Fair shares of a SIMD: the issue arbiter prefers the waves of the lower slots, so that without help
+    // pairs 0 .. NP/2-1 finish their units after 78 % of the launch and the other half then runs alone,
+    // latency-bound, on a half-empty CU (tools/chain_stamps.py: wave lifetimes 14.8 M against 19.0 M clocks).
+    // Every wave publishes the iteration it is in and compares it with the wave of the same role of pair
+    // p ^ NP/2 -- the one it shares its SIMD with: whoever is ahead steps down one priority level until the
+    // other has caught up ("chain_debug" bit 128 = off).
+    __shared__ int prog[2 * NP];
     if (threadIdx.x < NP) { ready[threadIdx.x] = 0; taken[threadIdx.x] = 0; }
+    if (threadIdx.x < 2 * NP) prog[threadIdx.x] = 0;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int pair = wave < NP ? wave : wave - NP;
+#define CHAIN_FAIR(iter, behind_prio, ahead_prio)                                                        \
+    do {                                                                                                 \
+        if (FLAGS && !(a.debug & 128)) {                                                                 \
+            if (lane == 0) __hip_atomic_store(&prog[wave], (iter), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+            const int other_ = __builtin_amdgcn_readfirstlane(                                           \
+                __hip_atomic_load(&prog[wave ^ (NP / 2)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); \
+            if (other_ < (iter)) __builtin_amdgcn_s_setprio(ahead_prio);                                 \
+            else __builtin_amdgcn_s_setprio(behind_prio);                                                \
+        }                                                                                                \
+    } while (0)
     // Bounded polling: a logic error must not hang the GPU.  After 2^23 naps (a third of a second, far
     // beyond anything a partner wave of the same workgroup can be late by) the wave GIVES UP: it
     // reports the fault through the context's fault word (the host turns it into HIPDSP_ERR_HIP at the
@@ -986,6 +1093,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
         for (int it = 0; it < a.n_iter; it++) {
             const long long tile = base + (long long)it * TILE;
             const bool active = tile >= start && tile < loop_end;
+            if (!(a.debug & 64)) CHAIN_FAIR(it, 1, 0);
             if (FLAGS && pending) {                            // H2 of the previous (quiet) tile
                 CHAIN_WAIT_FOR(taken, pending, it);
                 pending = 0;
@@ -1221,6 +1329,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
         for (int it = 0; it < a.n_iter; it++) {
             const long long tile = base + (long long)it * TILE;
             const bool active = tile >= start && tile < loop_end;
+            if (!(a.debug & 64)) CHAIN_FAIR(it, 3, 2);
             if (FLAGS) { if (active) CHAIN_WAIT_FOR(ready, it + 1, it); }
             else __syncthreads();                              // B1
             STAMP_AT(8);                                       // waited for the IIR wave's tile
@@ -1251,8 +1360,16 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                                 v2f w[PPL];
 #pragma unroll
                                 for (int i = 0; i < PPL; i++) w[i] = reg(j0 + i);
-                                psd_frame<NFFT, LPF, R1, R2, R3, DB>(w, fb, tw2, tw3, twn, win, lane, a.scale, true,
-                                                                     oc + f * (long long)F, dc + f * (long long)F);
+                                if (STAMP) {
+                                    STAMP_AT(10);                  // (between the frames)
+                                    auto hook = [&](int n) { STAMP_AT(11 + n); };
+                                    psd_frame<NFFT, LPF, R1, R2, R3, DB>(w, fb, tw2, tw3, twn, win, lane, a.scale, true,
+                                                                         oc + f * (long long)F, dc + f * (long long)F, hook);
+                                    STAMP_AT(15);                  // split step, PSD, stores
+                                } else {
+                                    psd_frame<NFFT, LPF, R1, R2, R3, DB>(w, fb, tw2, tw3, twn, win, lane, a.scale, true,
+                                                                         oc + f * (long long)F, dc + f * (long long)F);
+                                }
                             }
                         } else {
                             // two frames side by side: lanes 0-31 take frame m, lanes 32-63 frame m + 1 (HOP / 128 registers
@@ -1577,6 +1694,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_bwd_kernel(const SosPl
 
 #undef CHAIN_WAIT_FOR
 #undef CHAIN_POST
+#undef CHAIN_FAIR
 
 __global__ void zero_rows_kernel(float *__restrict__ y, long long y_pitch, long long n, float value)
 {
@@ -1852,6 +1970,8 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
     b.ckpt = (const double *)work; b.ckpt_pitch = ckpt_pitch;
     b.T = frames; b.skip = skip; b.n_tiles = n_tiles; b.edge = edge;
     b.rectify = rectify; b.clamp = clamp; b.gain = (float)gain;
+    b.trace = ctx->sos_trace;
+    b.fair = ctx->sos_fair;
     const long long used_tiles = n_tiles - skip / TILE;      // tiles below `skip` are never visited
     long long seg_len = 0;
     plan_segments(ctx, used_tiles * TILE, channels, warmE, &seg_len, &b.n_seg);
@@ -1863,7 +1983,8 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
     switch (SE) {
     case 1:
         if (ctx->sos_prefetch && frames >= 4 * TILE) {
-            if (ctx->sos_no_pin) hipLaunchKernelGGL((env_bwd_kernel<1, true, false>), grid, block, 0, ctx->stream, edev, b);
+            if (ctx->sos_trace) hipLaunchKernelGGL((env_bwd_kernel<1, true, true, true>), grid, block, 0, ctx->stream, edev, b);
+            else if (ctx->sos_no_pin) hipLaunchKernelGGL((env_bwd_kernel<1, true, false>), grid, block, 0, ctx->stream, edev, b);
             else hipLaunchKernelGGL((env_bwd_kernel<1, true>), grid, block, 0, ctx->stream, edev, b);
         } else hipLaunchKernelGGL((env_bwd_kernel<1, false>), grid, block, 0, ctx->stream, edev, b);
         break;

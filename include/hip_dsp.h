@@ -70,6 +70,9 @@ int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
  *                        whole CU each, so a kernel that stays resident next to it (RCCL's all-gather in the
  *                        multi-GPU step) needs CUs of its own or a second round of workgroups forms
  *   "sos_no_pin"         non-zero: plan tables fetched by just-in-time scalar loads (A/B, tools/pin_ab.py)
+ *   "sos_trace"          diagnostics: device address (0 = off) of 9 int64 per wave of the envelope's backward sweep --
+ *                        start and end of the wave in 100 MHz ticks, its HW_ID, 6 clock sums (tools/sweep_trace.py)
+ *   "sos_fair"           0: the single-wave sweeps without rotating issue priorities (A/B)
  *   "force_generic_fft"  non-zero: every nfft takes the generic radix-2 / four-step kernels
  *   "spec_kernel"        0 = default per size, 2 = two-stage, 3 = three-stage FFT kernel
  *   "spec_fpw"           consecutive frames per wave (0 = automatic)

@@ -17,8 +17,9 @@
 // MODE 0 copy, 1 read, 2 write.  tile = TK KB per wave and step.
 template <int MODE, int TK>
 __global__ __launch_bounds__(64) void sweep(const float4 *__restrict__ in, float4 *__restrict__ out, long long n4,
-                                            int streams, int waves_per_stream)
+                                            int streams, int waves_per_stream, long long *ends = nullptr)
 {
+    const long long w0 = ends ? wall_clock64() : 0;
     const int lane = threadIdx.x;
     const int w = blockIdx.x;
     const int s = w / waves_per_stream, j = w % waves_per_stream;
@@ -56,6 +57,13 @@ __global__ __launch_bounds__(64) void sweep(const float4 *__restrict__ in, float
         }
     }
     if (acc == 12345.678f) out[0].x = acc;
+    if (ends && threadIdx.x == 0) {                 // when did this wave start and end (100 MHz ticks), and where did it run
+        ends[3 * blockIdx.x] = w0;
+        ends[3 * blockIdx.x + 1] = wall_clock64();
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        ends[3 * blockIdx.x + 2] = hw;
+    }
 }
 
 template <typename F> float timeit(F f, int reps)
@@ -98,6 +106,30 @@ int main()
         const double gb = (double)(n4 / streams / 128 * 128) * streams * 16 / 1e9;
         float c = timeit([&] { hipLaunchKernelGGL((sweep<0, 2>), dim3(W), dim3(64), 0, 0, in, out, n4, streams, wps); }, 5);
         printf("streams %5d (2 KB tiles): copy %.3f ms %5.0f GB/s\n", streams, c, 2 * gb / c * 1e3);
+    }
+    {   // do the 4096 waves of the sweeps' pattern end together?  (a tail with few waves left cannot fill the HBM pipes)
+        long long *ends; CK(hipMalloc(&ends, W * 24));
+        hipLaunchKernelGGL((sweep<0, 8>), dim3(W), dim3(64), 0, 0, in, out, n4, W, 1, ends);
+        hipLaunchKernelGGL((sweep<0, 8>), dim3(W), dim3(64), 0, 0, in, out, n4, W, 1, ends);
+        CK(hipDeviceSynchronize());
+        std::vector<long long> h(3 * W);
+        CK(hipMemcpy(h.data(), ends, W * 24, hipMemcpyDeviceToHost));
+        long long t0 = h[0];
+        for (int i = 0; i < W; i++) t0 = std::min(t0, h[3 * i]);
+        std::vector<double> e(W);
+        double slot_sum[16] = {0}; int slot_n[16] = {0};
+        for (int i = 0; i < W; i++) {
+            e[i] = (h[3 * i + 1] - t0) * 1e-5;       // ms
+            const int slot = (int)(h[3 * i + 2] & 15); // wave slot within the SIMD
+            slot_sum[slot] += e[i]; slot_n[slot]++;
+        }
+        std::vector<double> sorted = e;
+        std::sort(sorted.begin(), sorted.end());
+        printf("copy, 4096 streams: waves end at min %.3f  10%% %.3f  median %.3f  90%% %.3f  max %.3f ms\n", sorted[0], sorted[W / 10],
+               sorted[W / 2], sorted[W * 9 / 10], sorted[W - 1]);
+        printf("mean end by wave slot of the SIMD:");
+        for (int k = 0; k < 16; k++) if (slot_n[k]) printf("  %d: %.3f (%d)", k, slot_sum[k] / slot_n[k], slot_n[k]);
+        printf("\n");
     }
     for (int wv : {8192, 2048}) {
         const double gb = (double)(n4 / wv / 512 * 512) * wv * 16 / 1e9;
