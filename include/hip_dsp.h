@@ -83,7 +83,8 @@ int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
  *                        8 = one FFT wave withholds one hand-over (test of the fault report below);
  *                        16 = clock counters of one wave into the first 16 bytes of the PSD;
  *                        32 = diagnostic build: db_out receives 16 clock sums per wave (tools/chain_stamps.py);
- *                        64 = FFT waves without their raised issue priority
+ *                        64 = no issue priorities at all; 128 (results unchanged) = FFT waves above IIR waves
+ *                        only, without the progress words that keep the waves of a SIMD in step
  * Device-side faults: the waits between the waves of hipdsp_chain_forward's kernel are bounded; a wave
  * whose wait runs out writes a fault word owned by the context and ends the launch early.
  * hipdsp_ctx_synchronize, hipdsp_memcpy_d2h, hipdsp_event_elapsed_ms and the next
