@@ -8,6 +8,7 @@
 #include <cmath>
 #include <type_traits>
 
+#pragma clang fp contract(fast)
 namespace {
 
 constexpr float DB_MIN_POWER = 1e-20f;      // thunderlab decibel default min_power
@@ -318,3 +319,4 @@ template <> __device__ __forceinline__ void dft<32>(float2 *v)
 
 
 }  // namespace
+#pragma clang fp contract(off)

@@ -862,6 +862,7 @@ __device__ __forceinline__ void psd_frame(const v2f *w, float2 *fb, const float2
                                           const float2 *twn, const float2 *win, int lane, float scale, bool keep,
                                           float *__restrict__ o, float *__restrict__ od, Hook hook = Hook())
 {
+#pragma clang fp contract(fast)
     constexpr int M = NFFT / 2, PPL = M / LPF;
     static_assert(PPL == R1 && R1 * R2 * R3 == M, "one first-stage butterfly per lane");
     const int l = lane % LPF, g0 = (lane / LPF) * LPF;
