@@ -23,6 +23,7 @@ any gather and with each of the three tile sizes (`legs`: compute_ms / gather_ms
 """
 
 import argparse
+import ctypes
 import json
 import math
 import os
@@ -626,6 +627,31 @@ def main():
     if fuse3:
         stage_gbps = round((12.0*C*T + 4.0*C*nd*F + ckpt_bytes)/(ms[names[0]]*1e-3)/1e9, 1)
 
+    # the engine clock the fused sweep actually runs at (shader clocks against the 100 MHz wall clock of one wave
+    # that lives through the launch, "chain_debug" bit 16): the chip's power cap, not HBM, sets this kernel's time
+    engine_mhz = None
+    if fuse3 and rank == 0:
+        try:
+            if main_gather is not None:
+                main_gather.drain()
+            ctx.set_option('chain_debug', 16)
+            hipdsp.chain_forward(ctx, plan, eplan, dx, T, df, T, C, T, args.nfft, args.hop, args.rate, ds, nd,
+                                 rectify=True, gain=np.pi/2)
+            ctx.synchronize()
+            words = np.zeros(2, dtype=np.int64)
+            hipdsp.check(hipdsp.lib.hipdsp_memcpy_d2h(ctx.handle, words.ctypes.data_as(ctypes.c_void_p),
+                                                      ctypes.c_void_p(ds.ptr), 16))
+            if words[1] > 0:
+                engine_mhz = round(float(words[0])/float(words[1])*100.0, 0)
+        except Exception:
+            engine_mhz = None
+        finally:
+            ctx.set_option('chain_debug', 0)
+            # (the 16 bytes are the first PSD values of channel 0: the launch below writes them again)
+            hipdsp.chain_forward(ctx, plan, eplan, dx, T, df, T, C, T, args.nfft, args.hop, args.rate, ds, nd,
+                                 rectify=True, gain=np.pi/2)
+            ctx.synchronize()
+
     # N > 1: the same K steps again without any gather and with each tile size, gathers alone as well
     legs = None
     if multi:
@@ -712,7 +738,8 @@ def main():
                          'frac': round(achieved/HBM_PEAK_GBS, 4), 'traffic': traffic,
                          'algorithmic_bytes': alg_bytes[dom],
                          'device_copy_GBps': round(copy_gbps, 1),
-                         'per_stage_accounting_GBps': stage_gbps},
+                         'per_stage_accounting_GBps': stage_gbps,
+                         'engine_clock_MHz_in_kernel': engine_mhz},
             'kernels': kernels,
             'chain_algorithmic_GBps': round(sum(alg_bytes.values())/(dt/args.steps)/1e9, 1),
             'parity_max_rel_err': parity,

@@ -73,6 +73,7 @@ def test_one_json_line_with_the_contract_keys():
     assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0
     assert d['parity_max_rel_err'] < 1e-4 and 'invalid' not in d
     assert d['roofline']['kernel'].startswith('chain_fwd')      # N = 1 default: the fused forward sweep
+    assert 500 < r['engine_clock_MHz_in_kernel'] < 2600         # measured inside the kernel, live
 
 
 @pytest.mark.gpu
