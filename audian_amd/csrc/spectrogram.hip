@@ -1143,6 +1143,14 @@ extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pit
     if (nsource >= nfft) n_valid = (nsource - (nfft - hop)) / hop;
     if (n_valid > frames_out) n_valid = frames_out;
     if (n_valid > 0) HD_REQUIRE(x != nullptr && x_pitch >= frames, "bad input");
+    if (n_valid == 0) {
+        // a slab shorter than one window (bufferedspectrogram.py:47-49: dest[:] = 0): nothing may read x -- the
+        // framed kernels request frame 0 before they look at the frame count (found by tools/fuzz_stress.py as a
+        // memory fault when the slab ended at the end of a mapping)
+        hipLaunchKernelGGL(big_zero_tail_kernel, dim3(256, (unsigned)channels), dim3(256), 0, ctx->stream, out, db_out,
+                           (long long)out_pitch, (long long)(nfft / 2 + 1), 0LL, (long long)frames_out);
+        return hd_launch_status("big_zero_tail_kernel");
+    }
     double wss = 0.0;
     for (int i = 0; i < nfft; i++) {
         double w = 0.5 - 0.5 * cos(2.0 * M_PI * (double)i / (double)nfft);

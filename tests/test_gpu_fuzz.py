@@ -311,3 +311,89 @@ def test_random_chain_forward_cases(oracle, seed):
     finally:
         c.set_max_segments(0)
         c.set_option('chain_debug', 0)
+
+
+@pytest.mark.parametrize('seed', range(20))
+def test_random_chain_shapes_sections_and_modes(oracle, seed):
+    """The round-2 generalisations of the fused sweep under random draws: every window shape the kernel is built
+    for, band-passes of 1-4 sections, envelopes of 1-2 sections, dB epilogue (2048/1024), frame split with the
+    role-split backward sweep (2048/1024), barrier / flag hand-over and every priority mode, random lengths around
+    tile multiples, pitches, channel counts and segmentations.  Filtered trace and envelope against the oracle, the
+    PSD against the oracle's spectrogram of the SAME filtered trace and against the separate kernel."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rng = np.random.default_rng(91000 + seed)
+    rate = float(rng.choice([44100.0, 48000.0, 96000.0, 192000.0]))
+    nfft, hop = [(2048, 1024), (2048, 512), (1024, 512), (1024, 256), (512, 256)][int(rng.integers(0, 5))]
+    F = nfft//2 + 1
+    T = int(rng.integers(4, 40))*TILE + int(rng.integers(-TILE + 1, TILE)) if rng.integers(0, 3) else \
+        int(rng.integers(4*TILE, 6*TILE))
+    T = max(T, 4*TILE)
+    C = int(rng.integers(1, 6))
+    lo = float(rng.uniform(50.0, 0.05*rate))
+    sos = butter_sos(int(rng.integers(1, 5)), (lo, float(rng.uniform(2*lo, 0.4*rate))), 'bandpass', rate)
+    esos = butter_sos(int(rng.integers(1, 5)), float(rng.uniform(5.0, 2000.0)), 'lowpass', rate)
+    xp, fp = T + int(rng.integers(0, 9)), T + int(rng.integers(0, 9))
+    nd = (T + hop - 1)//hop + int(rng.integers(-3, 4))
+    pp = (nd + int(rng.integers(0, 3)))*F
+    want_db = (nfft, hop) == (2048, 1024) and rng.integers(0, 3) == 0
+    split = (nfft, hop) == (2048, 1024) and not want_db and rng.integers(0, 3) == 0
+    x = (rng.standard_normal((C, T))*rng.uniform(0.1, 3.0) + rng.uniform(-0.5, 0.5)).astype(np.float32)
+    c = gh.ctx()
+    c.set_max_segments(int(rng.choice([0, 0, 1, 2, 5])))
+    dbg = int(rng.choice([0, 0, 4, 64, 128]))
+    if dbg == 4 and ((nfft, hop) != (2048, 1024) or len(sos) > 2):
+        dbg = 0                      # (the barrier variant is built for the first shape and two sections only)
+    c.set_option('chain_debug', dbg)
+    c.set_option('chain_split_frames', int(split))
+    try:
+        host = np.zeros((C, xp), dtype=np.float32)
+        host[:, :T] = x
+        dx = hipdsp.DeviceArray(c, (C, xp), np.float32)
+        hipdsp.lib.hipdsp_memcpy_h2d(c.handle, hipdsp._p(dx), host.ctypes.data, host.nbytes)
+        yf = hipdsp.DeviceArray(c, (C, fp), np.float32)
+        ye = hipdsp.DeviceArray(c, (C, T), np.float32)
+        ps = hipdsp.DeviceArray(c, (C*pp,), np.float32)
+        hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(ps), 0x7f, 4*C*pp)
+        db = hipdsp.DeviceArray(c, (C*pp,), np.float32) if want_db else None
+        fplan, eplan = hipdsp.SosPlan(c, sos), hipdsp.SosPlan(c, esos)
+        hipdsp.chain_forward(c, fplan, eplan, dx, xp, yf, fp, C, T, nfft, hop, rate, ps, nd, psd_pitch=pp, db_out=db)
+        if split:
+            hipdsp.chain_backward(c, eplan, yf, fp, ye, T, C, T, nfft, hop, rate, ps, nd, psd_pitch=pp)
+        else:
+            hipdsp.sosfilt_envelope(c, fplan, eplan, dx, xp, yf, fp, ye, T, C, T, phase=2)
+        c.set_option('chain_split_frames', 0)
+        s1 = hipdsp.DeviceArray(c, (C*pp,), np.float32)
+        hipdsp.spectrogram(c, yf, fp, C, T, nfft, hop, rate, s1, nd, out_pitch=pp)
+        gf = yf.to_host()[:, :T]
+        ge = ye.to_host()
+        gs = ps.to_host().reshape(C, pp)[:, :nd*F].reshape(C, nd, F)
+        ss = s1.to_host().reshape(C, pp)[:, :nd*F].reshape(C, nd, F)
+        guard = np.frombuffer(b'\x7f\x7f\x7f\x7f', dtype=np.float32)[0]
+        assert np.all(ps.to_host().reshape(C, pp)[:, nd*F:] == guard)
+        want_f = oracle.sosfilt(sos, x.T.astype(np.float64))
+        want_e = np.zeros_like(want_f)
+        oracle.envelope_process(esos, gf.T.astype(np.float64), want_e, 0)
+        want_s = np.zeros((nd, C, F))
+        oracle.spectrogram_process(gf.T.astype(np.float64), want_s, rate, nfft, hop)
+        what = (seed, nfft, hop, len(sos), len(esos), T, C, bool(want_db), bool(split))
+        for ch in range(C):
+            assert rel_err(gf[ch], want_f[:, ch]) < TOL, what + (ch,)
+            assert rel_err(ge[ch], want_e[:, ch]) < TOL, what + (ch,)
+            for j in range(nd):
+                peak = np.max(np.abs(want_s[j, ch]))
+                if peak == 0:
+                    assert np.all(gs[ch, j] == 0), what + (j, ch)
+                else:
+                    assert np.max(np.abs(gs[ch, j] - want_s[j, ch]))/peak < TOL, what + (j, ch)
+                    assert np.max(np.abs(gs[ch, j] - ss[ch, j]))/peak < 1e-5, what + (j, ch)
+        if want_db:
+            gdb = db.to_host().reshape(C, pp)[:, :nd*F].reshape(C, nd, F)
+            wdb = oracle.decibel(gs)
+            fin = np.isfinite(wdb)
+            assert np.array_equal(np.isfinite(gdb), fin), what
+            assert np.max(np.abs(gdb[fin] - wdb[fin])) < 1e-3, what
+    finally:
+        c.set_max_segments(0)
+        c.set_option('chain_debug', 0)
+        c.set_option('chain_split_frames', 0)

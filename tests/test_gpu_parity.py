@@ -759,3 +759,23 @@ def test_chain_frame_split_forward_and_backward(oracle, T, max_segments):
     finally:
         c.set_max_segments(0)
         c.set_option('chain_split_frames', 0)
+
+
+@pytest.mark.parametrize('nfft', [8, 64, 256, 512, 1024, 2048, 4096, 8192, 65536, 300])
+def test_spectrogram_of_a_slab_shorter_than_one_window(nfft):
+    """bufferedspectrogram.py:47-49: fewer source samples than one window -> the whole destination is zero (dB:
+    -inf), for every kernel family, and NOTHING may read the slab (tools/fuzz_stress.py found the three-stage
+    kernel requesting frame 0 before looking at the frame count: a memory fault when the slab ended at the end
+    of a mapping).  The source pointer is the library's smallest allocation here."""
+    from audian_amd import hipdsp
+    c = gh.ctx()
+    C, nd, F = 3, 5, nfft//2 + 1
+    for T in (0, 1, nfft//2 + 1, nfft - 1):
+        dx = hipdsp.DeviceArray(c, (C, max(T, 1)), np.float32)
+        dx.zero_()
+        out = hipdsp.DeviceArray(c, (C, nd, F), np.float32)
+        db = hipdsp.DeviceArray(c, (C, nd, F), np.float32)
+        hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(out), 0x7f, 4*C*nd*F)
+        hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(db), 0x7f, 4*C*nd*F)
+        hipdsp.spectrogram(c, dx, max(T, 1), C, T, nfft, max(nfft//4, 1), 48000.0, out, nd, db_out=db)
+        assert np.all(out.to_host() == 0) and np.all(db.to_host() == -np.inf), (nfft, T)

@@ -1,0 +1,40 @@
+"""More seeds of the seeded random GPU tests (tests/test_gpu_fuzz.py) than the suite runs: every test function of
+that module that takes (oracle, seed), seeds 1000 .. 1000 + N, time-boxed; needs an MI355X.
+    python tools/fuzz_stress.py [N=400] [minutes=8] [first seed=1000]
+"""
+import sys, os, time, inspect
+ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+os.chdir(ROOT)
+from oracle import oracle
+import test_gpu_fuzz as t
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+budget = 60.0*float(sys.argv[2]) if len(sys.argv) > 2 else 480.0
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+# every case is announced in a file BEFORE it runs (a kernel fault kills the process: the last line names the case)
+os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+progress = open(os.path.join(ROOT, 'gpurun_out', 'fuzz_progress.log'), 'w')
+tests = [(n, f) for n, f in inspect.getmembers(t, inspect.isfunction)
+         if n.startswith('test_random') and list(inspect.signature(f).parameters) == ['oracle', 'seed']]
+t0 = time.time()
+bad, done = 0, {n: 0 for n, _ in tests}
+for seed in range(first, first + N):
+    for name, f in tests:
+        if time.time() - t0 > budget:
+            break
+        progress.write(f'{name} {seed}\n'); progress.flush(); os.fsync(progress.fileno())
+        try:
+            f(oracle, seed)
+        except AssertionError as e:
+            bad += 1
+            print('FAIL', name, seed, str(e)[:300], flush=True)
+        except Exception as e:
+            bad += 1
+            print('ERROR', name, seed, type(e).__name__, str(e)[:300], flush=True)
+        done[name] += 1
+    if time.time() - t0 > budget:
+        break
+    if seed % 25 == 0:
+        print('seed', seed, 'elapsed %.0f s' % (time.time() - t0), flush=True)
+print('cases per test:', done)
+print('done, failures:', bad)
