@@ -14,6 +14,7 @@ first = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 # every case is announced in a file BEFORE it runs (a kernel fault kills the process: the last line names the case)
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 progress = open(os.path.join(ROOT, 'gpurun_out', 'fuzz_progress.log'), 'w')
+failures = open(os.path.join(ROOT, 'gpurun_out', 'fuzz_failures.log'), 'w')
 tests = [(n, f) for n, f in inspect.getmembers(t, inspect.isfunction)
          if n.startswith('test_random') and list(inspect.signature(f).parameters) == ['oracle', 'seed']]
 t0 = time.time()
@@ -28,9 +29,11 @@ for seed in range(first, first + N):
         except AssertionError as e:
             bad += 1
             print('FAIL', name, seed, str(e)[:300], flush=True)
+            failures.write(f'FAIL {name} {seed} {str(e)[:300]}\n'); failures.flush()
         except Exception as e:
             bad += 1
             print('ERROR', name, seed, type(e).__name__, str(e)[:300], flush=True)
+            failures.write(f'ERROR {name} {seed} {type(e).__name__} {str(e)[:300]}\n'); failures.flush()
         done[name] += 1
     if time.time() - t0 > budget:
         break
