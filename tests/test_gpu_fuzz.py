@@ -407,3 +407,153 @@ def test_random_chain_shapes_sections_and_modes(oracle, seed):
         c.set_max_segments(0)
         c.set_option('chain_debug', 0)
         c.set_option('chain_split_frames', 0)
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_random_envelope_multi_cases(oracle, seed):
+    """hipdsp_envelope_multi under random orders (1-12), cut-offs, splits of the cascade over plans, lengths around
+    tile multiples and the pad length, nbefore, pitches and channel counts."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rng = np.random.default_rng(31000 + seed)
+    rate = float(rng.choice([8000.0, 48000.0, 96000.0]))
+    if rng.integers(0, 2):
+        ehp = float(rng.uniform(1.0, 0.01*rate))
+        sos = butter_sos(int(rng.integers(1, 7)), (ehp, float(rng.uniform(4*ehp, 0.4*rate))), 'bandpass', rate)
+    else:
+        ehp = 0.0
+        sos = butter_sos(int(rng.integers(1, 13)), float(rng.uniform(0.002*rate, 0.4*rate)), 'lowpass', rate)
+    split, left = [], len(sos)
+    while left > 0:
+        n = int(rng.integers(1, min(4, left) + 1))
+        split.append(n); left -= n
+    edge = oracle.sosfiltfilt_edge(sos)
+    T = draw_length(rng, lo=1)
+    C = int(rng.integers(1, 5))
+    skip = int(rng.choice([0, 0, 1, rng.integers(0, T + 1)]))
+    x = (rng.standard_normal((T, C))*rng.uniform(0.1, 3.0)).astype(np.float32)
+    c = gh.ctx()
+    dx = gh.to_planar(c, x)
+    plans, i = [], 0
+    for n in split:
+        plans.append(hipdsp.SosPlan(c, sos[i:i + n]))
+        i += n
+    po = max(T - skip, 1) + int(rng.integers(0, 5))
+    dy = hipdsp.DeviceArray(c, (C, po), np.float32)
+    hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(dy), 0x7f, 4*C*po)
+    what = (seed, T, len(sos), tuple(split), skip)
+    if T <= edge:
+        with pytest.raises(ValueError, match='padlen'):
+            hipdsp.envelope_multi(c, plans, dx, T, dy, po, C, T, skip, clamp=ehp == 0)
+        return
+    hipdsp.envelope_multi(c, plans, dx, T, dy, po, C, T, skip, clamp=ehp == 0)
+    got = dy.to_host()
+    want = np.zeros((T - skip, C))
+    oracle.envelope_process(sos, x.astype(np.float64), want, skip, highpass_cutoff=ehp)
+    full = np.zeros((T, C))
+    oracle.envelope_process(sos, x.astype(np.float64), full, 0, highpass_cutoff=ehp)
+    for ch in range(C):
+        if T - skip > 0:
+            err = np.max(np.abs(got[ch, :T - skip] - want[:, ch]))
+            assert err <= TOL*max(np.max(np.abs(full[:, ch])), 1e-30) + \
+                4*np.finfo(np.float32).eps*(np.pi/2)*np.max(np.abs(x[:, ch])), what + (ch,)
+        assert np.all(got[ch, max(T - skip, 0):].view(np.uint32) == 0x7f7f7f7f), what + ('wrote past the row',)
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_random_unwrap_cases(oracle, seed):
+    """hipdsp_unwrap against the restated algorithm, bit for bit: random lengths around the 16384-sample chunks,
+    wrap counts from none to many per chunk, thresholds, clipping and down-scaling, pitches."""
+    from audian_amd import hipdsp
+    rng = np.random.default_rng(32000 + seed)
+    T = int(rng.choice([1, 2, int(rng.integers(3, 400)), 16384 + int(rng.integers(-3, 4)),
+                        int(rng.integers(1, 9))*16384 + int(rng.integers(-50, 51)), int(rng.integers(1000, 300000))]))
+    C = int(rng.integers(1, 5))
+    t = np.arange(T)
+    amp = float(rng.uniform(0.5, 6.0))
+    true = np.stack([amp*np.sin(2*np.pi*float(rng.uniform(1e-5, 2e-3))*t + float(rng.uniform(0, 6.28))*(ch > 0)) +
+                     float(rng.uniform(0, 0.2))*rng.standard_normal(T) for ch in range(C)], axis=1)
+    wrapped = ((true + 1.0) % 2.0 - 1.0).astype(np.float32)
+    px, py = T + int(rng.integers(0, 5)), T + int(rng.integers(0, 5))
+    host = np.zeros((C, px), dtype=np.float32)
+    host[:, :T] = wrapped.T
+    c = gh.ctx()
+    dx = hipdsp.DeviceArray(c, (C, px), np.float32)
+    hipdsp.lib.hipdsp_memcpy_h2d(c.handle, hipdsp._p(dx), host.ctypes.data, host.nbytes)
+    thresh = float(rng.choice([0.5, 1.0, 1.5, 1.9]))
+    clips, down = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    dy = hipdsp.DeviceArray(c, (C, py), np.float32)
+    hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(dy), 0x7f, 4*C*py)
+    hipdsp.unwrap(c, dx, px, C, T, thresh, dy, py, clips=clips, down_scale=down)
+    got = dy.to_host()
+    want = oracle.unwrap(wrapped, thresh, clips=clips, down_scale=down)
+    assert np.array_equal(got[:, :T].T, want), (seed, T, thresh, clips, down)
+    assert np.all(got[:, T:].view(np.uint32) == 0x7f7f7f7f), (seed, 'wrote past the row')
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_random_screen_reductions(oracle, seed):
+    """The SURVEY 8f rows under random shapes: min/max decimation of traces (bit-exact), decimated dB image and
+    mean spectrum of a spectrogram slab, band order statistics (bit-exact), PCM ingest (bit-exact)."""
+    from audian_amd import hipdsp
+    rng = np.random.default_rng(33000 + seed)
+    c = gh.ctx()
+    # min/max decimation
+    T, C = int(rng.integers(1, 200000)), int(rng.integers(1, 5))
+    x = rng.standard_normal((T, C)).astype(np.float32)
+    dx = gh.to_planar(c, x)
+    for _ in range(3):
+        start = int(rng.integers(0, T))
+        stop = int(rng.integers(start + 1, T + 1))
+        step = int(rng.choice([1, 2, 3, int(rng.integers(1, 5000)), stop - start]))
+        nseg = (stop - start + step - 1)//step
+        out = hipdsp.DeviceArray(c, (C, 2*nseg + 3), np.float32)
+        hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(out), 0x7f, 4*C*(2*nseg + 3))
+        hipdsp.minmax_decimate(c, dx, T, C, start, stop, step, out, 2*nseg + 3)
+        got = out.to_host()
+        want = oracle.minmax_decimate(x.astype(np.float64), start, stop, step)
+        assert np.array_equal(got[:, :2*nseg].astype(np.float64), want.T), (seed, T, start, stop, step)
+        assert np.all(got[:, 2*nseg:].view(np.uint32) == 0x7f7f7f7f), (seed, 'wrote past the row')
+    # spectrogram slab: decimated dB image, mean spectrum, band order statistics
+    frames, F = int(rng.integers(1, 3000)), int(rng.choice([5, 33, 129, 513, 1025, 2049]))
+    spec = (10.0**rng.uniform(-24, 2, size=(frames, F))).astype(np.float32)
+    spec[rng.random((frames, F)) < 0.02] = 0.0
+    ds = hipdsp.DeviceArray.from_host(c, spec)
+    start = int(rng.integers(0, frames))
+    stop = int(rng.integers(start + 1, frames + 1))
+    step = int(rng.choice([1, 2, int(rng.integers(1, 200)), stop - start]))
+    ncols = (stop - start + step - 1)//step
+    img = hipdsp.DeviceArray(c, (F, ncols), np.float32)
+    hipdsp.decibel_image_decimate(c, ds, img, frames, F, start, stop, step)
+    got = img.to_host()
+    want = oracle.decimated_db_image(spec[:, None, :], start, stop, step, 0)
+    fin = np.isfinite(want)
+    assert got.shape == want.shape and np.array_equal(np.isfinite(got), fin), (seed, frames, F, start, stop, step)
+    if fin.any():
+        assert np.max(np.abs(got[fin] - want[fin])) < 1e-4, (seed, frames, F)
+    out = hipdsp.DeviceArray(c, (F,), np.float32)
+    hipdsp.mean_spectrum_db(c, ds, F, start, stop, out)
+    assert np.max(np.abs(out.to_host().astype(np.float64) - oracle.mean_power_db(spec[:, None, :], start, stop, 0))) < 1e-3
+    cols = int(rng.integers(1, F + 1))
+    band = spec[:, F - cols:]
+    srt = np.sort(band.ravel())
+    n = frames*cols
+    o2 = hipdsp.DeviceArray(c, (2,), np.float32)
+    for rank in sorted({0, int(np.floor(0.95*(n - 1))), int(rng.integers(0, n)), n - 1}):
+        hipdsp.band_order_stats(c, ds.view(F - cols, (1,)), frames, cols, F, rank, o2)
+        g2 = o2.to_host()
+        assert g2[0] == srt[rank] and g2[1] == srt[min(rank + 1, n - 1)], (seed, frames, cols, rank)
+    # PCM ingest
+    nbytes = int(rng.choice([2, 3, 4]))
+    Tp, Cp = int(rng.integers(1, 50000)), int(rng.integers(1, 7))
+    raw = rng.integers(0, 256, size=(Tp, Cp, nbytes), dtype=np.uint8)
+    ints = np.zeros((Tp, Cp), dtype=np.int64)
+    for b in range(nbytes):
+        ints |= raw[:, :, b].astype(np.int64) << (8*b)
+    ints = np.where(ints >= 1 << (8*nbytes - 1), ints - (1 << 8*nbytes), ints)
+    scale = 1.0/float(1 << (8*nbytes - 1))
+    up = hipdsp.DeviceArray.from_host(c, raw.reshape(-1))
+    pitch = Tp + int(rng.integers(0, 4))
+    dst = hipdsp.DeviceArray(c, (Cp, pitch), np.float32)
+    hipdsp.pcm_unpack(c, up, nbytes, Tp, Cp, scale, dst, pitch)
+    assert np.array_equal(dst.to_host()[:, :Tp], (ints.T.astype(np.float64)*scale).astype(np.float32)), (seed, nbytes)
