@@ -541,3 +541,64 @@ def test_envelope_of_any_order_through_the_facade(oracle):
             want = full[:len(got)]
         for c in range(C):
             assert rel_err(got[:, c], want[:, c]) < TOL, (order, c)
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_random_walks_match_the_oracle_twins(oracle, seed):
+    """A random walk through what the GUI can do to the chain -- scroll anywhere (small steps that recycle the
+    overlap, jumps, the ends of the recording), change the filter cut-offs, the envelope parameters, the
+    spectrogram resolution, read parts of buffers in between -- device-backed traces against twins that keep
+    the same bookkeeping and compute with the oracle, compared after every action."""
+    from audian_amd.bufferedfilter import BufferedFilter
+    from audian_amd.bufferedenvelope import BufferedEnvelope
+    from audian_amd.bufferedspectrogram import BufferedSpectrogram
+    rng = np.random.default_rng(77000 + seed)
+    rate = float(rng.choice([8000.0, 16000.0, 22050.0]))
+    seconds = float(rng.uniform(12.0, 40.0))
+    channels = int(rng.integers(1, 4))
+    x = recording(rate, seconds, channels, seed=seed)
+    buffer_time, back_time = float(rng.uniform(2.0, 6.0)), float(rng.uniform(0.0, 1.5))
+    nfft = int(rng.choice([64, 256, 512, 1024]))
+    g = build((BufferedFilter, BufferedEnvelope, BufferedSpectrogram), x, rate, buffer_time, back_time, nfft=nfft)
+    o = build(oracle_twins(oracle), x, rate, buffer_time, back_time, nfft=nfft)
+    t0 = 0.0
+    for step in range(14):
+        action = int(rng.integers(0, 8))
+        if action <= 2:                                     # scroll a little
+            t0 = float(np.clip(t0 + rng.uniform(-1.5, 1.5), 0.0, seconds - 0.5))
+        elif action == 3:                                   # jump
+            t0 = float(rng.choice([0.0, seconds - 1.0, rng.uniform(0.0, seconds - 1.0)]))
+        elif action == 4:                                   # filter cut-offs (incl. the pass-through and one-sided designs)
+            hp = float(rng.choice([0.0, rng.uniform(20.0, 0.2*rate)]))
+            lp = float(rng.choice([rate/2, rng.uniform(max(2*hp, 200.0), 0.45*rate)]))
+            for twin in (g, o):
+                twin['filtered'].highpass_cutoff = hp
+                twin['filtered'].lowpass_cutoff = lp
+                twin['filtered'].update()
+        elif action == 5:                                   # envelope parameters
+            cut = float(rng.uniform(5.0, 0.1*rate))
+            ehp = float(rng.choice([0.0, 0.0, rng.uniform(0.5, cut/3)]))
+            order = int(rng.integers(1, 7))
+            for twin in (g, o):
+                twin['envelope'].envelope_cutoff = cut
+                twin['envelope'].highpass_cutoff = ehp
+                twin['envelope'].filter_order = order
+                twin['envelope'].update()
+        elif action == 6:                                   # spectrogram resolution
+            nf = int(rng.choice([64, 128, 256, 512, 1024, 2048]))
+            ov = float(rng.choice([0.0, 0.5, 0.75, 0.9]))
+            for twin in (g, o):
+                twin['spectrogram'].update(nfft=nf, overlap_frac=ov)
+        else:                                               # partial reads (host copy current there, stale elsewhere)
+            f, sp = g['filtered'], g['spectrogram']
+            if len(f.buffer) > 10:
+                a = int(rng.integers(0, len(f.buffer) - 5))
+                assert np.all(np.isfinite(f.buffer[a:a + 5, 0]))
+            if len(sp.buffer) > 2:
+                assert np.all(np.isfinite(sp.buffer[int(rng.integers(0, len(sp.buffer))), 0]))
+        t1 = min(t0 + float(rng.uniform(0.3, buffer_time*0.6)), seconds)
+        g.update_times(t0, t1)
+        o.update_times(t0, t1)
+        if step % 2 == 1 or action >= 4:
+            compare(g, o)
+    compare(g, o)

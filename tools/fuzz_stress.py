@@ -1,13 +1,15 @@
 """More seeds of the seeded random GPU tests (tests/test_gpu_fuzz.py) than the suite runs: every test function of
 that module that takes (oracle, seed), seeds 1000 .. 1000 + N, time-boxed; needs an MI355X.
     python tools/fuzz_stress.py [N=400] [minutes=8] [first seed=1000]
+    FUZZ_MODULE=test_gpu_facade python tools/fuzz_stress.py 60 9        (random walks through the facade)
 """
 import sys, os, time, inspect
 ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 os.chdir(ROOT)
 from oracle import oracle
-import test_gpu_fuzz as t
+import importlib
+t = importlib.import_module(os.environ.get('FUZZ_MODULE', 'test_gpu_fuzz'))     # FUZZ_MODULE=test_gpu_facade: the random walks
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 budget = 60.0*float(sys.argv[2]) if len(sys.argv) > 2 else 480.0
 first = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
