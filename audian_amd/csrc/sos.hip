@@ -951,12 +951,13 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
 {
     static_assert(SF > 0 && NP % 2 == 0, "band-pass in front; whole waves per SIMD");
     constexpr int DF = 2 * SF, DE = 2 * SE;
-    static_assert((NFFT == 2048 || NFFT == 1024 || NFFT == 512) && TILE % HOP == 0 && HOP % 128 == 0 && HOP <= NFFT &&
-                  NFFT <= TILE, "frames must be register windows of a tile");
+    static_assert((NFFT == 2048 || NFFT == 1024 || NFFT == 512 || NFFT == 256) && TILE % HOP == 0 && HOP % 128 == 0 &&
+                  HOP <= NFFT && NFFT <= TILE, "frames must be register windows of a tile");
+    static_assert(NFFT != 256 || HOP == 128, "256-sample frames: the reference's default, 50 % overlap");
     constexpr int M = NFFT / 2, F = M + 1, MP = M + M / 16;
-    constexpr int LPF = NFFT >= 1024 ? 64 : 32;  // lanes per frame; G frames side by side in an FFT wave
+    constexpr int LPF = NFFT >= 1024 ? 64 : (NFFT == 512 ? 32 : 16);  // lanes per frame; G frames side by side in an FFT wave
     constexpr int G = 64 / LPF;
-    constexpr int R1 = NFFT == 2048 ? 16 : 8, R2 = R1, R3 = NFFT == 1024 ? 8 : 4;
+    constexpr int R1 = NFFT == 2048 ? 16 : 8, R2 = NFFT == 256 ? 4 : R1, R3 = NFFT == 1024 ? 8 : 4;
     constexpr int TW2 = (R2 - 1) * R1, TW3 = R1 * R2, TWN = M / 2 + 1, NTAB = TW2 + TW3 + TWN + M;
     constexpr int PPL = NFFT / 128;             // registers (128 samples each) of one frame
     static_assert(FPT_OK(HOP, G), "whole groups of frames per tile");
@@ -1332,6 +1333,15 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
         for (int j = 0; j < 16; j++) cur_[j] = (v2f){0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < (PREV > 0 ? PREV : 1); j++) prv_[j] = (v2f){0.f, 0.f};
+        // G == 4 (256-sample frames, 16 lanes each): frame m of a tile is the two 128-sample blocks m - 1 and m.
+        // Lane group g takes the four frames m = 4 g + q, q < 4, and keeps THEIR five blocks 4 g - 1 .. 4 g + 3 in its
+        // own lanes -- block b as four values per lane (sample pairs l + 16 t, t < 4: the first-stage inputs of the
+        // 16-lane FFT), bb_[4 j + t] = block 4 g - 1 + j: no cross-lane move anywhere, 24 instead of 16 LDS loads
+        // per tile (a group's first block is its neighbour's last); pv_ carries block 15 into the next tile for
+        // group 0, whose block -1 it is.
+        v2f bb_[G == 4 ? 20 : 1], pv_[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) pv_[j] = (v2f){0.f, 0.f};
         bool have_prev = false;
         for (int it = 0; it < a.n_iter; it++) {
             const long long tile = base + (long long)it * TILE;
@@ -1342,10 +1352,26 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             if (FLAGS) { if (active) CHAIN_WAIT_FOR(ready, it + 1, it); }
             else __syncthreads();                              // B1
             STAMP_AT(8);                                       // waited for the IIR wave's tile
+            v2f pvn_[4];
             if (active) {
+                if constexpr (G == 4) {
+                    const int gq = lane >> 4, l16 = lane & 15;
 #pragma unroll
-                for (int j = 0; j < 16; j++)
-                    cur_[j] = *reinterpret_cast<const v2f *>(tlf + lds_float_index(2 * lane + 128 * j));
+                    for (int j = 0; j < 5; j++)
+#pragma unroll
+                        for (int tt = 0; tt < 4; tt++) {
+                            const int b = 4 * gq - 1 + j;              // (-1: the block the last tile left in pv_)
+                            const v2f h = *reinterpret_cast<const v2f *>(tlf + lds_float_index(128 * (b < 0 ? 0 : b) + 2 * (l16 + 16 * tt)));
+                            bb_[4 * j + tt] = (j == 0 && b < 0) ? pv_[tt] : h;
+                        }
+#pragma unroll
+                    for (int tt = 0; tt < 4; tt++)
+                        pvn_[tt] = *reinterpret_cast<const v2f *>(tlf + lds_float_index(128 * 15 + 2 * (l16 + 16 * tt)));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; j++)
+                        cur_[j] = *reinterpret_cast<const v2f *>(tlf + lds_float_index(2 * lane + 128 * j));
+                }
             }
             if (FLAGS) {                                        // (the release fence waits for the loads)
                 // "chain_debug" bit 8 (fault-path test): FFT wave 0 of workgroup 0 withholds the hand-over of
@@ -1359,11 +1385,28 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                 const long long t = tile / TILE;
                 if (tile >= lo && tile < hi) {                 // the unit that owns the tile writes its frames
                   if (!(a.debug & 1)) {
+                   if constexpr (G == 4) {
+                    const int gq = lane >> 4;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        // lane group gq: frame m = 4 gq + q of the tile = its blocks q and q + 1
+                        const long long f = t * FPT + 4 * gq + q + 1 - NFFT / HOP;
+                        const bool keep = (4 * gq + q > 0 || have_prev) && f >= 0 && f < a.n_valid;
+                        if (__builtin_amdgcn_ballot_w64(keep) != 0) {               // (wave-uniform: some group has a frame)
+                            v2f w[8];
+#pragma unroll
+                            for (int i = 0; i < 8; i++) w[i] = bb_[4 * q + i];
+                            const long long fc = keep ? f : 0;                      // a masked group still needs a legal address
+                            psd_frame<NFFT, LPF, R1, R2, R3, DB>(w, fb + gq * MP, tw2, tw3, twn, win, lane, a.scale, keep,
+                                                                 oc + fc * (long long)F, dc + fc * (long long)F);
+                        }
+                    }
+                   } else {
 #pragma unroll
                     for (int m = 0; m < FPT; m += G) {
                         const int j0 = ((m + 1) * HOP - NFFT) / 128;          // compile-time after unrolling
                         auto reg = [&](int j) -> v2f { return j < 0 ? prv_[(PREV + j) < 0 ? 0 : (PREV + j)] : cur_[j < 0 ? 0 : j]; };
-                        if (G == 1) {
+                        if constexpr (G == 1) {
                             const long long f = t * FPT + m + 1 - NFFT / HOP;
                             if ((j0 >= 0 || have_prev) && f >= 0 && f < a.n_valid && !(a.split && (f & 1))) {
                                 v2f w[PPL];
@@ -1406,10 +1449,16 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                             }
                         }
                     }
-                  } else if (t == -12345) oc[lane] = cur_[0].x + cur_[9].y + prv_[0].x;
+                   }
+                  } else if (t == -12345) oc[lane] = cur_[0].x + cur_[9].y + prv_[0].x + bb_[0].x;
                 }
+                if constexpr (G == 4) {
 #pragma unroll
-                for (int j = 0; j < PREV; j++) prv_[j] = cur_[16 - PREV + j];
+                    for (int j = 0; j < 4; j++) pv_[j] = pvn_[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < PREV; j++) prv_[j] = cur_[16 - PREV + j];
+                }
                 have_prev = true;
             }
             STAMP_AT(10);                                      // the tile's (at most) two frames
@@ -2198,10 +2247,10 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     HD_REQUIRE(SF > 0 && SE > 0, "plan has no coefficients");
     // shapes the kernel is built for: frames that are register windows of a 2048-sample tile
     const bool shape_ok = (nfft == 2048 && (hop == 1024 || hop == 512)) || (nfft == 1024 && (hop == 512 || hop == 256)) ||
-                          (nfft == 512 && hop == 256);
+                          (nfft == 512 && hop == 256) || (nfft == 256 && hop == 128);
     if (!shape_ok || SF > 4 || SE > 2 || frames < 4 * TILE ||
         fplan->host->warm >= (1LL << 40) || eplan->host->warm >= (1LL << 40)) {
-        hipdsp_set_error("the fused forward sweep covers nfft/hop 2048/1024, 2048/512, 1024/512, 1024/256 and 512/256, a band-pass of "
+        hipdsp_set_error("the fused forward sweep covers nfft/hop 2048/1024, 2048/512, 1024/512, 1024/256, 512/256 and 256/128, a band-pass of "
                          "at most four and an envelope of at most two sections that decay, and traces of at least %d "
                          "frames: use hipdsp_sosfilt_envelope + hipdsp_spectrogram", 4 * TILE);
         return HIPDSP_ERR_UNSUPPORTED;
@@ -2318,8 +2367,10 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
         HD_CHAIN_ALL(1024, 512)
     } else if (nfft == 1024 && hop == 256) {
         HD_CHAIN_ALL(1024, 256)
-    } else {
+    } else if (nfft == 512) {
         HD_CHAIN_ALL(512, 256)
+    } else {
+        HD_CHAIN_ALL(256, 128)
     }
 #undef HD_CHAIN_FULL
 #undef HD_CHAIN_LONG

@@ -1110,6 +1110,7 @@ int hd_fft_tables(hipdsp_ctx *ctx, int nfft, const float **dev)
     if (nfft == 2048) return fft_tables(ctx, 2048, 16, 16, 4, dev);
     if (nfft == 1024) return fft_tables(ctx, 1024, 8, 8, 8, dev);
     if (nfft == 512) return fft_tables(ctx, 512, 8, 8, 4, dev);
+    if (nfft == 256) return fft_tables(ctx, 256, 8, 4, 4, dev);
     hipdsp_set_error("no three-stage table set for nfft %d", nfft);
     return HIPDSP_ERR_UNSUPPORTED;
 }

@@ -317,7 +317,7 @@ def sosfilt_envelope(ctx, fplan, eplan, x, x_pitch, yf, yf_pitch, env, env_pitch
 def chain_forward(ctx, fplan, eplan, x, x_pitch, yf, yf_pitch, channels, frames, nfft, hop, fs, psd,
                   frames_out, psd_pitch=0, rectify=True, gain=np.pi/2, db_out=None):
     """Band-pass + envelope state sweep + spectrogram of the filtered trace in one pass over x
-    (nfft 2048 / hop 1024 only; NotImplementedError otherwise).  The envelope follows with
+    (nfft/hop 2048/1024, 2048/512, 1024/512, 1024/256, 512/256, 256/128; NotImplementedError otherwise).  The envelope follows with
     sosfilt_envelope(..., phase=2)."""
     check(lib.hipdsp_chain_forward(ctx.handle, fplan.handle, eplan.handle, _p(x), int(x_pitch), _p(yf),
                                    int(yf_pitch), int(channels), int(frames), int(bool(rectify)),

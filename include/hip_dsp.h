@@ -272,8 +272,9 @@ int hipdsp_envelope_multi(hipdsp_ctx *ctx, const hipdsp_sosplan *const *plans, i
  * equal hipdsp_sosfilt_envelope(phase 1) + hipdsp_spectrogram up to float32 rounding of the
  * frames that straddle an internal segment border.
  * Covers the window lengths whose frames are register windows of the sweep's 2048-sample tiles -- nfft / hop
- * 2048/1024, 2048/512, 1024/512, 1024/256 and 512/256 (the reference's overlap selector offers 50 % and 75 %,
- * databrowser.py:516-540; BASELINE configs[1] is 1024/256) -- band-pass plans of up to four and envelope
+ * 2048/1024, 2048/512, 1024/512, 1024/256, 512/256 and 256/128 (the reference's overlap selector offers 50 % and 75 %,
+ * databrowser.py:516-540; BASELINE configs[1] is 1024/256; 256/128 is BufferedSpectrogram's default,
+ * bufferedspectrogram.py:14-16) -- band-pass plans of up to four and envelope
  * plans of up to two decaying sections, and frames >= 8192; anything else returns HIPDSP_ERR_UNSUPPORTED
  * (use the separate calls).  psd layout, the zero tail and the optional db_out (decibel(psd), fused epilogue;
  * nfft 2048 / hop 1024 only) as in hipdsp_spectrogram. */

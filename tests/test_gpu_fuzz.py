@@ -334,7 +334,7 @@ def test_random_chain_shapes_sections_and_modes(oracle, seed):
     from audian_amd.design import butter_sos
     rng = np.random.default_rng(91000 + seed)
     rate = float(rng.choice([44100.0, 48000.0, 96000.0, 192000.0]))
-    nfft, hop = [(2048, 1024), (2048, 512), (1024, 512), (1024, 256), (512, 256)][int(rng.integers(0, 5))]
+    nfft, hop = [(2048, 1024), (2048, 512), (1024, 512), (1024, 256), (512, 256), (256, 128)][int(rng.integers(0, 6))]
     F = nfft//2 + 1
     T = int(rng.integers(4, 40))*TILE + int(rng.integers(-TILE + 1, TILE)) if rng.integers(0, 3) else \
         int(rng.integers(4*TILE, 6*TILE))

@@ -524,7 +524,7 @@ def test_chain_forward_equals_separate_calls(oracle, T, max_segments, handover):
             assert np.array_equal(np.isfinite(gdb[:, :nf, :]), fin)
             assert np.max(np.abs(gdb[:, :nf, :][fin] - want_db[fin])) < 1e-3
         with pytest.raises(NotImplementedError):
-            hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, 256, 128, rate, ps, nd)
+            hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, 256, 64, rate, ps, nd)
     finally:
         c.set_max_segments(0)
         c.set_option('chain_debug', 0)
@@ -637,7 +637,7 @@ def test_envelope_cascades_longer_than_one_plan(oracle, T):
                     assert rel_err(got[:, ch], one[:, ch]) < 1e-5
 
 
-@pytest.mark.parametrize('nfft,hop', [(2048, 512), (1024, 512), (1024, 256), (512, 256), (2048, 1024)])
+@pytest.mark.parametrize('nfft,hop', [(2048, 512), (1024, 512), (1024, 256), (512, 256), (256, 128), (2048, 1024)])
 @pytest.mark.parametrize('T,max_segments', [(8192, 0), (20481, 0), (70001, 0), (300000, 3), (1500000, 0)])
 def test_chain_forward_other_windows_and_longer_bandpasses(oracle, T, max_segments, nfft, hop):
     """The fused forward sweep for every window the kernel is built for (frames are register windows of a

@@ -29,7 +29,7 @@ def timed(f, n=4):
 
 for order in (2, 4):
     fplan = hipdsp.SosPlan(ctx, butter_sos(order, (300.0, 3000.0), 'bandpass', rate))
-    for nfft, hop in [(2048, 1024), (1024, 512), (1024, 256), (2048, 512), (512, 256)]:
+    for nfft, hop in [(2048, 1024), (1024, 512), (1024, 256), (2048, 512), (512, 256), (256, 128)]:
         nd = (T + hop - 1)//hop
         F = nfft//2 + 1
         ds = hipdsp.DeviceArray(ctx, (C, nd, F), np.float32)
