@@ -106,3 +106,33 @@ def test_compiler_tracked_loads_only_take_a_queue_slot(tmp_path):
     # as a younger operation behind the prefetch
     text = GOOD.replace('\tglobal_store_dword v[30:31], v11, off\n', '\tglobal_load_dword v50, v[30:31], off\n')
     assert run(text, tmp_path).returncode == 0
+
+
+def test_isa_tally_classifies_a_listing(tmp_path):
+    """tools/isa_tally.py (where do a sweep's VALU issue slots go): classes and per-block counts of a small listing."""
+    text = '''_Zmykernel_v1:
+	s_load_dwordx4 s[0:3], s[4:5], 0x0
+	v_cvt_f64_f32_e32 v[2:3], v1
+.LBB0_1:
+	v_fma_f64 v[4:5], s[0:1], v[2:3], v[4:5]
+	v_pk_fma_f32 v[6:7], v[6:7], v[8:9], v[10:11]
+	v_mov_b32_dpp v12, v13 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+	v_cndmask_b32_e64 v14, v15, v16, s[0:1]
+	ds_read_b128 v[20:23], v24
+	global_store_dwordx4 v[30:31], v[20:23], off
+	s_waitcnt vmcnt(0)
+	s_cbranch_scc0 .LBB0_1
+	s_endpgm
+.Lfunc_end0:
+'''
+    f = tmp_path/'k.s'
+    f.write_text(text)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'isa_tally.py'), str(f), 'mykernel', '1'],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    for want in ('valu f64 fma', 'valu f64 cvt', 'valu pk_f32', 'valu dpp', 'valu cndmask', 'lds', 'vmem', 'smem',
+                 's_waitcnt', 'branch'):
+        assert want in out, (want, out)
+    assert 'whole function: 11 instructions' in out
+    assert '.LBB0_1: 9' in out
