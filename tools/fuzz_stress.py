@@ -2,6 +2,7 @@
 that module that takes (oracle, seed), seeds 1000 .. 1000 + N, time-boxed; needs an MI355X.
     python tools/fuzz_stress.py [N=400] [minutes=8] [first seed=1000]
     FUZZ_MODULE=test_gpu_facade python tools/fuzz_stress.py 60 9        (random walks through the facade)
+    FUZZ_OPTIONS=1 python tools/fuzz_stress.py ...                      (random tuning options per case as well)
 """
 import sys, os, time, inspect
 ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
@@ -25,13 +26,25 @@ for seed in range(first, first + N):
     for name, f in tests:
         if time.time() - t0 > budget:
             break
-        progress.write(f'{name} {seed}\n'); progress.flush(); os.fsync(progress.fileno())
+        opts = {}
+        if os.environ.get('FUZZ_OPTIONS') == '1':
+            # tuning options whose values must not change any result beyond rounding, drawn per case
+            import numpy as _np, gpu_helpers as _gh
+            r = _np.random.default_rng(seed*131 + len(name))
+            opts = {'sos_waves_per_cu': int(r.choice([4, 8, 12, 16])), 'sos_prefetch': int(r.integers(0, 2)),
+                    'spec_kernel': int(r.choice([0, 0, 2, 3])), 'spec_no_half': int(r.integers(0, 2)),
+                    'spec_fpw': int(r.choice([0, 0, 1, 3, 16])), 'sos_fair': int(r.integers(0, 2)),
+                    'sos_no_pin': int(r.integers(0, 2)), 'chain_reserve_cus': int(r.choice([0, 0, 8, 100])),
+                    'force_generic_fft': int(r.integers(0, 8) == 0)}
+            for k, v in opts.items():
+                _gh.ctx().set_option(k, v)
+        progress.write(f'{name} {seed} {opts}\n'); progress.flush(); os.fsync(progress.fileno())
         try:
             f(oracle, seed)
         except AssertionError as e:
             bad += 1
-            print('FAIL', name, seed, str(e)[:300], flush=True)
-            failures.write(f'FAIL {name} {seed} {str(e)[:300]}\n'); failures.flush()
+            print('FAIL', name, seed, opts, str(e)[:300], flush=True)
+            failures.write(f'FAIL {name} {seed} {opts} {str(e)[:300]}\n'); failures.flush()
         except Exception as e:
             bad += 1
             print('ERROR', name, seed, type(e).__name__, str(e)[:300], flush=True)
