@@ -209,6 +209,7 @@ class BufferedData(BufferedArray):
     _pending = None
     _carry = None
     _ctx = None
+    _fused_token = False       # the source's own launch has already filled this trace's whole buffer (mirror)
 
     def __init__(self, name, source_name, tbefore=0, tafter=0, panel='none', panel_type='trace',
                  color='#00ee00', lw_thin=1.1, lw_thick=2):
@@ -388,6 +389,23 @@ class BufferedData(BufferedArray):
             call = None
         return call
 
+    def _take_fused(self, call):
+        """True when this call of process() is the recompute of the whole buffer that the SOURCE's fused
+        launch has already carried out (BufferedFilter.recompute_all: one launch fills the filtered trace
+        and the traces derived from it): the mirror is marked valid, nothing is launched."""
+        token, self._fused_token = self._fused_token, False
+        if not token or call is None or call.doffset != 0 or call.dnframes != len(self._hostbuf) or \
+           self._dev is None:
+            return False
+        self._dev_valid = [[0, call.dnframes]]
+        self._stale = [[0, call.dnframes]]
+        return True
+
+    def _builtin(self, cls):
+        """process() and recompute() are the built-in ones (a subclass that overrides either computes
+        in its own way and takes no part in fused launches)."""
+        return type(self).process is cls.process and type(self).recompute is BufferedData.recompute
+
     def _device_source(self, source, call):
         """(device pointer holder, pitch in elements) of the source slab, planar float32.
         Uses the source trace's mirror when it is valid there, else uploads `source`."""
@@ -557,11 +575,11 @@ class BufferedData(BufferedArray):
         self.move_buffer(offset, floor((first + count)*self.rate/src.rate) - offset)
         self.bufferframes = len(self._hostbuf)
 
-    def load_buffer(self, offset, nframes, buffer):
-        """Fill `buffer` (frames [offset, offset + nframes) of this trace) from the source's
-        buffer through process() (buffereddata.py:91-109)."""
-        if _TRACE:
-            print(f'load {self.name} {offset/self.rate:.3f} - {(offset + nframes)/self.rate:.3f}')
+    def _load_geometry(self, offset, nframes):
+        """Which slab of the source's buffer load_buffer hands to process() for frames
+        [offset, offset + nframes) of this trace: (first, count, lead) -- `count` source frames from
+        `first` (relative to the source's buffer), the first `lead` of them ahead of the span
+        (buffereddata.py:93-107)."""
         src = self.source
         # the same span in source frames
         first = floor(offset*src.rate/self.rate)
@@ -576,6 +594,15 @@ class BufferedData(BufferedArray):
         if first < 0:                             # the source's buffer starts later than that
             lead, count, first = lead + first, count + first, 0
         count = min(count, self._source_len() - first)
+        return first, count, lead
+
+    def load_buffer(self, offset, nframes, buffer):
+        """Fill `buffer` (frames [offset, offset + nframes) of this trace) from the source's
+        buffer through process() (buffereddata.py:91-109)."""
+        if _TRACE:
+            print(f'load {self.name} {offset/self.rate:.3f} - {(offset + nframes)/self.rate:.3f}')
+        src = self.source
+        first, count, lead = self._load_geometry(offset, nframes)
         source = self._source_buffer()[first:first + count]
         if isinstance(src, BufferedData) and any(min(r1, first + count) > max(r0, first) for r0, r1 in src._stale):
             # the raw host slice would show stale frames to a subclass that reads `source` itself

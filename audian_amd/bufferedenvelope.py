@@ -28,6 +28,22 @@ class BufferedEnvelope(BufferedData):
         self.sos = None
         self.update()
 
+    def _fusable_with(self, filt):
+        """True if this envelope's whole-buffer recompute is exactly what the filter's fused launch
+        computes (BufferedFilter._plan_fusion): one plan of at most two decaying sections, over the very
+        frames the filter produces (same offset and length: no pre-roll trimmed)."""
+        if not self._builtin(BufferedEnvelope) or self.sos is None or self._plans or self._plan is None or \
+           len(self.sos) > 2:
+            return False
+        warm, edge = self._plan.info()
+        if warm >= 1 << 40:
+            return False
+        if len(filt._hostbuf) > 0:
+            self.allocate_buffer()               # what recompute() does first
+        n = len(self._hostbuf)
+        first, count, lead = self._load_geometry(self.offset, n) if n > 0 else (1, 0, 0)
+        return first == 0 and lead == 0 and count == len(filt._hostbuf) and n == count and count > edge
+
     def process(self, source, dest, nbefore):
         """dest = sosfiltfilt(sos, (pi/2)|source|, axis=0)[nbefore:], negatives clamped to
         0 unless a high-pass is set; zeros when the design failed
@@ -39,6 +55,8 @@ class BufferedEnvelope(BufferedData):
                              f'({len(source) - nbefore},) into shape ({len(dest)},)')
         call = self._take_call(source, dest)
         if len(dest) == 0:
+            return
+        if self._take_fused(call):
             return
         ddst, dpitch, is_mirror = self._device_dest(dest, call)
         keep = None

@@ -9,6 +9,9 @@ from .buffereddata import BufferedData
 from .design import butter_sos
 
 
+MIN_FUSED_FRAMES = 8192       # hipdsp_chain_forward / the prefetching sweeps want at least four 2048-sample tiles
+
+
 def make_plans(ctx, sos, max_sections):
     """SOS table -> list of device plans of at most `max_sections` sections each.
     Splitting a zero-state cascade is exact; the hand-over between plans is float32."""
@@ -43,6 +46,7 @@ class BufferedFilter(BufferedData):
                               color=color, lw_thin=lw_thin, lw_thick=lw_thick)
         self._reset(lowpass=1)
         self._plans = []
+        self._fuse = None          # set by recompute_all() for the one process() call it triggers
 
     def _reset(self, lowpass):
         self.highpass_cutoff, self.lowpass_cutoff, self.filter_order, self.sos = 0, lowpass, 2, None
@@ -66,7 +70,11 @@ class BufferedFilter(BufferedData):
             return
         dsrc, spitch, keep = self._device_source(source, call)
         ddst, dpitch, is_mirror = self._device_dest(dest, call)
-        if self.sos is None:
+        fuse, self._fuse = self._fuse, None
+        if fuse is not None and is_mirror and nbefore == 0 and call.doffset == 0 and \
+           call.dnframes == len(self._hostbuf) and self._process_fused(fuse, dsrc, spitch, ddst, dpitch, ns):
+            fuse['done'] = True
+        elif self.sos is None:
             hipdsp.sosfilt(self.ctx, None, dsrc, spitch, ddst, dpitch, self.channels, ns, nbefore)
         else:
             plans = self._plans
@@ -83,6 +91,86 @@ class BufferedFilter(BufferedData):
         self._finish_dest(dest, ddst, dpitch, is_mirror, call)
         if keep is not None or not is_mirror:
             self.ctx.synchronize()
+
+    # ---- one launch for the filter and the traces derived from it -----------------------------------
+    def _plan_fusion(self):
+        """Which of the traces derived from this one can be computed by the filter's own launch:
+        a spectrogram whose frames the fused forward sweep covers (hipdsp_chain_forward) and/or an
+        envelope of at most two sections over the same frames (its state sweep rides along, the
+        backward sweep follows).  None when there is nothing to fuse; everything else -- no filter,
+        a cascade longer than one plan, short buffers, other windows, an envelope that starts later
+        than the filtered buffer (pre-roll trimmed after a scroll), subclasses with their own
+        process() -- keeps the separate process() calls of the dependency walk."""
+        from .bufferedspectrogram import BufferedSpectrogram
+        from .bufferedenvelope import BufferedEnvelope
+        if not self._builtin(BufferedFilter) or self.sos is None or len(self._plans) != 1:
+            return None
+        n = len(self._hostbuf)
+        if n < MIN_FUSED_FRAMES or self._plans[0].info()[0] >= 1 << 40:
+            return None
+        first, count, lead = self._load_geometry(self.offset, n)
+        if lead != 0 or count != n:
+            return None
+        spec = env = None
+        for dest in self.dests:
+            if not dest.need_update:
+                continue
+            if spec is None and isinstance(dest, BufferedSpectrogram):
+                geom = dest._fusable_with(self)
+                if geom is not None:
+                    spec = (dest, geom)
+            elif env is None and isinstance(dest, BufferedEnvelope):
+                if dest._fusable_with(self):
+                    env = dest
+        if spec is None and env is None:
+            return None
+        return {'spec': spec, 'env': env, 'done': False}
+
+    def _process_fused(self, fuse, dsrc, spitch, ddst, dpitch, ns):
+        """The fused launch(es); False when the library does not cover the case after all."""
+        from . import hipdsp
+        plan = self._plans[0]
+        spec, env = fuse['spec'], fuse['env']
+        eplan = env._plan if env is not None else None
+        edev = env._mirror() if env is not None else None
+        clamp = env is not None and env.highpass_cutoff == 0
+        try:
+            if spec is not None:
+                trace, (nd, spec_frames) = spec
+                F = trace.nfft//2 + 1
+                hipdsp.chain_forward(self.ctx, plan, eplan, dsrc, spitch, ddst, dpitch, self.channels, ns,
+                                     trace.nfft, trace.hop, self.rate, trace._mirror(), nd, psd_pitch=nd*F,
+                                     rectify=True, gain=np.pi/2, spec_frames=spec_frames)
+                if env is not None:
+                    hipdsp.sosfilt_envelope(self.ctx, plan, eplan, dsrc, spitch, ddst, dpitch, edev, ns,
+                                            self.channels, ns, rectify=True, gain=np.pi/2, clamp=clamp, phase=2)
+            else:
+                hipdsp.sosfilt_envelope(self.ctx, plan, eplan, dsrc, spitch, ddst, dpitch, edev, ns,
+                                        self.channels, ns, rectify=True, gain=np.pi/2, clamp=clamp, phase=0)
+        except NotImplementedError:
+            return False
+        if spec is not None:
+            spec[0]._fused_token = True
+        if env is not None:
+            env._fused_token = True
+        return True
+
+    def recompute_all(self):
+        """Recompute this trace and the traces derived from it (buffereddata.py:149-153) -- depth first as
+        in the reference, but the filter's own launch already fills the mirrors of the derived traces it
+        can serve (_plan_fusion); their recompute() in the walk below then only does its bookkeeping
+        (buffer_changed, spec_rect, frequencies)."""
+        if not self.need_update:
+            return
+        if self._source_len() > 0:
+            self.allocate_buffer()
+        self._fuse = self._plan_fusion() if len(self._hostbuf) > 0 else None
+        try:
+            self.reload_buffer()
+        finally:
+            self._fuse = None
+        for dest in self.dests:
+            dest.recompute_all()
 
     def update(self):
         """Design the filter for the current cut-offs and order, refresh the device plans and

@@ -19,6 +19,9 @@ def decibel(power, ref_power=1.0, min_power=1e-20):
     return out if out.ndim else float(out)
 
 
+# nfft / hop the filter's fused forward sweep writes (hipdsp_chain_forward)
+FUSED_WINDOWS = {(2048, 1024), (2048, 512), (1024, 512), (1024, 256), (512, 256), (256, 128)}
+
 # parameter limits of the reference (bufferedspectrogram.py:83-100)
 MIN_NFFT = 8
 MAX_NFFT = 2**30
@@ -63,6 +66,22 @@ class BufferedSpectrogram(BufferedData):
         # the y axis of a spectrogram is frequency
         self.ampl_min, self.ampl_max = 0, 0.5*self.source.rate
 
+    def _fusable_with(self, filt):
+        """(frames, source samples) of this spectrogram's whole-buffer recompute if the filter's fused
+        forward sweep can write it (BufferedFilter._plan_fusion), else None: the window must be one of the
+        sweep's and the first frame must start at the first sample of the filtered buffer."""
+        if not self._builtin(BufferedSpectrogram) or (self.nfft, self.hop) not in FUSED_WINDOWS:
+            return None
+        if len(filt._hostbuf) > 0:
+            self.allocate_buffer()               # what recompute() does first
+        nd = len(self._hostbuf)
+        if nd == 0:
+            return None
+        first, count, lead = self._load_geometry(self.offset, nd)
+        if first != 0 or lead != 0 or count <= 0:
+            return None
+        return nd, count
+
     def process(self, source, dest, nbefore):
         """dest[k, c, :] = one-sided PSD of source[k*hop : k*hop + nfft, c]; frames that do
         not fit into the source are zero (bufferedspectrogram.py:45-66)."""
@@ -70,7 +89,11 @@ class BufferedSpectrogram(BufferedData):
         call = self._take_call(source, dest)
         nd = len(dest)
         F = self.nfft//2 + 1
-        if nd > 0:
+        if nd > 0 and self._take_fused(call):
+            nsource = min((nd - 1)*self.hop + self.nfft, len(source))
+            if nsource >= self.nfft:
+                self.frequencies = np.arange(F)*self.source.rate/self.nfft
+        elif nd > 0:
             dsrc, spitch, keep = self._device_source(source, call)
             ddst, dpitch, is_mirror = self._device_dest(dest, call)
             hipdsp.spectrogram(self.ctx, dsrc, spitch, self.channels, len(source), self.nfft,

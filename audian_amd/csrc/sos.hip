@@ -38,6 +38,7 @@ struct SosPlanDev {
     double G[L * MAXD];             // G[j * D + r] = (A^(L-1-j) B)[r]
     double M[6 * MAXD * MAXD];      // M[k * D * D + r * D + c] = (A^(L*2^k))[r][c]
     double zi[MAXD];                // scipy sosfilt_zi, flattened (z0,z1) per section
+    double AT[MAXD * MAXD];         // AT[r * D + c] = (A^TILE)[r][c]: the state hand-over between time segments (env_fix_kernel)
     long long warm;                 // warm-up samples, multiple of TILE
     int n_sections;
     int edge;                       // sosfiltfilt pad length
@@ -58,6 +59,9 @@ struct SeqArgs {
     const float *zi_ref;
     long long zi_ref_pitch;
     double zi_scale;
+    // the cascade filters gain * in (hipdsp_envelope_multi: the pi/2 of the rectified trace rides on the first
+    // plan's numerator instead of on every sample); launch_scan turns 0 into 1
+    double gain;
 };
 
 __device__ __forceinline__ long long opaque_zero()
@@ -179,7 +183,9 @@ __global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *__restri
 #define CASC_PLAN() PLAN_OF(P0)
 #define CASC_CARRY carry
 #define CASC_IN(v) (v)
+#define CASC_GAIN a.gain
 #include "sos_cascade.inc"
+#undef CASC_GAIN
 #undef CASC_S
 #undef CASC_PLAN
 #undef CASC_CARRY
@@ -217,7 +223,7 @@ struct CkptArgs {
     long long in_pitch, yf_pitch, ckpt_pitch;
     long long T, seg_len;
     int n_seg, edge, rectify;
-    float gain;
+    double gain;            // the envelope filters gain * |y|: folded into its cascade (CASC_GAIN), never into the samples
 };
 
 // 16-byte global load the compiler does not track: the caller counts vmcnt by hand, so that the
@@ -258,9 +264,12 @@ __global__ __launch_bounds__(64) void sos_ckpt_kernel(const SosPlanDev *__restri
     long long hi = lo + a.seg_len;
     const bool last_seg = hi >= T;
     if (hi > T) hi = T;
-    long long env_start = lo - PE0->warm;
-    const bool env_true = env_start <= 0;
-    if (env_start < 0) env_start = 0;
+    // The envelope cascade has NO warm-up: a segment behind the first starts it from zero state at its own first
+    // tile, its tile states are therefore the ZERO-STATE ones, and the state it ends with goes where the next
+    // segment's first (always zero) tile state would go; env_fix_kernel then hands the true states over from
+    // segment to segment and corrects the tile states (exact) -- only the band-pass still warms up.
+    const long long env_start = lo;
+    const bool env_true = seg == 0;
     long long start = env_start;
     if (SF > 0) start -= PF0->warm;
     if (start < 0) start = 0;               // zero state at sample 0 is the filter's true state
@@ -359,12 +368,13 @@ __global__ __launch_bounds__(64) void sos_ckpt_kernel(const SosPlanDev *__restri
             __syncthreads();
             continue;
         }
-        // ---- envelope input in place: r = gain*|y|, then the odd extension past T
+        // ---- envelope input in place: r = |y| (exact; the gain rides on the cascade, CASC_GAIN), then the odd
+        // extension past T
         if (a.rectify) {
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 float4 v = lds[lds_slot(lane, q)];
-                v = make_float4(a.gain * fabsf(v.x), a.gain * fabsf(v.y), a.gain * fabsf(v.z), a.gain * fabsf(v.w));
+                v = make_float4(fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w));
                 lds[lds_slot(lane, q)] = v;
             }
         }
@@ -388,12 +398,12 @@ __global__ __launch_bounds__(64) void sos_ckpt_kernel(const SosPlanDev *__restri
             // left odd extension: ext[i] = 2 r(0) - r(edge - i), i < edge, from zi * ext[0];
             // wave-uniform serial steps
             const SosPlanDev *P = PLAN_OF(PE0);
-            const float r0 = ldsf[lds_float_index(0)];
-            const double x0 = (double)(2.f * r0 - ldsf[lds_float_index(edge)]);
+            const double r0 = (double)ldsf[lds_float_index(0)];
+            const double x0 = a.gain * (2.0 * r0 - (double)ldsf[lds_float_index(edge)]);
 #pragma unroll
             for (int r = 0; r < DE; r++) ce_[r] = P->zi[r] * x0;
             for (int i = 0; i < edge; i++) {
-                double cur = (double)(2.f * r0 - ldsf[lds_float_index(edge - i)]);
+                double cur = a.gain * (2.0 * r0 - (double)ldsf[lds_float_index(edge - i)]);
 #pragma unroll
                 for (int s2 = 0; s2 < SE; s2++) {
                     const double y = fma(P->coef[s2][0], cur, ce_[2 * s2]);
@@ -403,11 +413,13 @@ __global__ __launch_bounds__(64) void sos_ckpt_kernel(const SosPlanDev *__restri
                 }
             }
         }
-        if (tile >= lo && lane == 0) {
+        // (the slot of a later segment's first tile receives the end state of the segment before it, see below)
+        if ((tile > lo || env_true) && lane == 0) {
 #pragma unroll
             for (int r = 0; r < DE; r++) ckpt[(tile / TILE) * DE + r] = ce_[r];
         }
-        if (tile + TILE >= loop_end) {
+        const bool last_tile = tile + TILE >= loop_end;
+        if (last_tile && last_seg) {
             if (PREFETCH && SF == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             break;
         }
@@ -425,16 +437,148 @@ __global__ __launch_bounds__(64) void sos_ckpt_kernel(const SosPlanDev *__restri
 #define CASC_PLAN() PLAN_OF(PE0)
 #define CASC_CARRY ce_
 #define CASC_IN(v) (v)
+#define CASC_GAIN a.gain
 #define CASC_NO_OUTPUT
 #include "sos_cascade.inc"
 #undef CASC_NO_OUTPUT
+#undef CASC_GAIN
 #undef CASC_S
 #undef CASC_PLAN
 #undef CASC_CARRY
 #undef CASC_IN
         if (PREFETCH && SF == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (last_tile) {
+            // the (zero-state, for seg > 0) state this segment ends with: into the slot of the next segment's first tile
+            if (lane == 0) {
+#pragma unroll
+                for (int r = 0; r < DE; r++) ckpt[(tile / TILE + 1) * DE + r] = ce_[r];
+            }
+            break;
+        }
         __syncthreads();
     }
+}
+
+// Exact state hand-over between the time segments of the envelope's forward sweep.  After the sweep
+// the slot of segment k's first tile (k >= 1) holds e_(k-1), the state segment k-1 ended with having started from
+// zero (segment 0: from the true initial state), and the other slots hold zero-state tile states.  With
+// P = A^segment the true state entering segment k is S_k = e_(k-1) + P S_(k-1) = sum_j P^j e_(k-1-j), cut off
+// where ||P^j|| < 2^-60 (the plan's warm-up length says where), and the true state entering tile m of segment k is
+// its zero-state one + A^(TILE m) S_k -- added for the tiles of the warm-up length only, beyond which it is below
+// float64 rounding.  One block per channel; segments are taken from the last to the first in chunks of the block
+// size so that every e_k is read before it is overwritten with S_(k+1).
+template <int SE>
+__global__ __launch_bounds__(256) void env_fix_kernel(const SosPlanDev *__restrict__ P0, double *ckpt_all, long long ckpt_pitch,
+                                                      int n_seg, long long seg_tiles, long long n_tiles)
+{
+    constexpr int D = 2 * SE;
+    double *ckpt = ckpt_all + (long long)blockIdx.x * ckpt_pitch;
+    double AT[D][D], P[D][D];
+#pragma unroll
+    for (int r = 0; r < D; r++)
+#pragma unroll
+        for (int c = 0; c < D; c++) { AT[r][c] = P0->AT[r * D + c]; P[r][c] = r == c ? 1.0 : 0.0; }
+    {   // P = AT^seg_tiles by binary exponentiation
+        double Q[D][D];
+#pragma unroll
+        for (int r = 0; r < D; r++)
+#pragma unroll
+            for (int c = 0; c < D; c++) Q[r][c] = AT[r][c];
+        for (long long e = seg_tiles; e > 0; e >>= 1) {
+            double t[D][D];
+            if (e & 1) {
+#pragma unroll
+                for (int r = 0; r < D; r++)
+#pragma unroll
+                    for (int c = 0; c < D; c++) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int k = 0; k < D; k++) acc = fma(P[r][k], Q[k][c], acc);
+                        t[r][c] = acc;
+                    }
+#pragma unroll
+                for (int r = 0; r < D; r++)
+#pragma unroll
+                    for (int c = 0; c < D; c++) P[r][c] = t[r][c];
+            }
+#pragma unroll
+            for (int r = 0; r < D; r++)
+#pragma unroll
+                for (int c = 0; c < D; c++) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; k++) acc = fma(Q[r][k], Q[k][c], acc);
+                    t[r][c] = acc;
+                }
+#pragma unroll
+            for (int r = 0; r < D; r++)
+#pragma unroll
+                for (int c = 0; c < D; c++) Q[r][c] = t[r][c];
+        }
+    }
+    const long long warm_tiles = P0->warm / TILE;                  // ||A^(TILE warm_tiles)|| < 2^-60
+    const long long terms = (warm_tiles + seg_tiles - 1) / seg_tiles + 1;
+    for (long long k_hi = n_seg - 1; k_hi >= 1; k_hi -= blockDim.x) {
+        const long long k = k_hi - threadIdx.x;
+        double S[D];
+#pragma unroll
+        for (int r = 0; r < D; r++) S[r] = 0.0;
+        if (k >= 1) {
+            // Horner from the oldest term: S = e_(k-J) ; S = P S + e_(k-J+1) ; ... ; + e_(k-1); e_j sits in slot (j+1) seg_tiles
+            long long j = k - terms;
+            if (j < 0) j = 0;
+            for (; j < k; j++) {
+                const double *e = ckpt + (j + 1) * seg_tiles * D;
+                double t[D];
+#pragma unroll
+                for (int r = 0; r < D; r++) {
+                    double acc = e[r];
+#pragma unroll
+                    for (int c = 0; c < D; c++) acc = fma(P[r][c], S[c], acc);
+                    t[r] = acc;
+                }
+#pragma unroll
+                for (int r = 0; r < D; r++) S[r] = t[r];
+            }
+        }
+        __syncthreads();
+        if (k >= 1) {
+            const long long t0 = k * seg_tiles;
+            long long cnt = (k == n_seg - 1) ? n_tiles - t0 : seg_tiles;     // tile slots of segment k
+            if (cnt > warm_tiles + 1) cnt = warm_tiles + 1;
+#pragma unroll
+            for (int r = 0; r < D; r++) ckpt[t0 * D + r] = S[r];              // (its zero-state tile state is zero)
+            for (long long m = 1; m < cnt; m++) {
+                double t[D];
+#pragma unroll
+                for (int r = 0; r < D; r++) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int c = 0; c < D; c++) acc = fma(AT[r][c], S[c], acc);
+                    t[r] = acc;
+                }
+#pragma unroll
+                for (int r = 0; r < D; r++) { S[r] = t[r]; ckpt[(t0 + m) * D + r] += t[r]; }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int launch_env_fix(hipdsp_ctx *ctx, const SosPlanDev *edev, int SE, double *ckpt, long long ckpt_pitch, long long channels,
+                   int n_seg, long long seg_len, long long n_tiles)
+{
+    if (n_seg <= 1) return HIPDSP_OK;
+    dim3 grid((unsigned)channels), block(256);
+    const long long seg_tiles = seg_len / TILE;
+    switch (SE) {
+    case 1: hipLaunchKernelGGL((env_fix_kernel<1>), grid, block, 0, ctx->stream, edev, ckpt, ckpt_pitch, n_seg, seg_tiles, n_tiles); break;
+    case 2: hipLaunchKernelGGL((env_fix_kernel<2>), grid, block, 0, ctx->stream, edev, ckpt, ckpt_pitch, n_seg, seg_tiles, n_tiles); break;
+    case 3: hipLaunchKernelGGL((env_fix_kernel<3>), grid, block, 0, ctx->stream, edev, ckpt, ckpt_pitch, n_seg, seg_tiles, n_tiles); break;
+    case 4: hipLaunchKernelGGL((env_fix_kernel<4>), grid, block, 0, ctx->stream, edev, ckpt, ckpt_pitch, n_seg, seg_tiles, n_tiles); break;
+    default: return HIPDSP_OK;
+    }
+    return hd_launch_status("env_fix_kernel");
 }
 
 // Fair shares of a SIMD for persistent waves that do not talk to each other.  The issue arbiters serve the
@@ -451,13 +595,7 @@ __device__ __forceinline__ void rotate_issue_priority(unsigned slot)
     else if (p == 2) __builtin_amdgcn_s_setprio(2);
     else __builtin_amdgcn_s_setprio(3);
 }
-// gain * |x| and max(x, 0) as single instructions (results as gain * fabsf(x) and fmaxf(x, 0.f))
-__device__ __forceinline__ float gain_abs(float gain, float x)
-{
-    float r;
-    asm("v_mul_f32_e64 %0, %1, |%2|" : "=v"(r) : "s"(gain), "v"(x));
-    return r;
-}
+// max(x, 0) as a single instruction (result as fmaxf(x, 0.f))
 __device__ __forceinline__ float max_zero(float x)
 {
     float r;
@@ -487,7 +625,7 @@ struct BwdArgs {
     long long n_tiles;       // ceil((T + edge) / TILE)
     long long seg_tiles, warm_tiles;
     int n_seg, edge, rectify, clamp;
-    float gain;
+    double gain;             // as in CkptArgs
     long long *trace;        // option "sos_trace": 9 words per wave (start, end in 100 MHz ticks, HW_ID, 6 clock sums)
     int fair;                // rotate_issue_priority() per tile (option "sos_fair", default off: no gain measured)
 };
@@ -569,15 +707,13 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
         if (PREFETCH && pre) {
             // (the wait for this tile's prefetch sits at the end of the previous iteration, behind
             // the stores it is counted against)
-            // (one wave-uniform branch around the eight, and gain * |x| as ONE double-rate multiply with a source
-            // modifier: left to itself hipcc emits and + packed multiply + select per sample, 2.5 x the issue time)
+            // (one wave-uniform branch around the eight; |x| is exact -- the gain rides on the forward cascade, CASC_GAIN)
             if (a.rectify) {
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     asm volatile("" : "+v"(nx[k]));
                     lds[lds_slot(8 * k + (lane >> 3), lane & 7)] =
-                        make_float4(gain_abs(a.gain, nx[k].x), gain_abs(a.gain, nx[k].y), gain_abs(a.gain, nx[k].z),
-                                    gain_abs(a.gain, nx[k].w));
+                        make_float4(fabsf(nx[k].x), fabsf(nx[k].y), fabsf(nx[k].z), fabsf(nx[k].w));
                 }
             } else {
 #pragma unroll
@@ -610,8 +746,7 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
                 asm volatile("" : "+v"(t));
                 float4 v = make_float4(p < T ? t.x : 0.f, p + 1 < T ? t.y : 0.f, p + 2 < T ? t.z : 0.f,
                                        p + 3 < T ? t.w : 0.f);
-                if (a.rectify)
-                    v = make_float4(a.gain * fabsf(v.x), a.gain * fabsf(v.y), a.gain * fabsf(v.z), a.gain * fabsf(v.w));
+                if (a.rectify) v = make_float4(fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w));
                 lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = v;
             }
             v4f ck[SE];
@@ -633,7 +768,7 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
             if (lane < edge) {
                 const long long pj = T + lane;
                 if (pj >= tile && pj < tile + TILE) {
-                    if (a.rectify) { ra = a.gain * fabsf(ra); rb = a.gain * fabsf(rb); }
+                    if (a.rectify) { ra = fabsf(ra); rb = fabsf(rb); }
                     ldsf[lds_float_index((int)(pj - tile))] = 2.f * ra - rb;
                 }
             }
@@ -641,8 +776,7 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 float4 v = load_four(in, tile + 256 * k + 4 * lane, T);
-                if (a.rectify)
-                    v = make_float4(a.gain * fabsf(v.x), a.gain * fabsf(v.y), a.gain * fabsf(v.z), a.gain * fabsf(v.w));
+                if (a.rectify) v = make_float4(fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w));
                 lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = v;
             }
 #pragma unroll
@@ -655,7 +789,7 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
                 const long long pj = T + lane;
                 if (pj >= tile && pj < tile + TILE) {
                     float ra = in[T - 1], rb = in[T - 2 - lane];
-                    if (a.rectify) { ra = a.gain * fabsf(ra); rb = a.gain * fabsf(rb); }
+                    if (a.rectify) { ra = fabsf(ra); rb = fabsf(rb); }
                     ldsf[lds_float_index((int)(pj - tile))] = 2.f * ra - rb;
                 }
             }
@@ -674,7 +808,9 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
 #define CASC_CARRY cfw_
 #define CASC_IN(v) (v)
 #define CASC_PIN_GROUPS PIN
+#define CASC_GAIN a.gain
 #include "sos_cascade.inc"
+#undef CASC_GAIN
 #undef CASC_CARRY
         __syncthreads();
         TRACE_AT(2);                               // forward cascade
@@ -756,16 +892,17 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
 }
 
 // ---- building blocks of sosfiltfilt for cascades longer than one plan (hipdsp_envelope_multi) -------
-// ext = odd extension of r = gain * |x| (or x) by `edge` samples on both sides (scipy odd_ext,
-// scipy/signal/_arraytools.py:99-107), float32 arithmetic like the fused kernels
+// ext = odd extension of r = |x| (or x) by `edge` samples on both sides (scipy odd_ext,
+// scipy/signal/_arraytools.py:99-107), float32 arithmetic like the fused kernels; the gain of the rectified trace
+// rides on the first plan's cascade (SeqArgs::gain)
 __global__ void odd_ext_kernel(const float *__restrict__ x, long long x_pitch, long long T, int edge, int rectify,
-                               float gain, float *__restrict__ out, long long out_pitch)
+                               float *__restrict__ out, long long out_pitch)
 {
     const long long ch = blockIdx.y;
     const float *xc = x + ch * x_pitch;
     float *oc = out + ch * out_pitch;
     const long long N = T + 2LL * edge;
-    auto r = [&](long long k) { const float v = xc[k]; return rectify ? gain * fabsf(v) : v; };
+    auto r = [&](long long k) { const float v = xc[k]; return rectify ? fabsf(v) : v; };
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
         float v;
         if (i < edge) v = 2.f * r(0) - r(edge - i);
@@ -949,8 +1086,9 @@ template <int SF, int SE, int NP, bool FLAGS, bool DB, int NFFT = 2048, int HOP 
 __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPlanDev *__restrict__ PF0,
                                                                    const SosPlanDev *__restrict__ PE0, ChainArgs a)
 {
-    static_assert(SF > 0 && NP % 2 == 0, "band-pass in front; whole waves per SIMD");
-    constexpr int DF = 2 * SF, DE = 2 * SE;
+    // SE == 0: no envelope behind the filter (the reference's default trace set, plugins.py:11-13: filter + spectrogram)
+    static_assert(SF > 0 && SE >= 0 && NP % 2 == 0, "band-pass in front; whole waves per SIMD");
+    constexpr int DF = 2 * SF, DE = SE > 0 ? 2 * SE : 1;
     static_assert((NFFT == 2048 || NFFT == 1024 || NFFT == 512 || NFFT == 256) && TILE % HOP == 0 && HOP % 128 == 0 &&
                   HOP <= NFFT && NFFT <= TILE, "frames must be register windows of a tile");
     static_assert(NFFT != 256 || HOP == 128, "256-sample frames: the reference's default, 50 % overlap");
@@ -1046,9 +1184,9 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
     long long hi = lo + a.c.seg_len;
     const bool last_seg = hi >= T;
     if (hi > T) hi = T;
-    long long env_start = lo - PE0->warm;
-    const bool env_true = env_start <= 0;
-    if (env_start < 0) env_start = 0;
+    // no envelope warm-up: zero-state tile states + env_fix_kernel, exactly as in sos_ckpt_kernel
+    const long long env_start = lo;
+    const bool env_true = seg == 0;
     long long start = env_start - PF0->warm;
     if (start < 0) start = 0;
     long long loop_end = last_seg ? T + edge : hi;
@@ -1077,7 +1215,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
         float *rprev = rprevs[pair];
         const float *in = a.c.in + ch * a.c.in_pitch;
         float *yf = a.c.yf + ch * a.c.yf_pitch;
-        double *ckpt = a.c.ckpt + ch * a.c.ckpt_pitch;
+        double *ckpt = SE > 0 ? a.c.ckpt + ch * a.c.ckpt_pitch : nullptr;
         double cf_[DF], ce_[DE];
 #pragma unroll
         for (int r = 0; r < DF; r++) cf_[r] = 0.0;
@@ -1142,17 +1280,17 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             // Phase 1 of the envelope cascade rides on phase 3 of the band-pass: every filtered sample is
             // multiplied into the envelope's G table while it is still a register -- |y| as a source modifier of
             // the float64 multiply-add, the gain once per tile on the sums -- so that a quiet tile needs neither a
-            // pass over the tile in LDS nor a conversion or a multiplication per sample.  (The value is the
-            // band-pass output BEFORE its rounding to float32: the tile states then belong to inputs that differ
-            // from what the backward sweep recomputes from by 6e-8 relative, i.e. by less than the float32
-            // rounding of the filtered trace itself.)  Tiles that are not quiet (odd extension in reach,
-            // envelope warm-up not begun) ignore the result and take the path through LDS.
+            // pass over the tile in LDS nor a conversion or a multiplication per sample.  The value is the
+            // band-pass output AFTER its rounding to float32, converted back: the filtered trace in HBM is what the
+            // backward sweep recomputes the forward cascade from, so states and recomputation see the same input
+            // (ADVICE round 2).  Tiles that are not quiet (odd extension in reach) ignore the result and take the
+            // path through LDS.
             double etap[DE];
 #pragma unroll
             for (int r = 0; r < DE; r++) etap[r] = 0.0;
             if (active && !(a.debug & 2)) {
-                const float tgain = a.c.gain;
-                const SosPlanDev *PEt = PLAN_OF(PE0);
+                const double tgain = a.c.gain;
+                const SosPlanDev *PEt = PLAN_OF(SE > 0 ? PE0 : PF0);
 #define CASC_S SF
 #define CASC_PLAN() PLAN_OF(PF0)
 #define CASC_CARRY cf_
@@ -1161,9 +1299,11 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
 #define CASC_STAMP(n) STAMP_AT(1 + (n))
 #define CASC_TAP(j, e, y)                                                               \
     do {                                                                                \
-        if (((j) & 3) == 0) PEt = PLAN_OF(PE0);                                         \
-        const double rd_ = fabs(y);                                                      \
-        _Pragma("unroll") for (int r_ = 0; r_ < DE; r_++) etap[r_] = fma(PEt->G[(j) * DE + r_], rd_, etap[r_]); \
+        if constexpr (SE > 0) {                                                         \
+            if (((j) & 3) == 0) PEt = PLAN_OF(PE0);                                     \
+            const double rd_ = fabs((double)(e));                                        \
+            _Pragma("unroll") for (int r_ = 0; r_ < DE; r_++) etap[r_] = fma(PEt->G[(j) * DE + r_], rd_, etap[r_]); \
+        }                                                                               \
     } while (0)
 #include "sos_cascade.inc"
 #undef CASC_TAP
@@ -1174,7 +1314,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
 #undef CASC_CARRY
 #undef CASC_IN
 #pragma unroll
-                for (int r = 0; r < DE; r++) etap[r] *= (double)tgain;
+                for (int r = 0; r < DE; r++) etap[r] *= tgain;
             }
             WAVE_SYNC();
             if (FLAGS) { if (active) CHAIN_POST(ready, it + 1); }
@@ -1201,18 +1341,22 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             // An interior tile of the envelope sweep (neither it nor the next one touches T, no left
             // extension) is not modified any more: the rectification rides on the cascade's input
             // and, with the flags, H2 is only needed before the NEXT tile goes into LDS.
-            const bool quiet = active && tile >= env_start && a.c.rectify && tile + 2 * TILE <= T &&
-                               !(env_true && tile == 0) && tile + TILE < loop_end && !(a.debug & 2);
+            // (the last tile of a segment that is not the trace's last advances the state too: its end state is handed
+            // to the next segment by env_fix_kernel)
+            const bool last_tile = tile + TILE >= loop_end;
+            const bool quiet = SE > 0 && active && tile >= env_start && a.c.rectify && tile + 2 * TILE <= T &&
+                               !(env_true && tile == 0) && (!last_tile || !last_seg) && !(a.debug & 2);
             if (FLAGS) {
                 if (active) {
-                    if (quiet) pending = it + 1;
+                    if (quiet || SE == 0) pending = it + 1;
                     else CHAIN_WAIT_FOR(taken, it + 1, it);
                 }
             } else {
                 __syncthreads();                               // B2: the FFT wave has its copy
             }
+            if constexpr (SE > 0) {
             if (quiet) {
-                if (tile >= lo && lane == 0) {
+                if ((tile > lo || env_true) && lane == 0) {
 #pragma unroll
                     for (int r = 0; r < DE; r++) ckpt[(tile / TILE) * DE + r] = ce_[r];
                 }
@@ -1233,15 +1377,18 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
 #undef CASC_PLAN
 #undef CASC_CARRY
 #undef CASC_IN
+                if (last_tile && lane == 0) {
+#pragma unroll
+                    for (int r = 0; r < DE; r++) ckpt[(tile / TILE + 1) * DE + r] = ce_[r];
+                }
                 WAVE_SYNC();
             } else if (active && tile >= env_start && !(a.debug & 2)) {
-                // ---- envelope input in place: r = gain*|y|, then the odd extension past T
+                // ---- envelope input in place: r = |y| (the gain rides on the cascade), then the odd extension past T
                 if (a.c.rectify) {
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
                         float4 v = lds[lds_slot(lane, q)];
-                        v = make_float4(a.c.gain * fabsf(v.x), a.c.gain * fabsf(v.y), a.c.gain * fabsf(v.z),
-                                        a.c.gain * fabsf(v.w));
+                        v = make_float4(fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w));
                         lds[lds_slot(lane, q)] = v;
                     }
                 }
@@ -1262,12 +1409,12 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                 }
                 if (env_true && tile == 0) {
                     const SosPlanDev *Pz = PLAN_OF(PE0);
-                    const float r0 = ldsf[lds_float_index(0)];
-                    const double x0 = (double)(2.f * r0 - ldsf[lds_float_index(edge)]);
+                    const double r0 = (double)ldsf[lds_float_index(0)];
+                    const double x0 = a.c.gain * (2.0 * r0 - (double)ldsf[lds_float_index(edge)]);
 #pragma unroll
                     for (int r = 0; r < DE; r++) ce_[r] = Pz->zi[r] * x0;
                     for (int i = 0; i < edge; i++) {
-                        double cur = (double)(2.f * r0 - ldsf[lds_float_index(edge - i)]);
+                        double cur = a.c.gain * (2.0 * r0 - (double)ldsf[lds_float_index(edge - i)]);
 #pragma unroll
                         for (int s2 = 0; s2 < SE; s2++) {
                             const double y = fma(Pz->coef[s2][0], cur, ce_[2 * s2]);
@@ -1277,11 +1424,11 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                         }
                     }
                 }
-                if (tile >= lo && lane == 0) {
+                if ((tile > lo || env_true) && lane == 0) {
 #pragma unroll
                     for (int r = 0; r < DE; r++) ckpt[(tile / TILE) * DE + r] = ce_[r];
                 }
-                if (tile + TILE < loop_end) {
+                if (!last_tile || !last_seg) {
                     {
                         const float4 keep0 = lds[lds_slot(62 + ((lane >> 3) & 1), lane & 7)];
                         WAVE_SYNC();
@@ -1294,18 +1441,25 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
 #define CASC_PLAN() PLAN_OF(PE0)
 #define CASC_CARRY ce_
 #define CASC_IN(v) (v)
+#define CASC_GAIN a.c.gain
 #define CASC_NO_OUTPUT
 #define CASC_ROLLED_GROUPS
 #include "sos_cascade.inc"
 #undef CASC_ROLLED_GROUPS
 #undef CASC_NO_OUTPUT
+#undef CASC_GAIN
 #undef CASC_S
 #undef CASC_PLAN
 #undef CASC_CARRY
 #undef CASC_IN
+                    if (last_tile && lane == 0) {
+#pragma unroll
+                        for (int r = 0; r < DE; r++) ckpt[(tile / TILE + 1) * DE + r] = ce_[r];
+                    }
                 }
                 WAVE_SYNC();
             }
+            }   // SE > 0
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last (dummy) prefetch
         STAMP_AT(7);
@@ -1558,7 +1712,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_bwd_kernel(const SosPl
             fetch(pre ? t0 : top_full);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        const float rgain = a.b.gain;
+        const double rgain = a.b.gain;
         int it = 0;
         for (long long rt = rt_start; rt < rt_hi; rt++) {
             it++;
@@ -1618,7 +1772,8 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_bwd_kernel(const SosPl
 #define CASC_S SE
 #define CASC_PLAN() PLAN_OF(P0)
 #define CASC_CARRY cfw_
-#define CASC_IN(v) (a.b.rectify ? rgain * fabsf(v) : (v))
+#define CASC_IN(v) (a.b.rectify ? fabsf(v) : (v))
+#define CASC_GAIN rgain
 #define CASC_ROLLED_GROUPS
 #define CASC_STAMP(n) do { if ((n) == 1) CHAIN_WAIT_FOR(taken, it, it); } while (0)
 #include "sos_cascade.inc"
@@ -1631,7 +1786,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_bwd_kernel(const SosPl
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
                         float4 v = lds[lds_slot(lane, q)];
-                        v = make_float4(rgain * fabsf(v.x), rgain * fabsf(v.y), rgain * fabsf(v.z), rgain * fabsf(v.w));
+                        v = make_float4(fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w));
                         lds[lds_slot(lane, q)] = v;
                     }
                 }
@@ -1645,7 +1800,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_bwd_kernel(const SosPl
                 if (lane < edge) {
                     const long long pj = T + lane;
                     if (pj >= tile && pj < tile + TILE) {
-                        if (a.b.rectify) { ra = rgain * fabsf(ra); rb = rgain * fabsf(rb); }
+                        if (a.b.rectify) { ra = fabsf(ra); rb = fabsf(rb); }
                         ldsf[lds_float_index((int)(pj - tile))] = 2.f * ra - rb;
                     }
                 }
@@ -1668,7 +1823,8 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_bwd_kernel(const SosPl
                 for (int r = 0; r < DE; r++) cb_[r] = P->zi[r] * (double)v0;
                 WAVE_SYNC();
             }
-            // ---- backward cascade over the forward outputs, last sample first
+            // ---- backward cascade over the forward outputs, last sample first (the gain belongs to the forward one)
+#undef CASC_GAIN
 #define CASC_CARRY cb_
 #define CASC_IN(v) (v)
 #define CASC_REVERSED
@@ -1866,6 +2022,8 @@ int fill_plan(SosPlanDev *p, const double *sos, int S)
             for (int c = 0; c < D; c++) p->M[k * D * D + r * D + c] = pw.v[r][c];
         pw = mat_mul(pw, pw);
     }
+    for (int r = 0; r < D; r++)
+        for (int c = 0; c < D; c++) p->AT[r * D + c] = pw.v[r][c];
     // pw == A^(L*64) == A^TILE.  warm = TILE * (smallest m with ||A^(TILE*m)|| < 2^-60)
     const double tol = ldexp(1.0, -60);
     const int MAXBITS = 40;
@@ -1953,6 +2111,7 @@ void plan_segments(const hipdsp_ctx *ctx, long long N, long long channels, long 
 
 int launch_scan(hipdsp_ctx *ctx, const SosPlanDev *dev, int S, SeqArgs a, long long channels, long long warm)
 {
+    if (a.gain == 0.0) a.gain = 1.0;
     plan_segments(ctx, a.N, channels, warm, &a.seg_len, &a.n_seg);
     long long blocks = channels * a.n_seg;
     if (blocks > 0x7fffffffLL) {
@@ -1989,8 +2148,10 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
         memset(&fa, 0, sizeof(fa));
         fa.in = x; fa.yf = yf; fa.ckpt = (double *)work;
         fa.in_pitch = x_pitch; fa.yf_pitch = yf_pitch; fa.ckpt_pitch = ckpt_pitch;
-        fa.T = frames; fa.edge = edge; fa.rectify = rectify; fa.gain = (float)gain;
-        long long warm = warmF + warmE;
+        fa.T = frames; fa.edge = edge; fa.rectify = rectify; fa.gain = rectify ? gain : 1.0;
+        // only the band-pass warms up; the envelope's states are handed over exactly (env_fix_kernel), which needs
+        // a cascade that forgets (a plan that does not decay is never cut into segments)
+        long long warm = warmF;
         if (warmF >= (1LL << 40) || warmE >= (1LL << 40)) warm = 1LL << 50;
         plan_segments(ctx, frames, channels, warm, &fa.seg_len, &fa.n_seg);
         long long blocks = channels * fa.n_seg;
@@ -2017,6 +2178,8 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
 #undef HD_CKPT
         rc = hd_launch_status("sos_ckpt_kernel");
         if (rc != HIPDSP_OK) return rc;
+        rc = launch_env_fix(ctx, edev, SE, (double *)work, ckpt_pitch, channels, fa.n_seg, fa.seg_len, n_tiles);
+        if (rc != HIPDSP_OK) return rc;
     }
     if (phase == 1) return HIPDSP_OK;
     if (ctx->mid_event) HD_CHECK_HIP(hipEventRecord(ctx->mid_event, ctx->stream));
@@ -2027,7 +2190,7 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
     b.out = env; b.out_pitch = env_pitch;
     b.ckpt = (const double *)work; b.ckpt_pitch = ckpt_pitch;
     b.T = frames; b.skip = skip; b.n_tiles = n_tiles; b.edge = edge;
-    b.rectify = rectify; b.clamp = clamp; b.gain = (float)gain;
+    b.rectify = rectify; b.clamp = clamp; b.gain = rectify ? gain : 1.0;
     b.trace = ctx->sos_trace;
     b.fair = ctx->sos_fair;
     const long long used_tiles = n_tiles - skip / TILE;      // tiles below `skip` are never visited
@@ -2238,18 +2401,20 @@ int hipdsp_sosfilt_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const 
 int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hipdsp_sosplan *eplan,
                          const float *x, int64_t x_pitch, float *yf, int64_t yf_pitch, int64_t channels,
                          int64_t frames, int rectify, double gain, int nfft, int hop, double fs, float *psd,
-                         float *db_out, int64_t frames_out, int64_t psd_pitch)
+                         float *db_out, int64_t frames_out, int64_t psd_pitch, int64_t spec_frames)
 {
-    HD_REQUIRE(ctx != nullptr && fplan != nullptr && eplan != nullptr, "NULL argument");
+    HD_REQUIRE(ctx != nullptr && fplan != nullptr, "NULL argument");
     HD_REQUIRE(channels >= 0 && frames >= 0 && frames_out >= 0, "negative size");
+    HD_REQUIRE(spec_frames >= 0 && spec_frames <= frames, "spec_frames %lld not in [0, frames=%lld]",
+               (long long)spec_frames, (long long)frames);
     HD_REQUIRE(fs > 0, "fs must be positive");
-    const int SF = fplan->host->n_sections, SE = eplan->host->n_sections;
-    HD_REQUIRE(SF > 0 && SE > 0, "plan has no coefficients");
+    const int SF = fplan->host->n_sections, SE = eplan ? eplan->host->n_sections : 0;
+    HD_REQUIRE(SF > 0 && (SE > 0 || eplan == nullptr), "plan has no coefficients");
     // shapes the kernel is built for: frames that are register windows of a 2048-sample tile
     const bool shape_ok = (nfft == 2048 && (hop == 1024 || hop == 512)) || (nfft == 1024 && (hop == 512 || hop == 256)) ||
                           (nfft == 512 && hop == 256) || (nfft == 256 && hop == 128);
     if (!shape_ok || SF > 4 || SE > 2 || frames < 4 * TILE ||
-        fplan->host->warm >= (1LL << 40) || eplan->host->warm >= (1LL << 40)) {
+        fplan->host->warm >= (1LL << 40) || (eplan && eplan->host->warm >= (1LL << 40))) {
         hipdsp_set_error("the fused forward sweep covers nfft/hop 2048/1024, 2048/512, 1024/512, 1024/256, 512/256 and 256/128, a band-pass of "
                          "at most four and an envelope of at most two sections that decay, and traces of at least %d "
                          "frames: use hipdsp_sosfilt_envelope + hipdsp_spectrogram", 4 * TILE);
@@ -2264,7 +2429,7 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
         const int frc = hd_device_fault(ctx);
         if (frc != HIPDSP_OK) return frc;
     }
-    const int edge = eplan->host->edge;
+    const int edge = eplan ? eplan->host->edge : 0;
     if (channels == 0) return HIPDSP_OK;
     HD_REQUIRE(channels <= 65535, "more than 65535 channels");     // grid.y of the zero-tail launch
     HD_REQUIRE(x != nullptr && yf != nullptr && (psd != nullptr || frames_out == 0), "NULL data pointer");
@@ -2272,9 +2437,11 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     const long long F = nfft / 2 + 1;
     if (psd_pitch == 0) psd_pitch = frames_out * F;
     HD_REQUIRE(psd_pitch >= frames_out * F, "psd_pitch smaller than one channel");
-    // frames inside the trace, as in hipdsp_spectrogram (bufferedspectrogram.py:46-49)
+    // frames inside the trace, as in hipdsp_spectrogram (bufferedspectrogram.py:46-49); the spectrogram may be
+    // handed fewer samples than the filter produces (spec_frames: BufferedData.load_buffer's one frame "after")
+    const long long sframes = spec_frames > 0 ? spec_frames : frames;
     long long nsource = (frames_out - 1) * (long long)hop + nfft;
-    if (nsource > frames) nsource = frames;
+    if (nsource > sframes) nsource = sframes;
     long long n_valid = 0;
     if (frames_out > 0 && nsource >= nfft) n_valid = (nsource - (nfft - hop)) / hop;
     if (n_valid > frames_out) n_valid = frames_out;
@@ -2290,14 +2457,16 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     const long long n_tiles = (frames + edge + TILE - 1) / TILE;
     const long long ckpt_pitch = n_tiles * 2 * SE;                 // the layout the backward sweep expects
     void *work = nullptr;
-    rc = hipdsp_scratch(ctx, sizeof(double) * (size_t)ckpt_pitch * (size_t)channels, &work);
-    if (rc != HIPDSP_OK) return rc;
+    if (SE > 0) {
+        rc = hipdsp_scratch(ctx, sizeof(double) * (size_t)ckpt_pitch * (size_t)channels, &work);
+        if (rc != HIPDSP_OK) return rc;
+    }
     a.c.in = x; a.c.yf = yf; a.c.ckpt = (double *)work;
     a.c.in_pitch = x_pitch; a.c.yf_pitch = yf_pitch; a.c.ckpt_pitch = ckpt_pitch;
-    a.c.T = frames; a.c.edge = edge; a.c.rectify = rectify; a.c.gain = (float)gain;
+    a.c.T = frames; a.c.edge = edge; a.c.rectify = rectify; a.c.gain = rectify ? gain : 1.0;
     a.psd = psd; a.db = db_out; a.psd_pitch = psd_pitch; a.n_valid = n_valid;
     a.scale = (float)(1.0 / (fs * wss));
-    a.warm_total = fplan->host->warm + eplan->host->warm;
+    a.warm_total = fplan->host->warm;              // the envelope's states are handed over exactly (env_fix_kernel)
     a.debug = ctx->chain_debug;
     a.fault = ctx->fault_dev;
     a.split = (ctx->chain_split_frames && nfft == 2048 && hop == 1024 && !db_out) ? 1 : 0;
@@ -2319,11 +2488,12 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
                                db_out + n_valid * F, (long long)psd_pitch, n, -INFINITY);
     }
     dim3 grid((unsigned)blocks), block(128 * P);
+    const SosPlanDev *edev_ = eplan ? eplan->dev : nullptr;
     const bool flags = (ctx->chain_debug & 4) == 0;       // bit 4: workgroup barriers instead of the pairwise flags
     if ((ctx->chain_debug & 32) && db_out && SF == 2 && SE == 1 && flags && nfft == 2048 && hop == 1024) {
         // diagnostic build: db_out receives 16 clock sums per wave (needs >= blocks * 16 * 16 * 8 bytes)
         hipLaunchKernelGGL((chain_fwd_kernel<2, 1, P, true, false, 2048, 1024, true>), grid, block, 0, ctx->stream,
-                           fplan->dev, eplan->dev, a);
+                           fplan->dev, edev_, a);
         return hd_launch_status("chain_fwd_kernel");
     }
     // nfft 2048 / hop 1024 with plans of up to two sections: every variant (barriers for the tests, fused dB
@@ -2331,35 +2501,37 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
 #define HD_CHAIN_FULL(A, B)                                                                                         \
     case (A) * 8 + (B):                                                                                            \
         if (db_out) {                                                                                              \
-            if (flags) hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, true>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);  \
-            else hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, false, true>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);       \
+            if (flags) hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, true>), grid, block, 0, ctx->stream, fplan->dev, edev_, a);  \
+            else hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, false, true>), grid, block, 0, ctx->stream, fplan->dev, edev_, a);       \
         } else {                                                                                                   \
-            if (flags) hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, false>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a); \
-            else hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, false, false>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);      \
+            if (flags) hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, false>), grid, block, 0, ctx->stream, fplan->dev, edev_, a); \
+            else hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, false, false>), grid, block, 0, ctx->stream, fplan->dev, edev_, a);      \
         }                                                                                                          \
         break
 #define HD_CHAIN_LONG(A, B)                                                                                         \
     case (A) * 8 + (B):                                                                                            \
-        if (db_out) hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, true>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a); \
-        else hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, false>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a);       \
+        if (db_out) hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, true>), grid, block, 0, ctx->stream, fplan->dev, edev_, a); \
+        else hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, false>), grid, block, 0, ctx->stream, fplan->dev, edev_, a);       \
         break
 #define HD_CHAIN_SHAPE(A, B, N, H)                                                                                  \
     case (A) * 8 + (B):                                                                                            \
-        hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, false, N, H>), grid, block, 0, ctx->stream, fplan->dev, eplan->dev, a); \
+        hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, false, N, H>), grid, block, 0, ctx->stream, fplan->dev, edev_, a); \
         break
 #define HD_CHAIN_ALL(N, H)                                                                                          \
     switch (SF * 8 + SE) {                                                                                         \
+        HD_CHAIN_SHAPE(1, 0, N, H); HD_CHAIN_SHAPE(2, 0, N, H); HD_CHAIN_SHAPE(3, 0, N, H); HD_CHAIN_SHAPE(4, 0, N, H); \
         HD_CHAIN_SHAPE(1, 1, N, H); HD_CHAIN_SHAPE(1, 2, N, H); HD_CHAIN_SHAPE(2, 1, N, H); HD_CHAIN_SHAPE(2, 2, N, H); \
         HD_CHAIN_SHAPE(3, 1, N, H); HD_CHAIN_SHAPE(3, 2, N, H); HD_CHAIN_SHAPE(4, 1, N, H); HD_CHAIN_SHAPE(4, 2, N, H); \
     }
     if (nfft == 2048 && hop == 1024) {
-        if ((!flags) && (SF > 2)) {
-            hipdsp_set_error("the barrier variant of the fused sweep is built for plans of at most two sections");
+        if ((!flags) && (SF > 2 || SE == 0)) {
+            hipdsp_set_error("the barrier variant of the fused sweep is built for plans of one or two sections");
             return HIPDSP_ERR_UNSUPPORTED;
         }
         switch (SF * 8 + SE) {
             HD_CHAIN_FULL(1, 1); HD_CHAIN_FULL(1, 2); HD_CHAIN_FULL(2, 1); HD_CHAIN_FULL(2, 2);
             HD_CHAIN_LONG(3, 1); HD_CHAIN_LONG(3, 2); HD_CHAIN_LONG(4, 1); HD_CHAIN_LONG(4, 2);
+            HD_CHAIN_LONG(1, 0); HD_CHAIN_LONG(2, 0); HD_CHAIN_LONG(3, 0); HD_CHAIN_LONG(4, 0);
         }
     } else if (nfft == 2048 && hop == 512) {
         HD_CHAIN_ALL(2048, 512)
@@ -2376,7 +2548,9 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
 #undef HD_CHAIN_LONG
 #undef HD_CHAIN_SHAPE
 #undef HD_CHAIN_ALL
-    return hd_launch_status("chain_fwd_kernel");
+    rc = hd_launch_status("chain_fwd_kernel");
+    if (rc != HIPDSP_OK || SE == 0) return rc;
+    return launch_env_fix(ctx, eplan->dev, SE, (double *)work, ckpt_pitch, channels, a.c.n_seg, a.c.seg_len, n_tiles);
 }
 
 int hipdsp_envelope_multi(hipdsp_ctx *ctx, const hipdsp_sosplan *const *plans, int n_plans, const float *x,
@@ -2428,7 +2602,8 @@ int hipdsp_envelope_multi(hipdsp_ctx *ctx, const hipdsp_sosplan *const *plans, i
     const unsigned gx = (unsigned)((N + 1023) / 1024 > 4096 ? 4096 : (N + 1023) / 1024);
     const dim3 grid(gx, (unsigned)channels);
     hipLaunchKernelGGL(odd_ext_kernel, grid, dim3(256), 0, ctx->stream, x, (long long)x_pitch, (long long)frames, edge,
-                       rectify, (float)gain, buf[0], N);
+                       rectify, buf[0], N);
+    const double in_gain = rectify ? gain : 1.0;           // what the forward pass is fed is in_gain * buf[0]
     int cur = 0;
     for (int pass = 0; pass < 2 && rc == HIPDSP_OK; pass++) {
         // initial state of every section: its zi times the first sample of what the whole cascade is fed
@@ -2439,7 +2614,9 @@ int hipdsp_envelope_multi(hipdsp_ctx *ctx, const hipdsp_sosplan *const *plans, i
             memset(&a, 0, sizeof(a));
             a.in = buf[cur]; a.out = buf[cur ^ 1]; a.in_pitch = N; a.out_pitch = N;
             a.N = N; a.skip = 0;
-            a.zi_ref = ref; a.zi_ref_pitch = 1; a.zi_scale = gain_before[p];
+            // forward pass: the input gain on the first plan's numerator, and in every plan's initial state
+            a.zi_ref = ref; a.zi_ref_pitch = 1; a.zi_scale = gain_before[p] * (pass == 0 ? in_gain : 1.0);
+            a.gain = (pass == 0 && p == 0) ? in_gain : 1.0;
             rc = launch_scan(ctx, plans[p]->dev, plans[p]->host->n_sections, a, channels, plans[p]->host->warm);
             cur ^= 1;
         }
@@ -2514,7 +2691,7 @@ int hipdsp_chain_backward(hipdsp_ctx *ctx, const hipdsp_sosplan *eplan, const fl
     a.b.out = env; a.b.out_pitch = env_pitch;
     a.b.ckpt = (const double *)work; a.b.ckpt_pitch = ckpt_pitch;
     a.b.T = frames; a.b.skip = 0; a.b.n_tiles = n_tiles; a.b.edge = edge;
-    a.b.rectify = rectify; a.b.clamp = clamp; a.b.gain = (float)gain;
+    a.b.rectify = rectify; a.b.clamp = clamp; a.b.gain = rectify ? gain : 1.0;
     constexpr int P = 8;
     long long seg_len = 0;
     plan_segments_for((long long)(ctx->n_cus - ctx->chain_reserve_cus) * P, ctx->max_segments, n_tiles * TILE, channels,
@@ -2556,14 +2733,14 @@ int hipdsp_chain_backward_plan(hipdsp_ctx *ctx, const hipdsp_sosplan *eplan, int
 int hipdsp_chain_plan(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hipdsp_sosplan *eplan,
                       int64_t channels, int64_t frames, int64_t *segment_frames, int *n_segments)
 {
-    HD_REQUIRE(ctx != nullptr && fplan != nullptr && eplan != nullptr, "NULL argument");
+    HD_REQUIRE(ctx != nullptr && fplan != nullptr, "NULL argument");      // (eplan may be NULL: no envelope)
     HD_REQUIRE(segment_frames != nullptr && n_segments != nullptr, "NULL output");
     HD_REQUIRE(channels >= 1 && frames >= 1, "bad size");
-    HD_REQUIRE(fplan->host->n_sections > 0 && eplan->host->n_sections > 0, "plan has no coefficients");
+    HD_REQUIRE(fplan->host->n_sections > 0 && (eplan == nullptr || eplan->host->n_sections > 0), "plan has no coefficients");
     long long len = 0;
     int n = 0;
     plan_segments_for((long long)(ctx->n_cus - ctx->chain_reserve_cus) * 8, ctx->max_segments, frames, channels,
-                      fplan->host->warm + eplan->host->warm, &len, &n);
+                      fplan->host->warm, &len, &n);
     *segment_frames = len;
     *n_segments = n;
     return HIPDSP_OK;

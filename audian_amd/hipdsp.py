@@ -285,13 +285,24 @@ def _plan(plan):
     return plan.handle if plan is not None else ctypes.c_void_p(0)
 
 
+# How often each hot-path entry point has been called in this process: tests (and integrators) read these to see
+# WHICH launches a BufferedData.recompute_all() turned into (e.g. that the fused forward sweep ran).
+launches = {}
+
+
+def _count(name):
+    launches[name] = launches.get(name, 0) + 1
+
+
 def sosfilt(ctx, plan, x, x_pitch, y, y_pitch, channels, frames, skip=0):
+    _count('sosfilt')
     check(lib.hipdsp_sosfilt(ctx.handle, _plan(plan), _p(x), int(x_pitch), _p(y), int(y_pitch),
                              int(channels), int(frames), int(skip)))
 
 
 def envelope(ctx, plan, x, x_pitch, y, y_pitch, channels, frames, skip=0, rectify=True,
              gain=np.pi/2, clamp=True):
+    _count('envelope')
     check(lib.hipdsp_envelope(ctx.handle, _plan(plan), _p(x), int(x_pitch), _p(y), int(y_pitch),
                               int(channels), int(frames), int(skip), int(bool(rectify)),
                               float(gain), int(bool(clamp))))
@@ -301,6 +312,7 @@ def envelope_multi(ctx, plans, x, x_pitch, y, y_pitch, channels, frames, skip=0,
                    gain=np.pi/2, clamp=True):
     """sosfiltfilt envelope over a cascade split into several plans (hipdsp_envelope_multi)."""
     arr = (ctypes.c_void_p*len(plans))(*[p.handle for p in plans])
+    _count('envelope_multi')
     check(lib.hipdsp_envelope_multi(ctx.handle, arr, len(plans), _p(x), int(x_pitch), _p(y), int(y_pitch),
                                     int(channels), int(frames), int(skip), int(bool(rectify)), float(gain),
                                     int(bool(clamp))))
@@ -308,6 +320,7 @@ def envelope_multi(ctx, plans, x, x_pitch, y, y_pitch, channels, frames, skip=0,
 
 def sosfilt_envelope(ctx, fplan, eplan, x, x_pitch, yf, yf_pitch, env, env_pitch, channels, frames,
                      rectify=True, gain=np.pi/2, clamp=True, phase=0):
+    _count('sosfilt_envelope:%d' % phase)
     check(lib.hipdsp_sosfilt_envelope(ctx.handle, fplan.handle, eplan.handle, _p(x), int(x_pitch),
                                       _p(yf), int(yf_pitch), _p(env), int(env_pitch), int(channels),
                                       int(frames), int(bool(rectify)), float(gain), int(bool(clamp)),
@@ -315,14 +328,16 @@ def sosfilt_envelope(ctx, fplan, eplan, x, x_pitch, yf, yf_pitch, env, env_pitch
 
 
 def chain_forward(ctx, fplan, eplan, x, x_pitch, yf, yf_pitch, channels, frames, nfft, hop, fs, psd,
-                  frames_out, psd_pitch=0, rectify=True, gain=np.pi/2, db_out=None):
+                  frames_out, psd_pitch=0, rectify=True, gain=np.pi/2, db_out=None, spec_frames=0):
     """Band-pass + envelope state sweep + spectrogram of the filtered trace in one pass over x
     (nfft/hop 2048/1024, 2048/512, 1024/512, 1024/256, 512/256, 256/128; NotImplementedError otherwise).  The envelope follows with
-    sosfilt_envelope(..., phase=2)."""
-    check(lib.hipdsp_chain_forward(ctx.handle, fplan.handle, eplan.handle, _p(x), int(x_pitch), _p(yf),
+    sosfilt_envelope(..., phase=2).  eplan None: no envelope (filter + spectrogram only); spec_frames: the
+    spectrogram is handed only that many samples of the filtered trace (0 = all)."""
+    _count('chain_forward')
+    check(lib.hipdsp_chain_forward(ctx.handle, fplan.handle, _plan(eplan), _p(x), int(x_pitch), _p(yf),
                                    int(yf_pitch), int(channels), int(frames), int(bool(rectify)),
                                    float(gain), int(nfft), int(hop), float(fs), _p(psd), _p(db_out),
-                                   int(frames_out), int(psd_pitch)))
+                                   int(frames_out), int(psd_pitch), int(spec_frames)))
 
 
 def chain_backward(ctx, eplan, yf, yf_pitch, env, env_pitch, channels, frames, nfft, hop, fs, psd, frames_out,
@@ -346,13 +361,14 @@ def chain_backward_plan(ctx, eplan, channels, frames):
 def chain_plan(ctx, fplan, eplan, channels, frames):
     """(segment_frames, n_segments) of chain_forward for this shape (hipdsp_chain_plan)."""
     seg, n = ctypes.c_int64(), ctypes.c_int()
-    check(lib.hipdsp_chain_plan(ctx.handle, fplan.handle, eplan.handle, int(channels), int(frames),
+    check(lib.hipdsp_chain_plan(ctx.handle, fplan.handle, _plan(eplan), int(channels), int(frames),
                                 ctypes.byref(seg), ctypes.byref(n)))
     return int(seg.value), int(n.value)
 
 
 def spectrogram(ctx, x, x_pitch, channels, frames, nfft, hop, fs, out, frames_out, db_out=None,
                 out_pitch=0):
+    _count('spectrogram')
     check(lib.hipdsp_spectrogram(ctx.handle, _p(x), int(x_pitch), int(channels), int(frames),
                                  int(nfft), int(hop), float(fs), _p(out), _p(db_out),
                                  int(frames_out), int(out_pitch)))

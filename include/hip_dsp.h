@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HIPDSP_VERSION 100          /* 0.1.0 */
+#define HIPDSP_VERSION 101          /* 0.1.1 */
 
 #define HIPDSP_OK               0
 #define HIPDSP_ERR_INVALID      1   /* bad argument */
@@ -277,12 +277,18 @@ int hipdsp_envelope_multi(hipdsp_ctx *ctx, const hipdsp_sosplan *const *plans, i
  * bufferedspectrogram.py:14-16) -- band-pass plans of up to four and envelope
  * plans of up to two decaying sections, and frames >= 8192; anything else returns HIPDSP_ERR_UNSUPPORTED
  * (use the separate calls).  psd layout, the zero tail and the optional db_out (decibel(psd), fused epilogue;
- * nfft 2048 / hop 1024 only) as in hipdsp_spectrogram. */
+ * nfft 2048 / hop 1024 only) as in hipdsp_spectrogram.
+ * eplan == NULL: no envelope behind the filter (the reference's default trace set is filter + spectrogram,
+ * src/audian/plugins.py:11-13) -- band-pass and spectrogram only, nothing is parked in the scratch.
+ * spec_frames: the spectrogram is handed only the first spec_frames samples of yf (0 = all `frames`): through
+ * BufferedData.load_buffer (buffereddata.py:91-109) BufferedSpectrogram.process sees its own frames times hop
+ * plus ONE sample of the filtered buffer, so its last frame(s) are zero although the filter has the samples;
+ * this is what lets one launch serve BufferedFilter.recompute_all() (buffereddata.py:149-153). */
 int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan,
                          const hipdsp_sosplan *eplan, const float *x, int64_t x_pitch, float *yf,
                          int64_t yf_pitch, int64_t channels, int64_t frames, int rectify,
                          double gain, int nfft, int hop, double fs, float *psd, float *db_out,
-                         int64_t frames_out, int64_t psd_pitch);
+                         int64_t frames_out, int64_t psd_pitch, int64_t spec_frames);
 
 /* Frame split of the batch chain (nfft 2048 / hop 1024): with the context option "chain_split_frames" set,
  * hipdsp_chain_forward writes only the EVEN frames 2t of psd (frame 2t is tile t of its sweep) and this call,

@@ -602,3 +602,149 @@ def test_random_walks_match_the_oracle_twins(oracle, seed):
         if step % 2 == 1 or action >= 4:
             compare(g, o)
     compare(g, o)
+
+
+def launches_during(fn):
+    """What hipdsp entry points `fn()` called (hipdsp.launches before / after)."""
+    from audian_amd import hipdsp
+    before = dict(hipdsp.launches)
+    fn()
+    return {k: v - before.get(k, 0) for k, v in hipdsp.launches.items() if v != before.get(k, 0)}
+
+
+@pytest.mark.parametrize('shape', ['configs2', 'configs4', 'default_session', 'envelope_only'])
+def test_update_takes_the_fused_launch(oracle, shape):
+    """BufferedFilter.update() -> recompute_all() (buffereddata.py:149-153, databrowser.py:1264-1288) issues ONE
+    forward launch that fills the filtered trace, the spectrogram and the envelope's tile states, plus the
+    envelope's backward sweep -- the path bench.py times -- instead of one launch per process(); results,
+    buffer_changed, spec_rect and frequencies are those of the separate calls (oracle twins)."""
+    from audian_amd.bufferedfilter import BufferedFilter
+    from audian_amd.bufferedenvelope import BufferedEnvelope
+    from audian_amd.bufferedspectrogram import BufferedSpectrogram
+    from audian_amd.tracegraph import TraceGraph
+    if shape == 'configs2':           # BASELINE configs[2]'s chain (2048 / 1024, order 2, envelope 20 Hz), reduced size
+        rate, secs, C, nfft, env_cut, traces = 96000.0, 4.0, 3, 2048, 20.0, 'fse'
+    elif shape == 'configs4':         # configs[4]'s: 192 kHz, the window of the streaming demo
+        rate, secs, C, nfft, env_cut, traces = 192000.0, 2.0, 4, 2048, 20.0, 'fse'
+    elif shape == 'default_session':  # plugins.py:11-13: filter + spectrogram(256, 50 %), no envelope
+        rate, secs, C, nfft, env_cut, traces = 48000.0, 3.0, 2, 256, None, 'fs'
+    else:
+        rate, secs, C, nfft, env_cut, traces = 48000.0, 3.0, 2, 256, 200.0, 'fe'
+    x = recording(rate, secs, C, seed=21)
+
+    def graph(classes):
+        F, E, S = classes
+        g = TraceGraph(secs, 0.0)             # the whole recording is resident
+        g.add_trace(F())
+        if 's' in traces:
+            g.add_trace(S(nfft=nfft))
+        if 'e' in traces:
+            g.add_trace(E(envelope_cutoff=env_cut))
+        g.setup_traces()
+        g.open(x, rate)
+        for t in g.traces:
+            t.plot_items = [Item() for _ in range(t.channels)]
+        g.set_need_update()
+        return g
+    g = graph((BufferedFilter, BufferedEnvelope, BufferedSpectrogram))
+    o = graph(oracle_twins(oracle))
+    g.update_times(0.0, secs)
+    o.update_times(0.0, secs)
+    for hp, lp in [(300.0, 3000.0), (500.0, 5000.0)]:
+        for twin in (g, o):
+            twin['filtered'].highpass_cutoff = hp
+            twin['filtered'].lowpass_cutoff = lp
+        for t in g.traces:
+            t.buffer_changed[:] = False
+        got = launches_during(g['filtered'].update)
+        o['filtered'].update()
+        if traces == 'fse':
+            assert got == {'chain_forward': 1, 'sosfilt_envelope:2': 1}, got
+        elif traces == 'fs':
+            assert got == {'chain_forward': 1}, got
+        else:
+            assert got == {'sosfilt_envelope:0': 1}, got
+        for name in ('filtered', 'envelope', 'spectrogram'):
+            a, b = g[name], o[name]
+            if a is None:
+                continue
+            assert np.all(a.buffer_changed) and a._stale == [[0, len(a._hostbuf)]], name
+            assert a.offset == b.offset and a.buffer.shape == b.buffer.shape, name
+            if name == 'spectrogram':
+                assert a.spec_rect == [a.offset/a.rate, 0, len(a.buffer)/a.rate, rate/2 + a.fresolution]
+                assert np.array_equal(a.frequencies, np.arange(a.nfft//2 + 1)*rate/a.nfft)
+                for ch in range(a.channels):
+                    for k in range(len(a.buffer)):
+                        want = b.buffer[k, ch]
+                        if np.max(np.abs(want)) == 0:
+                            assert np.all(a.buffer[k, ch] == 0), (k, ch)
+                        else:
+                            assert rel_err(a.buffer[k, ch], want) < TOL, (name, k, ch)
+            else:
+                for ch in range(a.channels):
+                    assert rel_err(a.buffer[:, ch], b.buffer[:, ch]) < TOL, (name, ch)
+    # what the fused launch does not cover keeps the separate process() calls: no filter set ...
+    for twin in (g, o):
+        twin['filtered'].highpass_cutoff = 0.0
+        twin['filtered'].lowpass_cutoff = rate/2
+    got = launches_during(g['filtered'].update)
+    o['filtered'].update()
+    assert 'chain_forward' not in got and got.get('sosfilt', 0) == 1, got
+    # ... and a window the sweep is not built for
+    if 's' in traces:
+        for twin in (g, o):
+            twin['filtered'].highpass_cutoff = 300.0
+            twin['filtered'].lowpass_cutoff = 3000.0
+            twin['filtered'].update()
+            twin['spectrogram'].update(nfft=4096, overlap_frac=0.5)
+        got = launches_during(g['filtered'].update)
+        o['filtered'].update()
+        assert 'chain_forward' not in got and got.get('spectrogram', 0) == 1, got
+        a, b = g['spectrogram'], o['spectrogram']
+        for ch in range(a.channels):
+            for k in range(len(a.buffer)):
+                want = b.buffer[k, ch]
+                if np.max(np.abs(want)) > 0:
+                    assert rel_err(a.buffer[k, ch], want) < TOL, (k, ch)
+    # a process() called alone still computes (the plugin hook)
+    f = g['filtered']
+    dest = np.zeros((len(x) - 3, C))
+    f.process(x, dest, 3)
+    want = np.zeros_like(dest)
+    oracle.filter_process(f.sos, x, want, 3)
+    assert rel_err(dest, want) < TOL
+
+
+def test_fused_launch_only_when_the_slabs_coincide(oracle):
+    """After a scroll into the recording the envelope's buffer starts one second later than the filtered
+    buffer (its pre-roll is trimmed, buffereddata.py:75-88): the reference then starts sosfiltfilt there, so the
+    envelope keeps its own call while the spectrogram still rides the filter's launch; at the start of the file all
+    three coincide again."""
+    from audian_amd.bufferedfilter import BufferedFilter
+    from audian_amd.bufferedenvelope import BufferedEnvelope
+    from audian_amd.bufferedspectrogram import BufferedSpectrogram
+    rate = 32000.0
+    x = recording(rate, 60.0, 2, seed=8)
+    g = build((BufferedFilter, BufferedEnvelope, BufferedSpectrogram), x, rate, 4.0, 1.0, nfft=512)
+    o = build(oracle_twins(oracle), x, rate, 4.0, 1.0, nfft=512)
+    for twin in (g, o):
+        twin['filtered'].highpass_cutoff = 300.0
+        twin['filtered'].lowpass_cutoff = 3000.0
+        twin['filtered'].update()
+    g.update_times(30.0, 32.0)
+    o.update_times(30.0, 32.0)
+    assert g['envelope'].offset > g['filtered'].offset > 0
+    got = launches_during(g['filtered'].update)
+    o['filtered'].update()
+    aligned = g['spectrogram']._load_geometry(g['spectrogram'].offset, len(g['spectrogram']._hostbuf))[0] == 0
+    if aligned:
+        assert got == {'chain_forward': 1, 'envelope': 1}, got
+    else:
+        assert got == {'sosfilt': 1, 'spectrogram': 1, 'envelope': 1}, got
+    compare(g, o)
+    g.update_times(0.0, 2.0)
+    o.update_times(0.0, 2.0)
+    got = launches_during(g['filtered'].update)
+    o['filtered'].update()
+    assert got == {'chain_forward': 1, 'sosfilt_envelope:2': 1}, got
+    compare(g, o)

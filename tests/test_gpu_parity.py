@@ -25,7 +25,7 @@ def synth(rng, n, channels, rate):
 
 def test_library_and_device():
     from audian_amd import _lib, hipdsp
-    assert _lib.lib.hipdsp_version() == 100
+    assert _lib.lib.hipdsp_version() == 101
     c = gh.ctx()
     a = hipdsp.DeviceArray.from_host(c, np.arange(10, dtype=np.float32))
     assert np.array_equal(a.to_host(), np.arange(10, dtype=np.float32))
