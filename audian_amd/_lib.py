@@ -104,7 +104,7 @@ _SIGNATURES = {
     'hipdsp_sosplan_set_host': ([_vp, _vp, _vp, _int], _int),
     'hipdsp_sosplan_upload': ([_vp, _vp], _int),
     'hipdsp_sos_plan_host': ([_vp, _int, ctypes.POINTER(_i64), ctypes.POINTER(_int), _vp], _int),
-    'hipdsp_sos_segments_host': ([_i64, _int, _i64, _i64, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_int)], _int),
+    'hipdsp_sos_segments_host': ([_i64, _int, _int, _int, _i64, _i64, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_int)], _int),
     'hipdsp_sosplan_info': ([_vp, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_int)], _int),
     'hipdsp_sosfilt': ([_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64], _int),
     'hipdsp_envelope': ([_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _dbl, _int], _int),

@@ -21,13 +21,17 @@ struct hipdsp_ctx {
     int force_generic_fft; // tests: use the generic radix-2 kernel for every nfft
     void *fft_tables2[20]; // same for the two-stage kernel: tw2 | twn | window
     int sos_waves_per_cu;  // experiments: resident waves per CU the IIR planner aims for
+    int sos_waves_min;     // experiments: the planner's "a wave is alone with its latency below this many per CU" (0 = 4)
+    int chain_pairs, chain_pairs_min;   // the same two numbers for the fused sweeps' pairs of waves (0 = 8 / 2)
+    int sos_single_wave_wg; // experiments (A/B): the envelope's backward sweep as single-wave workgroups, as in rounds 1-2
     int sos_prefetch;      // experiments: register prefetch of the next tile in the envelope sweeps
     int spec_no_half;      // experiments/tests: do not reuse the overlapped half frame
     int spec_fpw, spec_kernel;   // experiments (tools/), 0 = defaults
     int chain_debug;       // experiments: ablation bits of the fused forward kernel
     int chain_split_frames; // hipdsp_chain_forward writes only the even frames (hipdsp_chain_backward the odd ones)
     int chain_reserve_cus; // CUs hipdsp_chain_forward leaves without a workgroup (room for a co-resident RCCL kernel)
-    long long *sos_trace;  // diagnostics: device buffer (3 int64 per wave) the envelope's backward sweep reports into
+    long long *sos_trace;  // diagnostics: device buffer (9 int64 per WAVE of the envelope's backward sweep = channels x segments
+                           // rows, hipdsp_chain... sizes unknown to the library: the tool sizes it from the planned grid)
     int sos_fair;          // rotating issue priorities in the single-wave sweeps (sos.hip: rotate_issue_priority)
     int sos_no_pin;        // experiments: scalar table loads left to hipcc's just-in-time placement (A/B of CASC_PIN_GROUPS)
     struct hd_pool *pool;  // stream-ordered cache of freed device blocks (ctx.hip)

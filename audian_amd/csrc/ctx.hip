@@ -99,6 +99,10 @@ int hipdsp_ctx_create(int device, void *stream, hipdsp_ctx **out)
     ctx->chain_reserve_cus = 0;
     ctx->chain_split_frames = 0;
     ctx->sos_waves_per_cu = 0;
+    ctx->sos_waves_min = 0;
+    ctx->sos_single_wave_wg = 0;
+    ctx->chain_pairs = 0;
+    ctx->chain_pairs_min = 0;
     ctx->spec_no_half = 0;
     ctx->pool = new hd_pool();
     ctx->sos_prefetch = 1;
@@ -173,6 +177,14 @@ int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value)
     if (strcmp(name, "force_generic_fft") == 0) { ctx->force_generic_fft = value != 0; return HIPDSP_OK; }
     if (strcmp(name, "spec_fpw") == 0) { ctx->spec_fpw = (int)value; return HIPDSP_OK; }
     if (strcmp(name, "sos_waves_per_cu") == 0) { ctx->sos_waves_per_cu = (int)value; return HIPDSP_OK; }
+    if (strcmp(name, "sos_waves_min") == 0) { ctx->sos_waves_min = (int)value; return HIPDSP_OK; }
+    if (strcmp(name, "chain_pairs") == 0) {
+        HD_REQUIRE(value >= 0 && value <= 8, "chain_pairs %lld not in [0, 8]", value);
+        ctx->chain_pairs = (int)value;
+        return HIPDSP_OK;
+    }
+    if (strcmp(name, "chain_pairs_min") == 0) { ctx->chain_pairs_min = (int)value; return HIPDSP_OK; }
+    if (strcmp(name, "sos_single_wave_wg") == 0) { ctx->sos_single_wave_wg = value != 0; return HIPDSP_OK; }
     if (strcmp(name, "sos_prefetch") == 0) { ctx->sos_prefetch = value != 0; return HIPDSP_OK; }
     if (strcmp(name, "pool_limit_mb") == 0) {
         HD_REQUIRE(value >= 0, "pool_limit_mb must be >= 0");

@@ -616,6 +616,14 @@ __device__ __forceinline__ unsigned wave_slot_of_simd()
     return hw;
 }
 
+// a wave-local fence: LDS operations of one wave execute in order, no workgroup barrier is needed between the
+// phases of a tile that a single wave walks
+#define WAVE_SYNC()                                          \
+    do {                                                     \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                     \
+    } while (0)
+
 struct BwdArgs {
     const float *in;         // the trace the envelope is taken of (before rectification)
     float *out;
@@ -626,12 +634,19 @@ struct BwdArgs {
     long long seg_tiles, warm_tiles;
     int n_seg, edge, rectify, clamp;
     double gain;             // as in CkptArgs
+    long long units;         // channels * n_seg (the grid is rounded up to whole workgroups)
     long long *trace;        // option "sos_trace": 9 words per wave (start, end in 100 MHz ticks, HW_ID, 6 clock sums)
     int fair;                // rotate_issue_priority() per tile (option "sos_fair", default off: no gain measured)
 };
 
-template <int SE, bool PREFETCH, bool PIN = true, bool TRACE = false>
-__global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restrict__ P0, BwdArgs a)
+// WPB waves per workgroup, each an independent (channel, segment) unit with an LDS tile of its own and no workgroup
+// barrier anywhere.  With WPB = 4 the hardware puts the four waves of a workgroup on the four SIMDs of ONE CU, so every
+// SIMD of the chip carries the same number of these persistent waves whatever else the dispatcher has seen before;
+// single-wave workgroups (WPB = 1) land wherever the dispatcher's round-robin stands -- a tiny copy kernel in front of
+// the launch (the spectrogram tile of the multi-GPU step) left some SIMDs with three waves and others with one:
+// 2.96 -> 3.8 ms at 32 channels (profiles/r03_forcedist_*), and probably the "two modes" of round 2.
+template <int SE, bool PREFETCH, bool PIN = true, bool TRACE = false, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void env_bwd_kernel(const SosPlanDev *__restrict__ P0, BwdArgs a)
 {
     // TRACE (diagnostic build, option "sos_trace"): shader clocks per part of an iteration, summed per wave
     long long tr_acc[6] = {0, 0, 0, 0, 0, 0};
@@ -645,11 +660,15 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
         }                                                        \
     } while (0)
     constexpr int DE = 2 * SE;
-    __shared__ float4 lds[64 * 8];
+    __shared__ float4 lds_all[WPB][64 * 8];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float4 *lds = lds_all[wave];
     float *ldsf = reinterpret_cast<float *>(lds);
-    const int lane = threadIdx.x;
-    const int seg = blockIdx.x % a.n_seg;
-    const long long ch = blockIdx.x / a.n_seg;
+    const int lane = threadIdx.x & 63;
+    const long long unit = (long long)blockIdx.x * WPB + wave;
+    if (unit >= a.units) return;                    // (no workgroup barrier anywhere: a wave may leave)
+    const int seg = (int)(unit % a.n_seg);
+    const long long ch = unit / a.n_seg;
     const float *in = a.in + ch * a.in_pitch;
     float *out = a.out + ch * a.out_pitch;
     const double *ckpt = a.ckpt + ch * a.ckpt_pitch;
@@ -728,7 +747,7 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
                 const v2d d = __builtin_bit_cast(v2d, nck[i]);
                 cfw_[2 * i] = d.x; cfw_[2 * i + 1] = d.y;
             }
-            __syncthreads();
+            WAVE_SYNC();
         } else if (PREFETCH) {
             // a tile that touches T (the top one or two of a channel).  Every load of this loop is
             // an untracked asm load: hipcc's own vmcnt(0) for a tracked one would also drain the
@@ -763,7 +782,7 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
             }
             asm volatile("" : "+v"(ra));
             asm volatile("" : "+v"(rb));
-            __syncthreads();
+            WAVE_SYNC();
             // right odd extension ext[T + i] = 2 r(T-1) - r(T-2-i), i < edge
             if (lane < edge) {
                 const long long pj = T + lane;
@@ -782,7 +801,7 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
 #pragma unroll
             for (int r = 0; r < DE; r++) cfw_[r] = ckpt[tidx * DE + r];
         }
-        __syncthreads();
+        WAVE_SYNC();
         if (!PREFETCH && tile + TILE > T) {
             // right odd extension ext[T + i] = 2 r(T-1) - r(T-2-i), i < edge, straight from HBM
             if (lane < edge) {
@@ -793,9 +812,9 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
                     ldsf[lds_float_index((int)(pj - tile))] = 2.f * ra - rb;
                 }
             }
-            __syncthreads();
+            WAVE_SYNC();
         }
-        if (PREFETCH) __syncthreads();
+        if (PREFETCH) WAVE_SYNC();
         TRACE_AT(0);                               // tile from the prefetch registers into LDS
         if (PREFETCH) {
             pre = rt + 1 < rt_hi && prefetchable(tidx - 1);
@@ -812,18 +831,18 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
 #include "sos_cascade.inc"
 #undef CASC_GAIN
 #undef CASC_CARRY
-        __syncthreads();
+        WAVE_SYNC();
         TRACE_AT(2);                               // forward cascade
         if (rt == 0) {
             // scipy: backward pass starts from zi * y_fwd[-1]; pad the rest of the tile with it
             const int last = (int)(T + edge - 1 - tile);
             const float v0 = ldsf[lds_float_index(last)];
-            __syncthreads();
+            WAVE_SYNC();
             for (int s2 = last + 1 + lane; s2 < TILE; s2 += 64) ldsf[lds_float_index(s2)] = v0;
             const SosPlanDev *P = PLAN_OF(P0);
 #pragma unroll
             for (int r = 0; r < DE; r++) cb_[r] = P->zi[r] * (double)v0;
-            __syncthreads();
+            WAVE_SYNC();
         }
         // ---- backward cascade over the forward outputs, last sample first
 #define CASC_CARRY cb_
@@ -835,7 +854,7 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
 #undef CASC_PLAN
 #undef CASC_CARRY
 #undef CASC_IN
-        __syncthreads();
+        WAVE_SYNC();
         TRACE_AT(3);                               // backward cascade
         if (rt >= rt_lo) {
             if (tile >= a.skip && tile + TILE <= T) {
@@ -875,14 +894,14 @@ __global__ __launch_bounds__(64) void env_bwd_kernel(const SosPlanDev *__restric
         } else if (PREFETCH) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // warm-up tile: no stores to count
         }
-        __syncthreads();
+        WAVE_SYNC();
         TRACE_AT(5);                               // wait for the prefetch
     }
 #undef TRACE_AT
     if (a.trace && lane == 0) {                       // tools/sweep_trace.py: do the waves of a SIMD progress alike?
         unsigned hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        long long *tr = a.trace + 9 * (long long)blockIdx.x;
+        long long *tr = a.trace + 9 * unit;
         tr[0] = trace_t0;
         tr[1] = wall_clock64();
         tr[2] = hw;
@@ -980,13 +999,9 @@ struct ChainArgs {
                               // bit 8: FFT wave 0 of workgroup 0 withholds one hand-over -- fault-path test)
     int *fault;               // hipdsp_ctx::fault_dev: where a wave that gave up waiting says so
     int split;                // frame split: only the even frames are written here, chain_bwd_kernel writes the odd ones
+    long long unit_stride;    // 0: unit = block * NP + pair; else unit = pair * unit_stride + block -- fewer units than the
+                              // chip has pairs are spread over all CUs, the pairs of a workgroup that get none idle
 };
-
-#define WAVE_SYNC()                                          \
-    do {                                                     \
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
-        __builtin_amdgcn_wave_barrier();                     \
-    } while (0)
 
 // One frame of NFFT samples per group of LPF lanes (2048: LPF 64, radix 16 x 16 x 4; 1024: 64, 8 x 8 x 8; 512: two
 // frames side by side in a wave, LPF 32, 8 x 8 x 4) from its PPL = NFFT / (2 LPF) values per lane (value t: samples
@@ -1174,7 +1189,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
     }
     __syncthreads();
 
-    const long long unit = (long long)blockIdx.x * NP + pair;
+    const long long unit = a.unit_stride ? (long long)pair * a.unit_stride + blockIdx.x : (long long)blockIdx.x * NP + pair;
     const bool unit_ok = unit < a.units;
     const int seg = unit_ok ? (int)(unit % a.c.n_seg) : 0;
     const long long ch = unit_ok ? unit / a.c.n_seg : 0;
@@ -2071,42 +2086,80 @@ int fill_plan(SosPlanDev *p, const double *sos, int S)
     return HIPDSP_OK;
 }
 
-// Choose the number of time segments per channel.  One wave per (channel, segment);
-// a segment costs its own length plus the warm-up it re-reads, and waves run in rounds
-// of `slots` resident waves: minimise rounds * (segment + warm-up).
-void plan_segments_for(long long slots, int max_segments, long long N, long long channels, long long warm,
-                       long long *seg_len, int *n_seg)
+// Choose the number of time segments per channel.  One wave (the fused sweep: one pair of waves) per (channel,
+// segment); a segment costs its own length plus the warm-up it re-reads, times what a tile step costs a wave that
+// shares its CU with w - 1 others (tools/occupancy_sweep.py, profiles/r03_occupancy_sweep.log):
+//   * single-wave sweeps (`per_simd` = 4): bound by the memory system from two waves per SIMD on -- 8, 12 or 16
+//     waves per CU move the same bytes per second, so a tile step costs a wave s / 2 with s = ceil(w / 4) waves on
+//     its SIMD -- and by a wave's own latency below (0.65 at one wave per SIMD): 8 per CU is never worse than 16
+//     and re-reads half the warm-ups; a short job (BASELINE configs[1]) runs best at 4;
+//   * fused sweeps (`per_simd` = 0): the pairs need each other's gaps -- 8 pairs per CU reach 0.66 tile steps per
+//     microsecond, 4 pairs 0.57, 2 pairs 0.37 -- so the CU is filled whenever the job allows:
+//     cost per tile step ~ w_max x (1 + 0.25 (1 - w / w_max)).
+// With more units than n_cus x w_max the waves run in rounds of that many.
+double tile_step_cost(long long w, int w_max, int per_simd)
 {
+    if (per_simd > 0) {
+        const long long sw = (w + per_simd - 1) / per_simd;
+        return sw <= 1 ? 0.65 : 0.5 * (double)sw;
+    }
+    return (double)w_max * (1.0 + 0.25 * (1.0 - (double)w / (double)w_max));
+}
+
+void plan_segments_occ(long long n_cus, int w_max, int per_simd, int max_segments, long long N, long long channels,
+                       long long warm, long long *seg_len, int *n_seg)
+{
+    if (n_cus < 1) n_cus = 1;
+    if (w_max < 1) w_max = 1;
     long long max_seg = (N + TILE - 1) / TILE;            // at least one tile per segment
     if (warm >= (1LL << 40)) max_seg = 1;                 // non-decaying filter: never segment
     if (max_segments > 0 && max_seg > max_segments) max_seg = max_segments;
     if (max_seg > 65536) max_seg = 65536;
     if (max_seg < 1) max_seg = 1;
+    const long long slots = n_cus * w_max;
     long long best_n = 1, best_len = (N + TILE - 1) / TILE * TILE;
     double best_cost = -1.0;
-    // candidates: segment counts that fill whole rounds, and powers of two below one round
-    for (long long rounds = 0; rounds <= 64; rounds++) {
-        for (int half = 0; half < (rounds == 0 ? 16 : 1); half++) {
-            long long n = rounds == 0 ? ((slots / channels) >> half) : rounds * slots / channels;
-            if (n < 1) n = 1;
-            if (n > max_seg) n = max_seg;
-            long long len = ((N + n - 1) / n + TILE - 1) / TILE * TILE;
-            if (len < TILE) len = TILE;
-            long long cnt = (N + len - 1) / len;
-            long long r = (channels * cnt + slots - 1) / slots;
-            double cost = (double)r * (double)(len + (cnt > 1 ? warm : 0));
-            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_n = cnt; best_len = len; }
-        }
-    }
+    auto consider = [&](long long n) {
+        if (n < 1) n = 1;
+        if (n > max_seg) n = max_seg;
+        long long len = ((N + n - 1) / n + TILE - 1) / TILE * TILE;
+        if (len < TILE) len = TILE;
+        const long long cnt = (N + len - 1) / len;
+        const long long units = channels * cnt;
+        const double span = (double)(len + (cnt > 1 ? warm : 0));
+        double cost;
+        if (units <= slots) cost = span * tile_step_cost((units + n_cus - 1) / n_cus, w_max, per_simd);
+        else cost = (double)((units + slots - 1) / slots) * span * tile_step_cost(w_max, w_max, per_simd);
+        if (best_cost < 0 || cost < best_cost * (1.0 - 1e-9)) { best_cost = cost; best_n = cnt; best_len = len; }
+    };
+    // candidates: the segment counts that fill whole waves-per-CU levels (most waves first, so that ties keep the
+    // chip full), whole rounds beyond that, and powers of two below one level
+    for (int w = w_max; w >= 1; w--) consider(n_cus * w / channels);
+    for (long long rounds = 2; rounds <= 64; rounds++) consider(rounds * slots / channels);
+    for (int half = 1; half < 16; half++) consider((n_cus / channels) >> half);
+    consider(1);
     *seg_len = best_len;
     *n_seg = (int)best_n;
 }
 
+// the single-wave sweeps: up to "sos_waves_per_cu" (16) waves per CU, four SIMDs per CU
+// ("sos_waves_min" = w, experiments: force w waves per CU by making every level below it cost the same)
 void plan_segments(const hipdsp_ctx *ctx, long long N, long long channels, long long warm,
                    long long *seg_len, int *n_seg)
 {
-    const long long slots = (long long)ctx->n_cus * (ctx->sos_waves_per_cu > 0 ? ctx->sos_waves_per_cu : 16);
-    plan_segments_for(slots, ctx->max_segments, N, channels, warm, seg_len, n_seg);
+    const int w_max = ctx->sos_waves_per_cu > 0 ? ctx->sos_waves_per_cu : 16;
+    plan_segments_occ(ctx->n_cus, w_max, ctx->sos_waves_min >= w_max ? 0 : 4, ctx->max_segments, N, channels, warm, seg_len, n_seg);
+}
+
+// the fused sweeps: up to 8 pairs of waves per workgroup = CU ("chain_pairs": fewer, experiments)
+constexpr int CHAIN_P = 8;
+void plan_segments_chain(const hipdsp_ctx *ctx, long long N, long long channels, long long warm,
+                         long long *seg_len, int *n_seg)
+{
+    int cus = ctx->n_cus - ctx->chain_reserve_cus;
+    if (cus < 1) cus = 1;                                  // (options set in an order that leaves none: ADVICE round 2)
+    plan_segments_occ(cus, ctx->chain_pairs > 0 ? ctx->chain_pairs : CHAIN_P, 0, ctx->max_segments, N, channels, warm, seg_len,
+                      n_seg);
 }
 
 int launch_scan(hipdsp_ctx *ctx, const SosPlanDev *dev, int S, SeqArgs a, long long channels, long long warm)
@@ -2198,9 +2251,17 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
     plan_segments(ctx, used_tiles * TILE, channels, warmE, &seg_len, &b.n_seg);
     b.seg_tiles = seg_len / TILE;
     b.warm_tiles = warmE / TILE;
-    long long blocks = channels * b.n_seg;
+    b.units = channels * b.n_seg;
+    constexpr int WPB = 4;                                   // waves per workgroup: one per SIMD of a CU
+    long long blocks = (b.units + WPB - 1) / WPB;
     HD_REQUIRE(blocks <= 0x7fffffffLL, "grid too large");
-    dim3 grid((unsigned)blocks), block(64);
+    dim3 grid((unsigned)blocks), block(64 * WPB);
+    if (ctx->sos_single_wave_wg) { grid = dim3((unsigned)b.units); block = dim3(64); }
+    if (ctx->sos_single_wave_wg && SE == 1 && ctx->sos_prefetch && frames >= 4 * TILE && !ctx->sos_trace && !ctx->sos_no_pin) {
+        hipLaunchKernelGGL((env_bwd_kernel<1, true, true, false, 1>), grid, block, 0, ctx->stream, edev, b);   // A/B
+        return hd_launch_status("env_bwd_kernel");
+    }
+    if (ctx->sos_single_wave_wg) { grid = dim3((unsigned)blocks); block = dim3(64 * WPB); }
     switch (SE) {
     case 1:
         if (ctx->sos_prefetch && frames >= 4 * TILE) {
@@ -2323,15 +2384,15 @@ int hipdsp_sos_plan_host(const double *host_sos, int n_sections, int64_t *warmup
     return HIPDSP_OK;
 }
 
-int hipdsp_sos_segments_host(int64_t resident_waves, int max_segments, int64_t frames, int64_t channels,
-                             int64_t warmup, int64_t *segment_frames, int *n_segments)
+int hipdsp_sos_segments_host(int64_t n_cus, int waves_max, int per_simd, int max_segments, int64_t frames,
+                             int64_t channels, int64_t warmup, int64_t *segment_frames, int *n_segments)
 {
-    HD_REQUIRE(resident_waves >= 1 && frames >= 1 && channels >= 1 && warmup >= 0 && max_segments >= 0,
-               "bad argument");
+    HD_REQUIRE(n_cus >= 1 && waves_max >= 1 && per_simd >= 0 && frames >= 1 && channels >= 1 && warmup >= 0 &&
+               max_segments >= 0, "bad argument");
     HD_REQUIRE(segment_frames != nullptr && n_segments != nullptr, "NULL output");
     long long len = 0;
     int n = 0;
-    plan_segments_for(resident_waves, max_segments, frames, channels, warmup, &len, &n);
+    plan_segments_occ(n_cus, waves_max, per_simd, max_segments, frames, channels, warmup, &len, &n);
     *segment_frames = len;
     *n_segments = n;
     return HIPDSP_OK;
@@ -2472,11 +2533,17 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     a.split = (ctx->chain_split_frames && nfft == 2048 && hop == 1024 && !db_out) ? 1 : 0;
     constexpr int P = 8;                                           // IIR waves (and FFT waves) per workgroup, one per CU
     // (hipdsp_chain_plan reports exactly this segmentation)
-    plan_segments_for((long long)(ctx->n_cus - ctx->chain_reserve_cus) * P, ctx->max_segments, frames, channels,
-                      a.warm_total, &a.c.seg_len, &a.c.n_seg);
+    plan_segments_chain(ctx, frames, channels, a.warm_total, &a.c.seg_len, &a.c.n_seg);
     a.units = channels * a.c.n_seg;
     a.n_iter = (int)((a.warm_total + a.c.seg_len + edge + TILE - 1) / TILE) + 1;
-    const long long blocks = (a.units + P - 1) / P;
+    long long blocks = (a.units + P - 1) / P;
+    {
+        const long long cus = ctx->n_cus - ctx->chain_reserve_cus > 0 ? ctx->n_cus - ctx->chain_reserve_cus : 1;
+        if (a.units < cus * P) {                                   // not every pair of the chip gets a unit: spread them
+            blocks = a.units < cus ? a.units : cus;
+            a.unit_stride = blocks;
+        }
+    }
     HD_REQUIRE(blocks <= 0x7fffffffLL, "grid too large");
     if (frames_out > n_valid) {                                    // zero tail (bufferedspectrogram.py:59)
         const long long n = (frames_out - n_valid) * F;
@@ -2694,8 +2761,7 @@ int hipdsp_chain_backward(hipdsp_ctx *ctx, const hipdsp_sosplan *eplan, const fl
     a.b.rectify = rectify; a.b.clamp = clamp; a.b.gain = rectify ? gain : 1.0;
     constexpr int P = 8;
     long long seg_len = 0;
-    plan_segments_for((long long)(ctx->n_cus - ctx->chain_reserve_cus) * P, ctx->max_segments, n_tiles * TILE, channels,
-                      eplan->host->warm, &seg_len, &a.b.n_seg);
+    plan_segments_chain(ctx, n_tiles * TILE, channels, eplan->host->warm, &seg_len, &a.b.n_seg);
     a.b.seg_tiles = seg_len / TILE;
     a.b.warm_tiles = eplan->host->warm / TILE;
     a.psd = psd; a.psd_pitch = psd_pitch; a.n_valid = n_valid;
@@ -2721,8 +2787,7 @@ int hipdsp_chain_backward_plan(hipdsp_ctx *ctx, const hipdsp_sosplan *eplan, int
     const long long n_tiles = (frames + eplan->host->edge + TILE - 1) / TILE;
     long long len = 0;
     int n = 0;
-    plan_segments_for((long long)(ctx->n_cus - ctx->chain_reserve_cus) * 8, ctx->max_segments, n_tiles * TILE, channels,
-                      eplan->host->warm, &len, &n);
+    plan_segments_chain(ctx, n_tiles * TILE, channels, eplan->host->warm, &len, &n);
     // segment s (walked from the END of the trace) covers frames [n_tiles*TILE - (s+1)*len, n_tiles*TILE - s*len)
     *first_border = n_tiles * TILE - len;
     *segment_frames = len;
@@ -2739,8 +2804,7 @@ int hipdsp_chain_plan(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hipdsp
     HD_REQUIRE(fplan->host->n_sections > 0 && (eplan == nullptr || eplan->host->n_sections > 0), "plan has no coefficients");
     long long len = 0;
     int n = 0;
-    plan_segments_for((long long)(ctx->n_cus - ctx->chain_reserve_cus) * 8, ctx->max_segments, frames, channels,
-                      fplan->host->warm, &len, &n);
+    plan_segments_chain(ctx, frames, channels, fplan->host->warm, &len, &n);
     *segment_frames = len;
     *n_segments = n;
     return HIPDSP_OK;

@@ -59,6 +59,12 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument('--channels', type=int, default=None, help='channels per GPU (default: the config\'s)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help="'weak' (default): the config's channels PER GPU (64 at configs[2]: 512 at N = 8); 'strong': "
+                         "the config's channels in TOTAL, sharded over the N GPUs (64 / N per GPU) -- BASELINE.json's "
+                         "metric as it is worded (\"64ch x 96kHz, 1/2/4/8 GPU\")")
+    ap.add_argument('--strong-world', type=int, default=None,
+                    help="rehearsal on fewer GPUs: run one rank's share of a strong-scaling run over this many GPUs")
     ap.add_argument('--seconds', type=float, default=None)
     ap.add_argument('--rate', type=float, default=None)
     ap.add_argument('--nfft', type=int, default=None)
@@ -298,57 +304,67 @@ def parity_subset(args, hipdsp, ctx, dx, df, ds, de, T, nd, sos, esos, extra=())
 
 
 class TorchGather:
-    """All-gather of the spectrogram tile with torch.distributed (RCCL at backend 'nccl'): the tile is
-    copied out of the rank's spectrogram on a side stream (double-buffered) and gathered asynchronously."""
+    """All-gather of the spectrogram tile with torch.distributed (RCCL at backend 'nccl').  The tile is copied out
+    of the rank's spectrogram ON THE COMPUTE STREAM right behind the forward sweep (0.03 ms for the visible tile) into
+    one of two buffers; the gather itself is enqueued on a side stream and waits for the step's BACKWARD sweep: it
+    then runs under the forward sweep of the next step, which plans no workgroup for `reserve` CUs.  The backward
+    sweep runs alone on the chip.  (Round 2 issued copy and gather on a side stream right behind the forward sweep and
+    lost 0.7-1.4 ms per step to it with one rank: the backward sweep was a kernel of persistent SINGLE-WAVE workgroups,
+    and any small kernel in front of its launch left the dispatcher's round-robin such that some SIMDs got three of
+    its waves and others one -- 2.96 -> 3.8-4.5 ms at 32 channels, profiles/r03_forcedist_trace_before.txt.  Its
+    workgroups are four waves now, one per SIMD of a CU.)"""
 
     def __init__(self, torch, dist, hipdsp, ctx, tspec, tile_frames, world, backend, cstream):
-        self.torch, self.dist, self.ctx, self.tspec, self.tf = torch, dist, ctx, tspec, tile_frames
+        self.torch, self.dist, self.hipdsp, self.ctx, self.tspec, self.tf = torch, dist, hipdsp, ctx, tspec, tile_frames
         self.world, self.backend, self.cstream = world, backend, cstream
         C, nd, F = tspec.shape
+        self.C, self.nd, self.F = C, nd, F
         self.whole = tile_frames == nd
         self.side = torch.cuda.Stream()
         self.tile = [None, None] if self.whole else \
             [torch.empty((C, tile_frames, F), dtype=torch.float32, device='cuda') for _ in range(2)]
         self.merged = torch.empty((world*C, tile_frames, F), dtype=torch.float32,
                                   device='cuda' if backend == 'nccl' else 'cpu')
-        self.work = None
         self.n = 0
-        self.done = torch.cuda.Event()
-        self.done.record(cstream)
+        self.src = None
+        self.gathered = [torch.cuda.Event(), torch.cuda.Event()]     # buffer b may be overwritten
+        for ev in self.gathered:
+            ev.record(cstream)
+        self.computed = torch.cuda.Event()
 
     def before_forward(self):
-        """The forward sweep is about to overwrite the spectrogram: a gather that reads it in place
-        (whole spectrogram) must have finished; a tile copy only needs its copy to be done."""
+        """The forward sweep is about to overwrite the spectrogram: a gather that reads it in place (whole
+        spectrogram) must have finished; a tile has been copied out on this very stream."""
         if self.whole:
-            self.drain()
-        else:
-            self.cstream.wait_event(self.done)
+            self.cstream.wait_event(self.gathered[0])
+
+    def after_forward(self):
+        """Right behind the forward sweep, on the compute stream: copy the tile out."""
+        if self.whole:
+            self.src = self.tspec
+            return
+        b = self.n % 2
+        self.cstream.wait_event(self.gathered[b])          # the gather of two steps ago has read this buffer
+        self.src = self.tile[b]
+        self.hipdsp.memcpy2d(self.ctx, self.src.data_ptr(), 4*self.tf*self.F, self.tspec.data_ptr(), 4*self.nd*self.F,
+                             4*self.tf*self.F, self.C)
 
     def issue(self):
-        """After the forward sweep of a step (enqueued on the compute stream)."""
+        """After the backward sweep has been enqueued: the gather follows it on the side stream."""
         torch = self.torch
-        self.side.wait_stream(self.cstream)
+        b = 0 if self.whole else self.n % 2
+        self.n += 1
+        self.computed.record(self.cstream)
+        self.side.wait_event(self.computed)
         with torch.cuda.stream(self.side):
-            if self.work is not None:
-                self.work.wait()                  # gathers run one after the other anyway
-                self.work = None
-            if self.whole:
-                src = self.tspec
-            else:
-                src = self.tile[self.n % 2]
-                src.copy_(self.tspec[:, :self.tf, :])
-                self.done.record(self.side)
-            self.n += 1
             if self.backend == 'nccl':
-                self.work = self.dist.all_gather_into_tensor(self.merged, src, async_op=True)
+                self.dist.all_gather_into_tensor(self.merged, self.src)      # (the side stream waits for it)
             else:
                 self.side.synchronize()
-                self.dist.all_gather_into_tensor(self.merged, src.cpu())
+                self.dist.all_gather_into_tensor(self.merged, self.src.cpu())
+            self.gathered[b].record(self.side)
 
     def drain(self):
-        if self.work is not None:
-            self.work.wait()
-            self.work = None
         self.side.synchronize()
 
     def alone(self, k):
@@ -368,9 +384,10 @@ class TorchGather:
 
 
 class AbiGather:
-    """The same exchange step through the C ABI (hipdsp_comm_* / hipdsp_allgather_f32): a second context on
-    its own stream copies the tile (hipdsp_memcpy2d_d2d) and enqueues ncclAllGather there; ordered against
-    the compute context with hipdsp events.  The 128-byte unique id travels over torch.distributed."""
+    """The same exchange step through the C ABI (hipdsp_comm_* / hipdsp_allgather_f32): the tile is copied on the
+    compute context (hipdsp_memcpy2d_d2d) behind the forward sweep, a second context on its own stream enqueues
+    ncclAllGather behind the backward sweep; ordered with hipdsp events.  The 128-byte unique id travels over
+    torch.distributed."""
 
     def __init__(self, torch, dist, hipdsp, ctx, ds, shape, tile_frames, world, rank, local_rank):
         self.torch, self.dist, self.hipdsp, self.ctx, self.ds, self.tf = torch, dist, hipdsp, ctx, ds, tile_frames
@@ -385,27 +402,34 @@ class AbiGather:
         self.tile = [None, None] if self.whole else \
             [hipdsp.DeviceArray(self.gctx, (C, tile_frames, F), np.float32) for _ in range(2)]
         self.merged = hipdsp.DeviceArray(self.gctx, (world*C, tile_frames, F), np.float32)
-        self.ev_fwd, self.ev_copied, self.ev_gathered = ctx.event(), ctx.event(), ctx.event()
+        self.ev_computed = ctx.event()
+        self.ev_gathered = [ctx.event(), ctx.event()]
         self.n = 0
-        self.gctx.record(self.ev_copied)
-        self.gctx.record(self.ev_gathered)
+        self.src = None
+        for ev in self.ev_gathered:
+            self.gctx.record(ev)
 
     def before_forward(self):
-        self.ctx.wait_event(self.ev_gathered if self.whole else self.ev_copied)
+        if self.whole:
+            self.ctx.wait_event(self.ev_gathered[0])
+
+    def after_forward(self):
+        h = self.hipdsp
+        if self.whole:
+            self.src = self.ds
+            return
+        b = self.n % 2
+        self.ctx.wait_event(self.ev_gathered[b])
+        self.src = self.tile[b]
+        h.memcpy2d(self.ctx, self.src, 4*self.tf*self.F, self.ds, 4*self.nd*self.F, 4*self.tf*self.F, self.C)
 
     def issue(self):
-        h = self.hipdsp
-        self.ctx.record(self.ev_fwd)
-        self.gctx.wait_event(self.ev_fwd)
-        if self.whole:
-            src = self.ds
-        else:
-            src = self.tile[self.n % 2]
-            h.memcpy2d(self.gctx, src, 4*self.tf*self.F, self.ds, 4*self.nd*self.F, 4*self.tf*self.F, self.C)
-            self.gctx.record(self.ev_copied)
+        b = 0 if self.whole else self.n % 2
         self.n += 1
-        self.comm.allgather(src, self.merged, self.C*self.tf*self.F)
-        self.gctx.record(self.ev_gathered)
+        self.ctx.record(self.ev_computed)
+        self.gctx.wait_event(self.ev_computed)
+        self.comm.allgather(self.src, self.merged, self.C*self.tf*self.F)
+        self.gctx.record(self.ev_gathered[b])
 
     def drain(self):
         self.gctx.synchronize()
@@ -485,6 +509,13 @@ def main():
     if reserve:
         ctx.set_option('chain_reserve_cus', reserve)
 
+    total_channels = None
+    if args.scaling == 'strong':
+        share = args.strong_world or world
+        total_channels = args.channels
+        if total_channels % share:
+            sys.exit(f'bench.py --scaling strong: {total_channels} channels do not divide over {share} GPUs')
+        args.channels = total_channels//share
     C, T = args.channels, int(round(args.seconds*args.rate))
     F = args.nfft//2 + 1
     nd = (T + args.hop - 1)//args.hop                 # BufferedData.update_step frames
@@ -591,10 +622,8 @@ def main():
         if ev:
             sctx.record(ev[6])
         if gatherer is not None:
-            # merged spectrogram tile on every rank: one RCCL all-gather over xGMI per step, issued right behind
-            # the spectrogram so that it runs under the backward sweep of this step and the forward sweep of the
-            # next one (which leaves `reserve` CUs to RCCL's kernel)
-            gatherer.issue()
+            # the tile of the merged spectrogram leaves the rank's spectrogram right behind the forward sweep
+            gatherer.after_forward()
         if ev and fused:
             sctx.record(ev[2])
         if overlap:
@@ -614,6 +643,11 @@ def main():
         if ev:
             ctx.set_mid_event(None)
             ctx.record(ev[3])
+        if gatherer is not None:
+            # merged spectrogram tile on every rank: one RCCL all-gather over xGMI per step, enqueued behind the
+            # backward sweep so that it runs under the forward sweep of the next step (which leaves `reserve` CUs
+            # to RCCL's kernel) and the backward sweep's persistent waves are dispatched onto an idle chip
+            gatherer.issue()
         if overlap:
             ctx.wait_event(ev_spec)       # the next step overwrites the filtered trace
         if ev:
@@ -762,7 +796,7 @@ def main():
                 g = None
                 try:
                     g = main_gather if name == args.tile else make_gatherer(name)
-                    gdt = dt if name == args.tile else timed_run(g, record=False)
+                    gdt = timed_run(g, record=False)          # (without the HIP events of the timed region, like compute_ms)
                     alone_s = g.alone(max(2, min(args.steps, 5)))
                     gb = tile_gb(name)
                     legs['tiles'][name] = {
@@ -810,19 +844,20 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt/args.steps*1e3,
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': args.scaling,
             'vs_baseline': None,
             'dtype': 'f32 I/O, f64 IIR state',
             'data': 'synthetic',
             'config': {
-                'workload': f'{args.config_name}: synthetic {C} ch/GPU x {args.seconds:g} s x '
+                'workload': (f'{args.config_name}, STRONG scaling: {total_channels} channels in total = ' if total_channels
+                             else f'{args.config_name}: synthetic ') + f'{C} ch/GPU x {args.seconds:g} s x '
                             f'{args.rate/1000:g} kHz float32; bandpass {args.hp:g}-{args.lp:g} Hz '
                             f'order {args.order} -> spectrogram nfft {args.nfft} hop {args.hop} '
                             f'+ envelope {args.env:g} Hz',
                 'channels_per_gpu': C, 'frames': T, 'spectrogram_frames': nd,
                 'parallelism': f'channel shard x{world}' +
                                (f', all-gather ({args.gather}) of the {args.tile} spectrogram tile '
-                                f'({4*C*tile_frames_of(args.tile)*F/1e9:.2f} GB per rank) behind the forward sweep, '
+                                f'({4*C*tile_frames_of(args.tile)*F/1e9:.2f} GB per rank) copied out behind the forward sweep, gathered behind the backward sweep (under the next forward sweep), '
                                 f'{reserve} CUs left to RCCL' if multi else ''),
                 'iir_warmup_samples': {'bandpass': warm_f, 'envelope': warm_e},
                 'streams': ('spectrogram on a second stream next to the envelope backward sweep '

@@ -62,7 +62,9 @@ int hipdsp_ctx_synchronize(hipdsp_ctx *ctx);
 int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
 /* Named tuning/testing options (results do not depend on them beyond rounding):
  *   "max_segments"       as hipdsp_ctx_set_max_segments
- *   "sos_waves_per_cu"   resident waves per CU the IIR segment planner aims for (16)
+ *   "sos_waves_per_cu"   most resident waves per CU the IIR segment planner uses (16; see hipdsp_sos_segments_host);
+ *                        "sos_waves_min" >= that: exactly that many (experiments); "chain_pairs" (8): most pairs of
+ *                        waves per CU of the fused sweeps
  *   "pool_limit_mb"      bytes (MiB) hipdsp_free may keep cached for hipdsp_malloc (1024)
  *   "sos_prefetch"       0: envelope sweeps without the register prefetch of the next tile (1)
  *   "chain_split_frames" non-zero: hipdsp_chain_forward (2048/1024, no db_out) leaves the odd frames to hipdsp_chain_backward
@@ -197,11 +199,17 @@ int hipdsp_sosplan_upload(hipdsp_ctx *ctx, hipdsp_sosplan *plan);
 int hipdsp_sos_plan_host(const double *host_sos, int n_sections, int64_t *warmup, int *edge,
                          double *zi);
 /* How the block-parallel IIR cuts `frames` samples of `channels` channels into time segments
- * (one wave per channel and segment) when `resident_waves` waves fit on the device at once
- * (CUs x "sos_waves_per_cu") and a segment has to re-read `warmup` samples before its range:
- * the count that minimises rounds x (segment + warm-up); segment_frames is a multiple of the
- * 2048-sample tile.  Host only (tests, capacity planning). */
-int hipdsp_sos_segments_host(int64_t resident_waves, int max_segments, int64_t frames,
+ * (one wave per channel and segment) on `n_cus` compute units that hold up to `waves_max` such
+ * waves each ("sos_waves_per_cu", 16; the fused sweeps: 8 pairs), when a segment has to re-read
+ * `warmup` samples before its range.  The count minimises
+ *     rounds x (segment + warm-up) x cost of a tile step at w waves per CU
+ * (rounds of n_cus x waves_max units when there are more).  per_simd = 4 (the single-wave sweeps, four
+ * SIMDs per CU): memory-bound from two waves per SIMD on, so a tile step costs ceil(w / 4) / 2, and 0.65
+ * at one wave per SIMD (measured, profiles/r03_occupancy_sweep.log): 8 waves per CU are preferred to 16,
+ * short jobs get 4.  per_simd = 0 (the fused sweeps): waves_max x (1 + 0.25 (1 - w / waves_max)) -- the
+ * CU is filled whenever the job allows.  segment_frames is a multiple of the 2048-sample tile.
+ * Host only (tests, capacity planning). */
+int hipdsp_sos_segments_host(int64_t n_cus, int waves_max, int per_simd, int max_segments, int64_t frames,
                              int64_t channels, int64_t warmup, int64_t *segment_frames,
                              int *n_segments);
 /* Introspection (tests): warm-up length in samples, sosfiltfilt pad length. */

@@ -74,49 +74,77 @@ def test_plan_rejects_bad_tables():
         plan_host(np.array([[np.nan, 0.0, 0.0, 1.0, 0.0, 0.0]]))
 
 
-def segments(resident, frames, channels, warm, max_segments=0):
+def segments(n_cus, w_max, per_simd, frames, channels, warm, max_segments=0):
     length = ctypes.c_int64()
     count = ctypes.c_int()
-    _lib.check(_lib.lib.hipdsp_sos_segments_host(resident, max_segments, frames, channels, warm,
+    _lib.check(_lib.lib.hipdsp_sos_segments_host(n_cus, w_max, per_simd, max_segments, frames, channels, warm,
                                                  ctypes.byref(length), ctypes.byref(count)))
     return int(length.value), int(count.value)
 
 
+def step_cost(w, w_max, per_simd):
+    if per_simd:
+        sw = -(-w//per_simd)
+        return 0.65 if sw <= 1 else 0.5*sw
+    return w_max*(1 + 0.25*(1 - w/w_max))
+
+
+def plan_cost(n_cus, w_max, per_simd, frames, channels, warm, n):
+    """The planner's cost model (include/hip_dsp.h): rounds x (segment + warm-up) x cost of a tile step."""
+    ln = max(TILE, -(-(-(-frames//n))//TILE)*TILE)
+    cnt = -(-frames//ln)
+    units = channels*cnt
+    span = ln + (warm if cnt > 1 else 0)
+    if units <= n_cus*w_max:
+        return span*step_cost(-(-units//n_cus), w_max, per_simd)
+    return -(-units//(n_cus*w_max))*span*step_cost(w_max, w_max, per_simd)
+
+
 def test_segment_planner_properties():
-    """Segments are whole tiles, cover the slab, and their number follows the cost model
-    rounds x (segment + warm-up)."""
+    """Segments are whole tiles, cover the slab, and their number follows the cost model."""
     rng = np.random.default_rng(0)
     for _ in range(300):
-        resident = int(rng.choice([256*8, 256*12, 256*16]))
+        n_cus = int(rng.choice([256, 248, 64]))
+        w_max, per_simd = [(16, 4), (12, 4), (8, 0)][int(rng.integers(0, 3))]
         channels = int(rng.integers(1, 300))
         frames = int(rng.integers(1, 60_000_000))
-        warm = int(rng.choice([2048, 4096, 53248, 400*2048, 2**50*2048]))
+        warm = int(rng.choice([0, 2048, 4096, 53248, 400*2048, 2**50*2048]))
         cap = int(rng.choice([0, 0, 1, 7]))
-        length, count = segments(resident, frames, channels, warm, cap)
+        length, count = segments(n_cus, w_max, per_simd, frames, channels, warm, cap)
         assert length % TILE == 0 and length >= TILE and count >= 1
         assert count*length >= frames > (count - 1)*length
         if cap:
             assert count <= cap
         if warm >= 2**40:
             assert count == 1                                  # a filter that never forgets
-        # no other candidate the planner considers is cheaper
-        def cost(n):
-            ln = -(-(-(-frames//n))//TILE)*TILE
-            cnt = -(-frames//ln)
-            rounds = -(-channels*cnt//resident)
-            return rounds*(ln + (warm if cnt > 1 else 0))
-        assert cost(count) <= cost(1)
+            continue
+        # no other segment count (that is allowed) is cheaper by the model
+        mine = plan_cost(n_cus, w_max, per_simd, frames, channels, warm, count)
+        top = min(cap or 10**9, -(-frames//TILE), 65536)
+        for n in {1, 2, 3, count + 1, max(1, count - 1), max(1, n_cus*w_max//channels), max(1, n_cus*4//channels),
+                  max(1, n_cus*8//channels), max(1, n_cus//channels)}:
+            if n <= top:
+                assert mine <= plan_cost(n_cus, w_max, per_simd, frames, channels, warm, n)*(1 + 1e-9), (n, count)
 
 
 def test_segment_planner_bench_configuration():
-    # BASELINE configs[2] on 256 CUs x 16 waves: 64 segments of 900 000 samples per channel
-    length, count = segments(256*16, 57_600_000, 64, 53248 + 4096)
-    assert count == 64 and length == -(-57_600_000//64//TILE)*TILE
+    # BASELINE configs[2], backward sweep on 256 CUs: 8 waves per CU (as fast as 16, half the warm-ups) = 32 segments
+    length, count = segments(256, 16, 4, 57_600_000, 64, 53248)
+    assert count == 32 and length == -(-57_600_000//32//TILE)*TILE
+    # ... the fused forward sweep (8 pairs per CU, band-pass warm-up only): 32 segments per channel
+    length, count = segments(256, 8, 0, 57_600_000, 64, 4096)
+    assert count == 32
+    # few channels per GPU (strong scaling, 8 of 64): 8 waves per CU again
+    length, count = segments(256, 16, 4, 57_600_000, 8, 53248)
+    assert count == 256
+    # BASELINE configs[1] (4 ch x 60 s x 48 kHz): a few tiles per segment at one wave per SIMD, not 1024 segments per channel
+    length, count = segments(256, 16, 4, 2_880_000, 4, 26624)
+    assert count <= 256 and length >= 4*TILE
     # a short interactive slab is not cut below what the warm-up makes worthwhile
-    length, count = segments(256*16, 200_000, 2, 53248)
+    length, count = segments(256, 16, 4, 200_000, 2, 53248)
     assert count*length >= 200_000 and length >= TILE
     with pytest.raises(ValueError):
-        segments(0, 10, 1, 0)
+        segments(0, 16, 4, 10, 1, 0)
 
 
 @pytest.mark.parametrize('btype,order,wn,rate', [
