@@ -62,6 +62,7 @@ struct SeqArgs {
     // the cascade filters gain * in (hipdsp_envelope_multi: the pi/2 of the rectified trace rides on the first
     // plan's numerator instead of on every sample); launch_scan turns 0 into 1
     double gain;
+    long long units;        // channels * n_seg (the grid is rounded up to whole workgroups)
 };
 
 __device__ __forceinline__ long long opaque_zero()
@@ -140,15 +141,29 @@ __device__ __forceinline__ double casc_wave_shr32(double x)
     return __builtin_bit_cast(double, ((long long)hi[0] << 32) | (unsigned int)lo[0]);
 }
 
+// a wave-local fence: LDS operations of one wave execute in order, no workgroup barrier is needed between the
+// phases of a tile that a single wave walks
+#define WAVE_SYNC()                                          \
+    do {                                                     \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                     \
+    } while (0)
+
+constexpr int WPB = 4;     // waves per workgroup of the single-wave-per-unit sweeps: one per SIMD of a CU (see env_bwd_kernel)
+
 // ---- sosfilt: BufferedFilter.process ------------------------------------------------------
 template <int S>
-__global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *__restrict__ P0, SeqArgs a)
+__global__ __launch_bounds__(64 * WPB) void sos_scan_kernel(const SosPlanDev *__restrict__ P0, SeqArgs a)
 {
     constexpr int D = 2 * S;
-    __shared__ float4 lds[64 * 8];
-    const int lane = threadIdx.x;
-    const int seg = blockIdx.x % a.n_seg;
-    const long long ch = blockIdx.x / a.n_seg;
+    __shared__ float4 lds_all[WPB][64 * 8];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float4 *lds = lds_all[wave];
+    const int lane = threadIdx.x & 63;
+    const long long unit = (long long)blockIdx.x * WPB + wave;
+    if (unit >= a.units) return;                    // (no workgroup barrier anywhere: a wave may leave)
+    const int seg = (int)(unit % a.n_seg);
+    const long long ch = unit / a.n_seg;
     const float *in = a.in + ch * a.in_pitch;
     float *out = a.out + ch * a.out_pitch;
 
@@ -177,7 +192,7 @@ __global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *__restri
 #pragma unroll
         for (int k = 0; k < 8; k++)
             lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = load_four(in, tile + 256 * k + 4 * lane, a.N);
-        __syncthreads();
+        WAVE_SYNC();
 
 #define CASC_S S
 #define CASC_PLAN() PLAN_OF(P0)
@@ -190,14 +205,14 @@ __global__ __launch_bounds__(64) void sos_scan_kernel(const SosPlanDev *__restri
 #undef CASC_PLAN
 #undef CASC_CARRY
 #undef CASC_IN
-        __syncthreads();
+        WAVE_SYNC();
         if (tile + TILE > olo) {      // warm-up tiles produce no output
 #pragma unroll
             for (int k = 0; k < 8; k++)
                 store_four(out, tile + 256 * k + 4 * lane, lds[lds_slot(8 * k + (lane >> 3), lane & 7)], olo, hi,
                            a.skip);
         }
-        __syncthreads();
+        WAVE_SYNC();
     }
 }
 
@@ -223,6 +238,7 @@ struct CkptArgs {
     long long in_pitch, yf_pitch, ckpt_pitch;
     long long T, seg_len;
     int n_seg, edge, rectify;
+    long long units;        // channels * n_seg (the grid is rounded up to whole workgroups; the fused sweep: ChainArgs::units)
     double gain;            // the envelope filters gain * |y|: folded into its cascade (CASC_GAIN), never into the samples
 };
 
@@ -244,16 +260,21 @@ __device__ __forceinline__ float asm_load4(const float *p)
 }
 
 template <int SF, int SE, bool PREFETCH>
-__global__ __launch_bounds__(64) void sos_ckpt_kernel(const SosPlanDev *__restrict__ PF0,
+__global__ __launch_bounds__(64 * WPB) void sos_ckpt_kernel(const SosPlanDev *__restrict__ PF0,
                                                       const SosPlanDev *__restrict__ PE0, CkptArgs a)
 {
     constexpr int DF = SF > 0 ? 2 * SF : 1, DE = 2 * SE;
-    __shared__ float4 lds[64 * 8];
-    __shared__ float rprev[64];            // rectified samples of the previous tile's last two rows
+    __shared__ float4 lds_all[WPB][64 * 8];
+    __shared__ float rprev_all[WPB][64];   // rectified samples of the previous tile's last two rows
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float4 *lds = lds_all[wave];
+    float *rprev = rprev_all[wave];
     float *ldsf = reinterpret_cast<float *>(lds);
-    const int lane = threadIdx.x;
-    const int seg = blockIdx.x % a.n_seg;
-    const long long ch = blockIdx.x / a.n_seg;
+    const int lane = threadIdx.x & 63;
+    const long long unit = (long long)blockIdx.x * WPB + wave;
+    if (unit >= a.units) return;                    // (no workgroup barrier anywhere: a wave may leave)
+    const int seg = (int)(unit % a.n_seg);
+    const long long ch = unit / a.n_seg;
     const float *in = a.in + ch * a.in_pitch;
     float *yf = SF > 0 ? a.yf + ch * a.yf_pitch : nullptr;
     double *ckpt = a.ckpt + ch * a.ckpt_pitch;
@@ -326,7 +347,7 @@ __global__ __launch_bounds__(64) void sos_ckpt_kernel(const SosPlanDev *__restri
             for (int k = 0; k < 8; k++)
                 lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = load_four(in, tile + 256 * k + 4 * lane, T);
         }
-        __syncthreads();
+        WAVE_SYNC();
         if (PREFETCH) {
             const long long next = tile + TILE;
             pre = next < loop_end && next + TILE <= T;
@@ -342,7 +363,7 @@ __global__ __launch_bounds__(64) void sos_ckpt_kernel(const SosPlanDev *__restri
 #undef CASC_PLAN
 #undef CASC_CARRY
 #undef CASC_IN
-            __syncthreads();
+            WAVE_SYNC();
             if (tile + TILE > lo && tile < hi) {
                 if (tile >= lo && tile + TILE <= hi) {
                     // interior tile: exactly 8 vector stores, then the counted wait
@@ -365,7 +386,7 @@ __global__ __launch_bounds__(64) void sos_ckpt_kernel(const SosPlanDev *__restri
         }
         if (tile < env_start) {                                  // band-pass warm-up only
             if (PREFETCH && SF == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            WAVE_SYNC();
             continue;
         }
         // ---- envelope input in place: r = |y| (exact; the gain rides on the cascade, CASC_GAIN), then the odd
@@ -378,7 +399,7 @@ __global__ __launch_bounds__(64) void sos_ckpt_kernel(const SosPlanDev *__restri
                 lds[lds_slot(lane, q)] = v;
             }
         }
-        __syncthreads();
+        WAVE_SYNC();
         auto rval = [&](long long j) -> float {          // r(j) for j in this tile or the row before it
             return j >= tile ? ldsf[lds_float_index((int)(j - tile))] : rprev[64 - (int)(tile - j)];
         };
@@ -390,9 +411,9 @@ __global__ __launch_bounds__(64) void sos_ckpt_kernel(const SosPlanDev *__restri
                 pj = T + lane;
                 if (pj >= tile && pj < tile + TILE) pv = 2.f * rval(T - 1) - rval(T - 2 - lane);
             }
-            __syncthreads();
+            WAVE_SYNC();
             if (lane < edge && pj >= tile && pj < tile + TILE) ldsf[lds_float_index((int)(pj - tile))] = pv;
-            __syncthreads();
+            WAVE_SYNC();
         }
         if (env_true && tile == 0) {
             // left odd extension: ext[i] = 2 r(0) - r(edge - i), i < edge, from zi * ext[0];
@@ -426,7 +447,7 @@ __global__ __launch_bounds__(64) void sos_ckpt_kernel(const SosPlanDev *__restri
         // keep the last two rows for an extension that reaches back over the tile border
         {
             const float4 keep0 = lds[lds_slot(62 + ((lane >> 3) & 1), lane & 7)];
-            __syncthreads();
+            WAVE_SYNC();
             if (lane < 16) {
                 rprev[4 * lane] = keep0.x; rprev[4 * lane + 1] = keep0.y;
                 rprev[4 * lane + 2] = keep0.z; rprev[4 * lane + 3] = keep0.w;
@@ -455,7 +476,7 @@ __global__ __launch_bounds__(64) void sos_ckpt_kernel(const SosPlanDev *__restri
             }
             break;
         }
-        __syncthreads();
+        WAVE_SYNC();
     }
 }
 
@@ -616,14 +637,6 @@ __device__ __forceinline__ unsigned wave_slot_of_simd()
     return hw;
 }
 
-// a wave-local fence: LDS operations of one wave execute in order, no workgroup barrier is needed between the
-// phases of a tile that a single wave walks
-#define WAVE_SYNC()                                          \
-    do {                                                     \
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
-        __builtin_amdgcn_wave_barrier();                     \
-    } while (0)
-
 struct BwdArgs {
     const float *in;         // the trace the envelope is taken of (before rectification)
     float *out;
@@ -645,8 +658,8 @@ struct BwdArgs {
 // single-wave workgroups (WPB = 1) land wherever the dispatcher's round-robin stands -- a tiny copy kernel in front of
 // the launch (the spectrogram tile of the multi-GPU step) left some SIMDs with three waves and others with one:
 // 2.96 -> 3.8 ms at 32 channels (profiles/r03_forcedist_*), and probably the "two modes" of round 2.
-template <int SE, bool PREFETCH, bool PIN = true, bool TRACE = false, int WPB = 4>
-__global__ __launch_bounds__(64 * WPB) void env_bwd_kernel(const SosPlanDev *__restrict__ P0, BwdArgs a)
+template <int SE, bool PREFETCH, bool PIN = true, bool TRACE = false, int WPB_ = WPB>
+__global__ __launch_bounds__(64 * WPB_) void env_bwd_kernel(const SosPlanDev *__restrict__ P0, BwdArgs a)
 {
     // TRACE (diagnostic build, option "sos_trace"): shader clocks per part of an iteration, summed per wave
     long long tr_acc[6] = {0, 0, 0, 0, 0, 0};
@@ -660,12 +673,12 @@ __global__ __launch_bounds__(64 * WPB) void env_bwd_kernel(const SosPlanDev *__r
         }                                                        \
     } while (0)
     constexpr int DE = 2 * SE;
-    __shared__ float4 lds_all[WPB][64 * 8];
+    __shared__ float4 lds_all[WPB_][64 * 8];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4 *lds = lds_all[wave];
     float *ldsf = reinterpret_cast<float *>(lds);
     const int lane = threadIdx.x & 63;
-    const long long unit = (long long)blockIdx.x * WPB + wave;
+    const long long unit = (long long)blockIdx.x * WPB_ + wave;
     if (unit >= a.units) return;                    // (no workgroup barrier anywhere: a wave may leave)
     const int seg = (int)(unit % a.n_seg);
     const long long ch = unit / a.n_seg;
@@ -2166,12 +2179,13 @@ int launch_scan(hipdsp_ctx *ctx, const SosPlanDev *dev, int S, SeqArgs a, long l
 {
     if (a.gain == 0.0) a.gain = 1.0;
     plan_segments(ctx, a.N, channels, warm, &a.seg_len, &a.n_seg);
-    long long blocks = channels * a.n_seg;
+    a.units = channels * a.n_seg;
+    long long blocks = (a.units + WPB - 1) / WPB;
     if (blocks > 0x7fffffffLL) {
         hipdsp_set_error("grid too large (%lld blocks)", blocks);
         return HIPDSP_ERR_INVALID;
     }
-    dim3 grid((unsigned)blocks), block(64);
+    dim3 grid((unsigned)blocks), block(64 * WPB);
     switch (S) {
     case 1: hipLaunchKernelGGL((sos_scan_kernel<1>), grid, block, 0, ctx->stream, dev, a); break;
     case 2: hipLaunchKernelGGL((sos_scan_kernel<2>), grid, block, 0, ctx->stream, dev, a); break;
@@ -2207,9 +2221,10 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
         long long warm = warmF;
         if (warmF >= (1LL << 40) || warmE >= (1LL << 40)) warm = 1LL << 50;
         plan_segments(ctx, frames, channels, warm, &fa.seg_len, &fa.n_seg);
-        long long blocks = channels * fa.n_seg;
+        fa.units = channels * fa.n_seg;
+        long long blocks = (fa.units + WPB - 1) / WPB;
         HD_REQUIRE(blocks <= 0x7fffffffLL, "grid too large");
-        dim3 grid((unsigned)blocks), block(64);
+        dim3 grid((unsigned)blocks), block(64 * WPB);
         const bool pf = ctx->sos_prefetch && frames >= 4 * TILE;
 #define HD_CKPT(A, B)                                                                                       \
     case (A) * 8 + (B):                                                                                     \
@@ -2252,8 +2267,7 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
     b.seg_tiles = seg_len / TILE;
     b.warm_tiles = warmE / TILE;
     b.units = channels * b.n_seg;
-    constexpr int WPB = 4;                                   // waves per workgroup: one per SIMD of a CU
-    long long blocks = (b.units + WPB - 1) / WPB;
+    long long blocks = (b.units + WPB - 1) / WPB;            // four waves per workgroup: one per SIMD of a CU
     HD_REQUIRE(blocks <= 0x7fffffffLL, "grid too large");
     dim3 grid((unsigned)blocks), block(64 * WPB);
     if (ctx->sos_single_wave_wg) { grid = dim3((unsigned)b.units); block = dim3(64); }
@@ -2481,10 +2495,6 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
                          "frames: use hipdsp_sosfilt_envelope + hipdsp_spectrogram", 4 * TILE);
         return HIPDSP_ERR_UNSUPPORTED;
     }
-    if (db_out && !(nfft == 2048 && hop == 1024) && !(ctx->chain_debug & 32)) {
-        hipdsp_set_error("the fused dB output is built for nfft 2048 / hop 1024 only");
-        return HIPDSP_ERR_UNSUPPORTED;
-    }
     HD_CHECK_HIP(hipSetDevice(ctx->device));
     {   // an earlier launch on this context may have reported a fault that nobody has looked at yet
         const int frc = hd_device_fault(ctx);
@@ -2582,7 +2592,8 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
         break
 #define HD_CHAIN_SHAPE(A, B, N, H)                                                                                  \
     case (A) * 8 + (B):                                                                                            \
-        hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, false, N, H>), grid, block, 0, ctx->stream, fplan->dev, edev_, a); \
+        if (db_out) hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, true, N, H>), grid, block, 0, ctx->stream, fplan->dev, edev_, a); \
+        else hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, false, N, H>), grid, block, 0, ctx->stream, fplan->dev, edev_, a); \
         break
 #define HD_CHAIN_ALL(N, H)                                                                                          \
     switch (SF * 8 + SE) {                                                                                         \

@@ -284,8 +284,8 @@ int hipdsp_envelope_multi(hipdsp_ctx *ctx, const hipdsp_sosplan *const *plans, i
  * databrowser.py:516-540; BASELINE configs[1] is 1024/256; 256/128 is BufferedSpectrogram's default,
  * bufferedspectrogram.py:14-16) -- band-pass plans of up to four and envelope
  * plans of up to two decaying sections, and frames >= 8192; anything else returns HIPDSP_ERR_UNSUPPORTED
- * (use the separate calls).  psd layout, the zero tail and the optional db_out (decibel(psd), fused epilogue;
- * nfft 2048 / hop 1024 only) as in hipdsp_spectrogram.
+ * (use the separate calls).  psd layout, the zero tail and the optional db_out (decibel(psd), fused epilogue:
+ * what SpecItem.update_plot shows, specitem.py:36) as in hipdsp_spectrogram, for every window of the list.
  * eplan == NULL: no envelope behind the filter (the reference's default trace set is filter + spectrogram,
  * src/audian/plugins.py:11-13) -- band-pass and spectrogram only, nothing is parked in the scratch.
  * spec_frames: the spectrogram is handed only the first spec_frames samples of yf (0 = all `frames`): through

@@ -691,6 +691,23 @@ def test_chain_forward_other_windows_and_longer_bandpasses(oracle, T, max_segmen
                     else:
                         assert rel_err(gs[ch, j], want_s[j, ch]) < TOL, (T, max_segments, j, ch)
                         assert rel_err(gs[ch, j], ss[ch, j]) < 1e-5, (T, max_segments, j, ch)
+            # the fused dB epilogue (SpecItem.update_plot's decibel(), specitem.py:36) for every window: same PSD
+            # bit for bit, decibel(PSD) next to it, -inf at and below 1e-20 and in the zero tail
+            db = hipdsp.DeviceArray(c, (C, nd + 2, F), np.float32)
+            ps2 = hipdsp.DeviceArray(c, (C, nd + 2, F), np.float32)
+            y2 = hipdsp.DeviceArray(c, (C, T), np.float32)
+            for arr in (db, ps2):
+                hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(arr), 0x7f, 4*C*(nd + 2)*F)
+            hipdsp.chain_forward(c, fplan, eplan, dx, T, y2, T, C, T, nfft, hop, rate, ps2, nd + 2, db_out=db)
+            assert np.array_equal(ps2.to_host(), gs) and np.array_equal(y2.to_host(), gf)
+            gdb, wdb = db.to_host(), oracle.decibel(gs.astype(np.float64))
+            fin = np.isfinite(wdb)
+            assert np.array_equal(np.isfinite(gdb), fin) and np.all(gdb[~fin] == -np.inf)
+            assert np.max(np.abs(gdb[fin] - wdb[fin])) < 1e-3, (T, nfft, hop)
+            # ... and without an envelope behind the filter (eplan NULL: the reference's default trace set)
+            hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(ps2), 0x7f, 4*C*(nd + 2)*F)
+            hipdsp.chain_forward(c, fplan, None, dx, T, y2, T, C, T, nfft, hop, rate, ps2, nd + 2)
+            assert np.array_equal(ps2.to_host(), gs) and np.array_equal(y2.to_host(), gf)
     finally:
         c.set_max_segments(0)
 
