@@ -130,6 +130,7 @@ _SIGNATURES = {
     'hipdsp_comm_create': ([_vp, _vp, _int, _int, _pp], _int),
     'hipdsp_comm_destroy': ([_vp, _vp], _int),
     'hipdsp_allgather_f32': ([_vp, _vp, _vp, _vp, _i64], _int),
+    'hipdsp_copy_probe': ([_vp, _vp, _vp, _sz], _int),
     'hipdsp_synth': ([_vp, _vp, _i64, _i64, _i64, _dbl, ctypes.c_uint64, _i64, _i64], _int),
 }
 

@@ -32,6 +32,7 @@ struct hipdsp_ctx {
     int chain_reserve_cus; // CUs hipdsp_chain_forward leaves without a workgroup (room for a co-resident RCCL kernel)
     long long *sos_trace;  // diagnostics: device buffer (9 int64 per WAVE of the envelope's backward sweep = channels x segments
                            // rows, hipdsp_chain... sizes unknown to the library: the tool sizes it from the planned grid)
+    long long sos_trace_rows;  // capacity of sos_trace in rows of 9 int64 (option "sos_trace_rows"; set it BEFORE "sos_trace")
     int sos_fair;          // rotating issue priorities in the single-wave sweeps (sos.hip: rotate_issue_priority)
     int sos_no_pin;        // experiments: scalar table loads left to hipcc's just-in-time placement (A/B of CASC_PIN_GROUPS)
     struct hd_pool *pool;  // stream-ordered cache of freed device blocks (ctx.hip)
@@ -85,6 +86,6 @@ static inline int hd_launch_status(const char *what)
 }
 
 int hipdsp_scratch(hipdsp_ctx *ctx, size_t bytes, void **out);
-// tw2 | tw3 | twn | window of the three-stage PSD kernel for nfft 2048 (radix 16 x 16 x 4) or 1024 (8 x 8 x 8),
-// device memory (spectrogram.hip)
+// tw2 | tw3 | twn | window of the three-stage PSD kernel, device memory (spectrogram.hip): served for nfft 2048
+// (radix 16 x 16 x 4), 1024 (8 x 8 x 8), 512 (8 x 8 x 4) and 256 (8 x 4 x 4) -- the sizes chain_fwd_kernel is built for
 int hd_fft_tables(hipdsp_ctx *ctx, int nfft, const float **dev);

@@ -100,6 +100,7 @@ int hipdsp_ctx_create(int device, void *stream, hipdsp_ctx **out)
     ctx->chain_split_frames = 0;
     ctx->sos_waves_per_cu = 0;
     ctx->sos_waves_min = 0;
+    ctx->sos_trace_rows = 0;
     ctx->sos_single_wave_wg = 0;
     ctx->chain_pairs = 0;
     ctx->chain_pairs_min = 0;
@@ -200,7 +201,12 @@ int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value)
     if (strcmp(name, "chain_debug") == 0) { ctx->chain_debug = (int)value; return HIPDSP_OK; }
     if (strcmp(name, "sos_no_pin") == 0) { ctx->sos_no_pin = value != 0; return HIPDSP_OK; }
     if (strcmp(name, "sos_fair") == 0) { ctx->sos_fair = value != 0; return HIPDSP_OK; }
-    if (strcmp(name, "sos_trace") == 0) { ctx->sos_trace = reinterpret_cast<long long *>((uintptr_t)value); return HIPDSP_OK; }
+    if (strcmp(name, "sos_trace_rows") == 0) { ctx->sos_trace_rows = value; return HIPDSP_OK; }
+    if (strcmp(name, "sos_trace") == 0) {
+        HD_REQUIRE(value == 0 || ctx->sos_trace_rows > 0, "set \"sos_trace_rows\" (capacity of the buffer in rows of 9 int64) first");
+        ctx->sos_trace = reinterpret_cast<long long *>((uintptr_t)value);
+        return HIPDSP_OK;
+    }
     if (strcmp(name, "chain_split_frames") == 0) { ctx->chain_split_frames = value != 0; return HIPDSP_OK; }
     if (strcmp(name, "chain_reserve_cus") == 0) {
         HD_REQUIRE(value >= 0 && value < ctx->n_cus, "chain_reserve_cus %lld not in [0, %d)", value, ctx->n_cus);
@@ -237,7 +243,15 @@ int hipdsp_malloc(hipdsp_ctx *ctx, size_t bytes, void **dptr)
     HD_CHECK_HIP(hipSetDevice(ctx->device));
     hd_pool *p = ctx->pool;
     const size_t want = (bytes + 511) & ~(size_t)511;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (ctx->stream) (void)hipStreamIsCapturing(ctx->stream, &capturing);
     auto it = p->cached.lower_bound(want);
+    // A block freed on ANOTHER stream needs an order between the two: an event wait -- which must not be issued into
+    // a stream capture (the event was recorded outside it) and does not exist for a block that was freed DURING a
+    // capture (no event could be recorded then).  Such candidates are passed over.
+    while (it != p->cached.end() && it->first <= want + want / 4 + 4096 && it->second.stream != ctx->stream &&
+           (it->second.freed == nullptr || capturing != hipStreamCaptureStatusNone))
+        ++it;
     if (it != p->cached.end() && it->first <= want + want / 4 + 4096) {
         const hd_block b = it->second;
         if (b.freed) {
@@ -286,13 +300,23 @@ int hipdsp_free(hipdsp_ctx *ctx, void *dptr)
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
         if (ctx->stream) (void)hipStreamIsCapturing(ctx->stream, &st);
         if (st == hipStreamCaptureStatusNone) {
+            hipError_t e = hipSuccess;
             if (!p->spare_events.empty()) {
                 b.freed = p->spare_events.back();
                 p->spare_events.pop_back();
             } else {
-                HD_CHECK_HIP(hipEventCreateWithFlags(&b.freed, hipEventDisableTiming));
+                e = hipEventCreateWithFlags(&b.freed, hipEventDisableTiming);
+                if (e != hipSuccess) b.freed = nullptr;
             }
-            HD_CHECK_HIP(hipEventRecord(b.freed, ctx->stream));
+            if (e == hipSuccess) e = hipEventRecord(b.freed, ctx->stream);
+            if (e != hipSuccess) {
+                // no event to order a later owner behind this stream: the block goes back to the driver instead
+                // of being leaked or cached without an order
+                (void)hipGetLastError();
+                if (b.freed) p->spare_events.push_back(b.freed);
+                HD_CHECK_HIP(hipFree(dptr));
+                return HIPDSP_OK;
+            }
         }
         p->cached.emplace(size, b);
         p->cached_bytes += size;

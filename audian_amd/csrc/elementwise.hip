@@ -495,6 +495,15 @@ __global__ __launch_bounds__(1024) void band_select_kernel(const float *__restri
 
 }  // namespace
 
+// The streaming ceiling of this box as MI355X_MICROARCH.md measures it: ONE float4 per thread, 256-thread blocks, no
+// loop -- reads and writes interleave at the finest grain (6.2-6.3 TB/s; grid-stride copies and hipMemcpy D2D reach
+// 4.7-5.1, tools/copy_sweep.hip).  bench.py reports it next to the 8 TB/s spec peak.
+__global__ __launch_bounds__(256) void copy_probe_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, long long n4)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) dst[i] = src[i];
+}
+
 extern "C" {
 
 int hipdsp_decibel(hipdsp_ctx *ctx, const float *p, float *out, int64_t n, double ref_power,
@@ -773,6 +782,18 @@ int hipdsp_mean_spectrum_db(hipdsp_ctx *ctx, const float *spec_tf, int64_t nfreq
                        (long long)nfreq, nsplit, 1.0 / (double)n, (float)(1.0 / ref_power), (float)min_power,
                        (float)floor_db, out);
     return hd_launch_status("mean_spectrum_finish");
+}
+
+int hipdsp_copy_probe(hipdsp_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    HD_REQUIRE(ctx != nullptr && dst != nullptr && src != nullptr, "NULL argument");
+    HD_REQUIRE(bytes % 16 == 0 && bytes / 16 / 256 < 0x7fffffffULL, "bytes must be a multiple of 16 (and below 8 TiB)");
+    if (bytes == 0) return HIPDSP_OK;
+    HD_CHECK_HIP(hipSetDevice(ctx->device));
+    const long long n4 = (long long)(bytes / 16);
+    hipLaunchKernelGGL(copy_probe_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const float4 *)src, (float4 *)dst, n4);
+    return hd_launch_status("copy_probe_kernel");
 }
 
 int hipdsp_synth(hipdsp_ctx *ctx, float *x, int64_t x_pitch, int64_t channels, int64_t frames, double rate,

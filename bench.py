@@ -122,6 +122,18 @@ def parse():
     return args
 
 
+def usable_cores():
+    """Host cores this process may really use: the affinity mask, capped by a cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota)/int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(args, sos, esos):
     """The reference's own CPU path (scipy call pattern, float64, one thread) on a
     bounded sample of the same workload; falls back to the C/NumPy oracle port."""
@@ -155,16 +167,17 @@ def cpu_baseline(args, sos, esos):
     # call sites are restated in oracle/scipy_path.py); "port": this repo's C/NumPy oracle instead
     out = {'value': C*T/dt/1e6, 'unit': 'Msamples/s', 'cores': 1,
            'kind': 'reference' if impl.startswith('scipy') else 'port',
-           'host_cores': os.cpu_count(),
+           'host_cores': os.cpu_count(), 'usable_cores': usable_cores(),
            'sample': f'{C} ch x {T/args.rate:g} s x {args.rate/1000:g} kHz float64, '
                      f'same chain, {dt:.1f} s wall; {impl}'}
-    # for fairness also an all-cores figure: channels split over 16 worker processes (the
-    # box's CPU share for one GPU), in a separate process tree that never touches the GPU
+    # for fairness also an all-cores figure: channels split over worker processes, one per channel up to the
+    # cores this process may use (affinity mask and cgroup quota), in a separate process tree that never
+    # touches the GPU
     try:
         import subprocess
         r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'scipy_path.py'), str(C),
                             str(T/args.rate), str(args.rate), str(args.nfft), str(args.hop),
-                            str(args.hp), str(args.lp), str(args.order), str(args.env), '16'],
+                            str(args.hp), str(args.lp), str(args.order), str(args.env), str(usable_cores())],
                            capture_output=True, text=True, timeout=180)
         if r.returncode == 0:
             allc = json.loads(r.stdout.strip().split('\n')[-1])
@@ -538,15 +551,22 @@ def main():
     hipdsp.synth(ctx, dx, T, C, T, args.rate, 1234 + args.config, c0=rank*C, c_total=world*C)
     ctx.synchronize()
 
-    # measured device-copy ceiling (read + write of one trace, hipMemcpy D2D), reported next
-    # to the 8 TB/s spec peak as SURVEY 8d asks; untimed, before the steps
-    ca, cb = ctx.event(), ctx.event()
-    hipdsp.lib.hipdsp_memcpy_d2d(ctx.handle, hipdsp._p(de), hipdsp._p(dx), 4*C*T)
+    # measured device-copy ceiling (read + write of one trace), reported next to the 8 TB/s spec peak as SURVEY 8d
+    # asks; untimed, before the steps: the float4-per-thread copy that reaches the part's streaming ceiling
+    # (hipdsp_copy_probe) and, for comparison with earlier rounds' lines, hipMemcpy D2D
+    ca, cb, cc = ctx.event(), ctx.event(), ctx.event()
+    nbytes = 4*C*T//16*16
+    hipdsp.check(hipdsp.lib.hipdsp_copy_probe(ctx.handle, hipdsp._p(de), hipdsp._p(dx), nbytes))
     ctx.record(ca)
     for _ in range(3):
-        hipdsp.lib.hipdsp_memcpy_d2d(ctx.handle, hipdsp._p(de), hipdsp._p(dx), 4*C*T)
+        hipdsp.check(hipdsp.lib.hipdsp_copy_probe(ctx.handle, hipdsp._p(de), hipdsp._p(dx), nbytes))
     ctx.record(cb)
-    copy_gbps = 3*8.0*C*T/(ctx.elapsed_ms(ca, cb)*1e-3)/1e9
+    for _ in range(3):
+        hipdsp.lib.hipdsp_memcpy_d2d(ctx.handle, hipdsp._p(de), hipdsp._p(dx), 4*C*T)
+    ctx.record(cc)
+    ctx.synchronize()
+    copy_gbps = 3*2.0*nbytes/(ctx.elapsed_ms(ca, cb)*1e-3)/1e9
+    memcpy_gbps = 3*8.0*C*T/(ctx.elapsed_ms(cb, cc)*1e-3)/1e9
 
     # The fused forward sweep (band-pass + envelope states + spectrogram in one launch) whenever the library
     # covers the shape: one untimed trial decides.
@@ -730,12 +750,13 @@ def main():
     achieved = alg_bytes[dom]/(ms[dom]*1e-3)/1e9
     # HBM bytes per launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE x 2
     # on gfx950, WRITE_SIZE; tools/summarize_profiles.py) -- only valid for the profiled shape
-    traffic = None
+    traffic = traffic_source = None
     pmc_file = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(pmc_file):
         pmc = json.load(open(pmc_file))
         if pmc.get('shape') == [C, T, args.nfft, args.hop] and dom in pmc.get('kernels', {}):
             traffic = pmc['kernels'][dom]['hbm_bytes']
+            traffic_source = 'profiles/' + str(pmc.get('source'))
     kernels = {k: {'ms': round(ms[k], 4),
                    'GBps': round(alg_bytes[k]/(ms[k]*1e-3)/1e9, 1) if k in alg_bytes and ms[k] > 0 else None}
                for k in names if k in alg_bytes}
@@ -867,9 +888,10 @@ def main():
             },
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved/HBM_PEAK_GBS, 4), 'traffic': traffic,
+                         'frac': round(achieved/HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_source,
                          'algorithmic_bytes': alg_bytes[dom],
-                         'device_copy_GBps': round(copy_gbps, 1),
+                         'device_copy_GBps': round(copy_gbps, 1),         # float4-per-thread copy kernel (hipdsp_copy_probe)
+                         'hipMemcpy_d2d_GBps': round(memcpy_gbps, 1),
                          'per_stage_accounting_GBps': stage_gbps,
                          'engine_clock_MHz_in_kernel': engine_mhz},
             'kernels': kernels,

@@ -72,8 +72,10 @@ int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
  *                        whole CU each, so a kernel that stays resident next to it (RCCL's all-gather in the
  *                        multi-GPU step) needs CUs of its own or a second round of workgroups forms
  *   "sos_no_pin"         non-zero: plan tables fetched by just-in-time scalar loads (A/B, tools/pin_ab.py)
- *   "sos_trace"          diagnostics: device address (0 = off) of 9 int64 per wave of the envelope's backward sweep --
- *                        start and end of the wave in 100 MHz ticks, its HW_ID, 6 clock sums (tools/sweep_trace.py)
+ *   "sos_trace"          diagnostics: device address (0 = off) of 9 int64 per wave (= channel x segment) of the
+ *                        envelope's backward sweep -- start and end of the wave in 100 MHz ticks, its HW_ID, 6 clock
+ *                        sums (tools/sweep_trace.py); "sos_trace_rows" (set it first) is the buffer's capacity in such
+ *                        rows, waves beyond it do not report
  *   "sos_fair"           0: the single-wave sweeps without rotating issue priorities (A/B)
  *   "force_generic_fft"  non-zero: every nfft takes the generic radix-2 / four-step kernels
  *   "spec_kernel"        0 = default per size, 2 = two-stage, 3 = three-stage FFT kernel
@@ -444,6 +446,14 @@ int hipdsp_comm_destroy(hipdsp_ctx *ctx, hipdsp_comm *comm);
 /* recv[r*count : (r+1)*count] = rank r's send[0:count], on the context's stream. */
 int hipdsp_allgather_f32(hipdsp_ctx *ctx, hipdsp_comm *comm, const float *send, float *recv,
                          int64_t count_per_rank);
+
+/* ---- measurement aid ("also report a measured device-copy ceiling") ---- */
+
+/* dst[0:bytes] = src[0:bytes] by the copy pattern that reaches this part's streaming ceiling: one float4 per
+ * thread, 256-thread blocks, no loop (MI355X_MICROARCH.md: 6.29 TB/s read + write; grid-stride copies and
+ * hipMemcpy D2D stay at 4.7-5.1).  bytes must be a multiple of 16; the buffers must not overlap.  bench.py
+ * times it as `roofline.device_copy_GBps`. */
+int hipdsp_copy_probe(hipdsp_ctx *ctx, void *dst, const void *src, size_t bytes);
 
 /* ---- synthetic input (bench / tests) --------------------------- */
 

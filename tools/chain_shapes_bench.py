@@ -38,12 +38,22 @@ for order in (2, 4):
         def separate():
             hipdsp.sosfilt_envelope(ctx, fplan, eplan, dx, T, df, T, de, T, C, T, phase=1)
             hipdsp.spectrogram(ctx, df, T, C, T, nfft, hop, rate, ds, nd)
-        fu, se = [], []
+        noenv = lambda: hipdsp.chain_forward(ctx, fplan, None, dx, T, df, T, C, T, nfft, hop, rate, ds, nd)
+        fu, se, ne = [], [], []
         for rnd in range(3):
             fu.append(timed(fused))
             se.append(timed(separate))
-        fu, se = sorted(fu)[1], sorted(se)[1]
+            ne.append(timed(noenv))
+        fu, se, ne = sorted(fu)[1], sorted(se)[1], sorted(ne)[1]
         gb = (8.0*C*T + 4.0*C*nd*F)/1e9
-        print(f'band-pass {order} sections, nfft {nfft} hop {hop}: fused {fu:7.3f} ms ({gb/fu*1e3:5.0f} GB/s of its '
-              f'{gb:.1f} GB) | separate {se:7.3f} ms | fused/separate {fu/se:.2f}', flush=True)
+        line = (f'band-pass {order} sections, nfft {nfft} hop {hop}: fused {fu:7.3f} ms ({gb/fu*1e3:5.0f} GB/s of its '
+                f'{gb:.1f} GB) | separate {se:7.3f} ms | fused/separate {fu/se:.2f} | no envelope (eplan NULL) {ne:7.3f} ms '
+                f'({gb/ne*1e3:5.0f} GB/s)')
+        if order == 2 and 4*C*nd*F < 40e9:
+            db = hipdsp.DeviceArray(ctx, (C, nd, F), np.float32)
+            wdb = lambda: hipdsp.chain_forward(ctx, fplan, eplan, dx, T, df, T, C, T, nfft, hop, rate, ds, nd, db_out=db)
+            t = sorted(timed(wdb) for _ in range(3))[1]
+            line += f' | with the dB output {t:7.3f} ms ({(gb + 4.0*C*nd*F/1e9)/t*1e3:5.0f} GB/s)'
+            db.free()
+        print(line, flush=True)
         ds.free()

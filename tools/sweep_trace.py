@@ -23,6 +23,7 @@ tr = hipdsp.DeviceArray(ctx, (W, 9), np.int64)
 tr.zero_()
 hipdsp.sosfilt_envelope(ctx, fplan, eplan, dx, T, df, T, de, T, C, T)       # checkpoints + warm
 ctx.set_option('sos_fair', int(os.environ.get('FAIR', '1')))
+ctx.set_option('sos_trace_rows', W)
 ctx.set_option('sos_trace', tr.ptr)
 e0, e1 = ctx.event(), ctx.event()
 ctx.record(e0)
