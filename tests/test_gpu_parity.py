@@ -137,6 +137,69 @@ def test_envelope_long_vs_oracle(oracle, env, order, hp, rate, T):
     assert np.array_equal(plain, gh.gpu_envelope(sos, x, clamp=hp == 0))
 
 
+@pytest.mark.parametrize('env,rate,T,C', [(20.0, 96000.0, 3000000, 1), (20.0, 96000.0, 1200000, 5), (5.0, 48000.0, 2000000, 2),
+                                          (500.0, 48000.0, 900000, 3)])
+def test_envelope_state_handover_is_exact_for_every_segmentation(oracle, env, rate, T, C):
+    """The envelope's forward sweep starts every time segment from ZERO state and env_fix_kernel hands the true
+    states over (exact, no warm-up): one segment, three, the planner's choice and one-tile segments
+    (hundreds of segments far shorter than the filter's memory: the 20 Hz low-pass at 96 kHz remembers 26 tiles, so
+    a state is the sum of up to 27 hand-overs) must agree to < 1e-6 with each other and to 1e-4 with the oracle --
+    through hipdsp_envelope, hipdsp_sosfilt_envelope and hipdsp_chain_forward + backward sweep."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rng = np.random.default_rng(int(T + env))
+    x = synth(rng, T, C, rate)
+    esos = butter_sos(2, env, 'lowpass', rate)
+    sos = butter_sos(2, (300.0, 3000.0), 'bandpass', rate)
+    want = np.zeros((T, C))
+    oracle.envelope_process(esos, x.astype(np.float64), want, 0)
+    c = gh.ctx()
+    dx = gh.to_planar(c, x)
+    fplan, eplan = hipdsp.SosPlan(c, sos), hipdsp.SosPlan(c, esos)
+    warm, _ = eplan.info()
+    nfft, hop = 2048, 1024
+    nd = (T + hop - 1)//hop
+    results, chains = {}, {}
+    try:
+        for name, opts in [('one', {'max_segments': 1}), ('three', {'max_segments': 3}), ('planner', {}),
+                           ('one-tile segments', {'n_cus': 1024, 'sos_waves_per_cu': 16, 'sos_waves_min': 16})]:
+            for k, v in opts.items():
+                c.set_option(k, v)
+            de = hipdsp.DeviceArray(c, (C, T), np.float32)
+            hipdsp.envelope(c, eplan, dx, T, de, T, C, T, 0)
+            results[name] = de.to_host()
+            yf, ye = hipdsp.DeviceArray(c, (C, T), np.float32), hipdsp.DeviceArray(c, (C, T), np.float32)
+            ps = hipdsp.DeviceArray(c, (C, nd, nfft//2 + 1), np.float32)
+            hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, nfft, hop, rate, ps, nd)
+            hipdsp.sosfilt_envelope(c, fplan, eplan, dx, T, yf, T, ye, T, C, T, phase=2)
+            seg, n = hipdsp.chain_plan(c, fplan, eplan, C, T)
+            chains[name] = (ye.to_host(), yf.to_host(), n, seg)
+            if name == 'one-tile segments' and warm >= 8*2048:
+                assert seg < warm//4 and n > 50          # many hand-overs inside the filter's memory
+            c.set_option('max_segments', 0)
+            c.set_option('n_cus', 256)
+            c.set_option('sos_waves_per_cu', 0)
+            c.set_option('sos_waves_min', 0)
+    finally:
+        for k, v in (('max_segments', 0), ('n_cus', 256), ('sos_waves_per_cu', 0), ('sos_waves_min', 0)):
+            c.set_option(k, v)
+    assert chains['one'][2] == 1 and chains['three'][2] <= 3
+    ref = results['one']
+    for name, got in results.items():
+        for ch in range(C):
+            assert rel_err(got[ch], want[:, ch]) < TOL, (name, ch)
+            assert rel_err(got[ch], ref[ch]) < 1e-6, (name, ch)
+    want_f = oracle.sosfilt(sos, x.astype(np.float64))
+    ref_e = chains['one'][0]
+    for name, (ge, gf, n, seg) in chains.items():
+        want_e = np.zeros((T, C))
+        oracle.envelope_process(esos, gf.T.astype(np.float64), want_e, 0)
+        for ch in range(C):
+            assert rel_err(gf[ch], want_f[:, ch]) < TOL, (name, ch)
+            assert rel_err(ge[ch], want_e[:, ch]) < TOL, (name, ch)
+            assert rel_err(ge[ch], ref_e[ch]) < 1e-6, (name, ch, n)
+
+
 @pytest.mark.parametrize('T', [2050, 70000, 300000])
 def test_envelope_skip_values_vs_oracle(oracle, T):
     """nbefore (skip) below, at and above tile borders: the backward sweep stops at the tile that
