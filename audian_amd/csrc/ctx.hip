@@ -102,6 +102,7 @@ int hipdsp_ctx_create(int device, void *stream, hipdsp_ctx **out)
     ctx->sos_waves_min = 0;
     ctx->sos_trace_rows = 0;
     ctx->sos_single_wave_wg = 0;
+    ctx->sos_debug = 0;
     ctx->chain_pairs = 0;
     ctx->chain_pairs_min = 0;
     ctx->spec_no_half = 0;
@@ -185,6 +186,7 @@ int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value)
         return HIPDSP_OK;
     }
     if (strcmp(name, "chain_pairs_min") == 0) { ctx->chain_pairs_min = (int)value; return HIPDSP_OK; }
+    if (strcmp(name, "sos_debug") == 0) { ctx->sos_debug = (int)value; return HIPDSP_OK; }
     if (strcmp(name, "sos_single_wave_wg") == 0) { ctx->sos_single_wave_wg = value != 0; return HIPDSP_OK; }
     if (strcmp(name, "sos_prefetch") == 0) { ctx->sos_prefetch = value != 0; return HIPDSP_OK; }
     if (strcmp(name, "pool_limit_mb") == 0) {

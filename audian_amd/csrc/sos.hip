@@ -633,6 +633,8 @@ struct BwdArgs {
     long long units;         // channels * n_seg (the grid is rounded up to whole workgroups)
     long long *trace;        // option "sos_trace": 9 words per wave (start, end in 100 MHz ticks, HW_ID, 6 clock sums)
     long long trace_rows;    // rows of `trace` (option "sos_trace_rows"): waves beyond it do not report
+    int debug;               // measurements only, results wrong (option "sos_debug"): 1 = every interior tile is stored into
+                             // the channel's first tile (writes stay in L2), 2 = every prefetch reads the first tile
     int fair;                // rotate_issue_priority() per tile (option "sos_fair", default off: no gain measured)
 };
 
@@ -696,8 +698,9 @@ __global__ __launch_bounds__(64 * WPB_) void env_bwd_kernel(const SosPlanDev *__
     v4f nx[8], nck[SE];
     bool pre = false;
     auto fetch = [&](long long tidx) {
+        const long long tsrc = (a.debug & 2) ? 0 : tidx;
 #pragma unroll
-        for (int k = 0; k < 8; k++) nx[k] = asm_load16(in + tidx * TILE + 256 * k + 4 * lane);
+        for (int k = 0; k < 8; k++) nx[k] = asm_load16(in + tsrc * TILE + 256 * k + 4 * lane);
 #pragma unroll
         for (int i = 0; i < SE; i++) nck[i] = asm_load16(ckpt + tidx * DE + 2 * i);
     };
@@ -858,11 +861,12 @@ __global__ __launch_bounds__(64 * WPB_) void env_bwd_kernel(const SosPlanDev *__
                 // interior tile: exactly 8 vector stores (max(x, 0) as one instruction: fmaxf() costs a second one
                 // that only quiets signalling NaNs)
                 if (a.clamp) {
+                    const long long tdst = (a.debug & 1) ? a.skip : tile;
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
                         const float4 v = lds[lds_slot(8 * k + (lane >> 3), lane & 7)];
                         f4u t; t.x = max_zero(v.x); t.y = max_zero(v.y); t.z = max_zero(v.z); t.w = max_zero(v.w);
-                        *reinterpret_cast<f4u *>(out + (tile + 256 * k + 4 * lane - a.skip)) = t;
+                        *reinterpret_cast<f4u *>(out + (tdst + 256 * k + 4 * lane - a.skip)) = t;
                     }
                 } else {
 #pragma unroll
@@ -2037,6 +2041,7 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
     b.rectify = rectify; b.clamp = clamp; b.gain = rectify ? gain : 1.0;
     b.trace = ctx->sos_trace;
     b.trace_rows = ctx->sos_trace_rows;
+    b.debug = ctx->sos_debug;
     b.fair = ctx->sos_fair;
     const long long used_tiles = n_tiles - skip / TILE;      // tiles below `skip` are never visited
     long long seg_len = 0;

@@ -849,6 +849,36 @@ def main():
         parity = parity_subset(args, hipdsp, ctx, dx, df, ds, de, T, nd, sos, esos, extra)
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args, sos, esos)
+    # Latency-sized jobs (BASELINE configs[1]: four launches of 5-100 us): the same step captured once into a
+    # hipGraph and replayed, as the interactive path does (configs[4], tests/test_gpu_graph.py) -- reported next to
+    # the launch-by-launch figure, which stays `value`
+    graph_ms = None
+    if rank == 0 and world == 1 and not multi and fuse3 and dt/args.steps < 2e-3:
+        try:
+            gctx = hipdsp.Context(local_rank, ctx.create_stream())
+            gctx.reserve(8*C*((T + edge + 2047)//2048)*2*len(esos))
+
+            def gstep():
+                hipdsp.chain_forward(gctx, plan, eplan, dx, T, df, T, C, T, args.nfft, args.hop, args.rate, ds, nd,
+                                     rectify=True, gain=np.pi/2)
+                hipdsp.sosfilt_envelope(gctx, plan, eplan, dx, T, df, T, de, T, C, T, rectify=True, gain=np.pi/2,
+                                        clamp=True, phase=2)
+            gstep()
+            gctx.synchronize()
+            gctx.graph_begin()
+            gstep()
+            graph = gctx.graph_end()
+            for _ in range(args.warmup):
+                gctx.graph_launch(graph)
+            gctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                gctx.graph_launch(graph)
+            gctx.synchronize()
+            graph_ms = (time.perf_counter() - t0)/args.steps*1e3
+            gctx.graph_destroy(graph)
+        except Exception as err:
+            graph_ms = f'failed: {type(err).__name__}: {err}'[:200]
     facade = None
     if rank == 0 and world == 1 and not multi and not args.no_facade and fuse3:
         try:
@@ -899,6 +929,8 @@ def main():
             'parity_max_rel_err': parity,
             'cpu_baseline': cpu,
         }
+        if graph_ms is not None:
+            line['graph_ms_per_step'] = graph_ms if isinstance(graph_ms, str) else round(graph_ms, 4)
         if facade is not None:
             line['facade'] = facade
             line['facade_ms_per_step'] = facade.get('facade_ms_per_step')
