@@ -52,7 +52,12 @@ class BufferedArray(object):
         right after opening the recording (``self.data.set_unwrap(unwrap, unwrap_clip, False, unit)``,
         src/audian/data.py:180; CLI ``-u`` / ``-U``, src/audian/audian.py:1485-1512).  ``thresh`` <= 1e-3
         turns it off.  Without clipping and down-scaling the amplitude range doubles.  audioio's source
-        is not available here: restated from its documentation (parity unpinned)."""
+        is not available here: restated from its documentation -- UNVERIFIED against audioio (parity
+        unpinned; `unit` is accepted and ignored).  Like audioio's per-buffer call, every slab a loader
+        reads is unwrapped on its own, starting from zero offset at its first frame: a buffer move that
+        keeps an overlap and loads the rest can therefore carry different offsets in the kept and the new
+        part of a recording that is wrapped at the seam (tests/test_gpu_facade.py pins exactly this
+        behaviour, not audioio's)."""
         self.unwrap_ampl = float(self.ampl_max if self.unwrap_thresh <= 1e-3 else self.unwrap_ampl)
         self.unwrap_thresh = float(thresh)
         self.unwrap_clips = bool(clips)

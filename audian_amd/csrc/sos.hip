@@ -704,6 +704,8 @@ __global__ __launch_bounds__(64 * WPB_) void env_bwd_kernel(const SosPlanDev *__
 #pragma unroll
         for (int i = 0; i < SE; i++) nck[i] = asm_load16(ckpt + tidx * DE + 2 * i);
     };
+    // (Tried in round 3 and dropped: the eight loads in four pairs spread over the forward cascade instead of one
+    // burst -- 6.02 against 5.98 ms, profiles/r03_bwd_split_ab.log.)
     // The fetch itself is unconditional (a tile that cannot be prefetched fetches the highest full
     // tile instead and drops it): a conditional asm load would make `nx` a phi of two register
     // sets, and the copies hipcc inserts for it read the registers while the loads are in flight.
