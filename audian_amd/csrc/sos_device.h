@@ -1,0 +1,238 @@
+// sos_device.h -- device helpers, launch argument blocks and small host helpers shared by the IIR sweeps (sos.hip) and
+// the fused sweeps (chain.hip).  Everything sits in an anonymous namespace: each translation unit gets its own copy.
+#pragma once
+#include "common.h"
+#include "sos_plan.h"
+
+struct hipdsp_sosplan {
+    SosPlanDev *host;      // pinned
+    SosPlanDev *dev;
+    hipEvent_t uploaded;
+    bool valid;
+};
+
+// defined in sos.hip: hands the true states over between the time segments of a forward sweep (env_fix_kernel)
+int hd_launch_env_fix(hipdsp_ctx *ctx, const SosPlanDev *edev, int SE, double *ckpt, long long ckpt_pitch, long long channels,
+                      int n_seg, long long seg_len, long long n_tiles);
+
+namespace {
+
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte aligned float4
+
+struct SeqArgs {
+    const float *in;        // channel 0 of the input
+    float *out;             // channel 0 of the output
+    long long in_pitch, out_pitch;
+    long long N;            // frames
+    long long seg_len;      // multiple of TILE
+    int n_seg;
+    long long skip;         // nbefore: the first `skip` outputs are dropped
+    // optional initial state of the cascade at sample 0 (scipy: sosfilt(..., zi = sosfilt_zi * x0)):
+    // plan zi * zi_scale * zi_ref[channel * zi_ref_pitch]; NULL = zero state
+    const float *zi_ref;
+    long long zi_ref_pitch;
+    double zi_scale;
+    // the cascade filters gain * in (hipdsp_envelope_multi: the pi/2 of the rectified trace rides on the first
+    // plan's numerator instead of on every sample); launch_scan turns 0 into 1
+    double gain;
+    long long units;        // channels * n_seg (the grid is rounded up to whole workgroups)
+};
+
+__device__ __forceinline__ long long opaque_zero()
+{
+    int z;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    return (long long)z;
+}
+
+// Slot (16 bytes) of quarter-row q of row `row` in the 64 x 8 tile image.  The XOR term must make three
+// access patterns conflict-free at once (MI355X_MICROARCH.md, LDS): the coalesced view (a 16-byte
+// access per lane, 8 consecutive lanes in one row: any XOR does), the row-per-lane ds_read_b128 (16-lane
+// groups {0-3,12-15,20-27}..., banks modulo 64 dwords: rows of equal parity must differ in the term,
+// which (row & 7) ^ (row >> 3 & 1) does over any 16 rows distinct modulo 16) and the row-per-lane
+// ds_write_b128 (8 consecutive lanes, banks modulo 32 dwords: 8 consecutive rows must differ -- the
+// round-1 term (row >> 1) & 7 repeated in pairs there, a 2-way conflict on every store of phase 3:
+// 11.7 % of the fused kernel's LDS cycles).
+__device__ __forceinline__ int lds_slot(int row, int q) { return row * 8 + (q ^ ((row & 7) ^ ((row >> 3) & 1))); }
+__device__ __forceinline__ int lds_float_index(int s) { return lds_slot(s >> 5, (s & 31) >> 2) * 4 + (s & 3); }
+
+// samples p..p+3 of a row of `n` frames, zeros past the end
+__device__ __forceinline__ float4 load_four(const float *in, long long p, long long n)
+{
+    if (p + 4 <= n) {
+        const f4u t = *reinterpret_cast<const f4u *>(in + p);
+        return make_float4(t.x, t.y, t.z, t.w);
+    }
+    float4 v;
+    v.x = p < n ? in[p] : 0.f;
+    v.y = p + 1 < n ? in[p + 1] : 0.f;
+    v.z = p + 2 < n ? in[p + 2] : 0.f;
+    v.w = p + 3 < n ? in[p + 3] : 0.f;
+    return v;
+}
+
+// store samples p..p+3 restricted to [lo, hi) at out[p - shift]
+__device__ __forceinline__ void store_four(float *out, long long p, float4 v, long long lo, long long hi,
+                                           long long shift)
+{
+    if (p >= lo && p + 4 <= hi) {
+        f4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+        *reinterpret_cast<f4u *>(out + (p - shift)) = t;
+    } else {
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (p + k >= lo && p + k < hi) out[p + k - shift] = e[k];
+    }
+}
+
+// The plan tables (coefficients, G, M: up to ~3 KB) are wave-uniform and must come through
+// scalar loads (s_load -> SGPR operands of v_fma_f64).  Hoisting them out of the tile loop would
+// need ~500 SGPRs and spill through v_writelane; a "memory" clobber would demote them to
+// per-lane vector loads.  So every use goes through PLAN_OF(): the same pointer plus an opaque,
+// always-zero scalar that the compiler must assume changes each time, which pins the s_load
+// next to its use.
+#define PLAN_OF(ptr) (reinterpret_cast<const SosPlanDev *>(reinterpret_cast<const char *>(ptr) + opaque_zero()))
+
+// The value of the lane below (lane 0: zero): a full-wave shift by one as a DPP move inside the VALU
+// (wave_shr:1, bound_ctrl) instead of a trip through the LDS crossbar (ds_bpermute) plus a select.
+__device__ __forceinline__ double casc_wave_shr1(double x)
+{
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x138, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x138, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Shift by 32 lanes with zero fill: v_permlane32_swap (gfx950) exchanges the upper half of its first
+// operand with the lower half of its second; first operand 0, second x -> (0..0, x[0..31]).
+__device__ __forceinline__ double casc_wave_shr32(double x)
+{
+    const long long b = __builtin_bit_cast(long long, x);
+    const auto lo = __builtin_amdgcn_permlane32_swap(0, (int)b, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(0, (int)(b >> 32), false, false);
+    return __builtin_bit_cast(double, ((long long)hi[0] << 32) | (unsigned int)lo[0]);
+}
+
+// a wave-local fence: LDS operations of one wave execute in order, no workgroup barrier is needed between the
+// phases of a tile that a single wave walks
+#define WAVE_SYNC()                                          \
+    do {                                                     \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                     \
+    } while (0)
+
+constexpr int WPB = 4;     // waves per workgroup of the single-wave-per-unit sweeps: one per SIMD of a CU (see env_bwd_kernel)
+
+struct CkptArgs {
+    const float *in;
+    float *yf;
+    double *ckpt;
+    long long in_pitch, yf_pitch, ckpt_pitch;
+    long long T, seg_len;
+    int n_seg, edge, rectify;
+    long long units;        // channels * n_seg (the grid is rounded up to whole workgroups; the fused sweep: ChainArgs::units)
+    double gain;            // the envelope filters gain * |y|: folded into its cascade (CASC_GAIN), never into the samples
+};
+
+// 16-byte global load the compiler does not track: the caller counts vmcnt by hand, so that the
+// wait for a prefetched tile does not also wait for the stores issued after it.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v4f asm_load16(const void *p)
+{
+    v4f r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ float asm_load4(const float *p)
+{
+    float r;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+
+// Fair shares of a SIMD for persistent waves that do not talk to each other.  The issue arbiters serve the
+// OLDEST wave first: of four waves of one SIMD that walk equal segments, the one in slot 0 gets whatever it
+// asks for and ends after 55 % of the launch, the one in slot 3 after 95 % (tools/sweep_trace.py), and the
+// tail with a quarter of the waves cannot keep the HBM pipes full.  Called once per tile, this gives the
+// four slots four DIFFERENT priorities that rotate with the shader clock (the same clock for all waves of
+// the SIMD, so the priorities stay distinct): every wave spends a quarter of the time at each level.
+__device__ __forceinline__ void rotate_issue_priority(unsigned slot)
+{
+    const unsigned p = (slot + (unsigned)(__builtin_readcyclecounter() >> 14)) & 3u;
+    if (p == 0) __builtin_amdgcn_s_setprio(0);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+// max(x, 0) as a single instruction (result as fmaxf(x, 0.f))
+__device__ __forceinline__ float max_zero(float x)
+{
+    float r;
+    asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ void set_issue_priority(int p)     // (s_setprio takes an immediate)
+{
+    if (p == 0) __builtin_amdgcn_s_setprio(0);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+__device__ __forceinline__ unsigned wave_slot_of_simd()
+{
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hw));
+    return hw;
+}
+
+struct BwdArgs {
+    const float *in;         // the trace the envelope is taken of (before rectification)
+    float *out;
+    const double *ckpt;
+    long long in_pitch, out_pitch, ckpt_pitch;
+    long long T, skip;
+    long long n_tiles;       // ceil((T + edge) / TILE)
+    long long seg_tiles, warm_tiles;
+    int n_seg, edge, rectify, clamp;
+    double gain;             // as in CkptArgs
+    long long units;         // channels * n_seg (the grid is rounded up to whole workgroups)
+    long long *trace;        // option "sos_trace": 9 words per wave (start, end in 100 MHz ticks, HW_ID, 6 clock sums)
+    long long trace_rows;    // rows of `trace` (option "sos_trace_rows"): waves beyond it do not report
+    int debug;               // measurements only, results wrong (option "sos_debug"): 1 = every interior tile is stored into
+                             // the channel's first tile (writes stay in L2), 2 = every prefetch reads the first tile
+    int fair;                // rotate_issue_priority() per tile (option "sos_fair", default off: no gain measured)
+};
+
+__global__ void zero_rows_kernel(float *__restrict__ y, long long y_pitch, long long n, float value)
+{
+    long long ch = blockIdx.y;
+    float *yo = y + ch * y_pitch;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        yo[i] = value;
+}
+
+// the single-wave sweeps: up to "sos_waves_per_cu" (16) waves per CU, four SIMDs per CU
+// ("sos_waves_min" = w, experiments: force w waves per CU by making every level below it cost the same)
+void plan_segments(const hipdsp_ctx *ctx, long long N, long long channels, long long warm,
+                   long long *seg_len, int *n_seg)
+{
+    const int w_max = ctx->sos_waves_per_cu > 0 ? ctx->sos_waves_per_cu : 16;
+    hd_plan_segments_occ(ctx->n_cus, w_max, ctx->sos_waves_min >= w_max ? 0 : 4, ctx->max_segments, N, channels, warm, seg_len, n_seg);
+}
+
+// the fused sweeps: up to 8 pairs of waves per workgroup = CU ("chain_pairs": fewer, experiments)
+constexpr int CHAIN_P = 8;
+void plan_segments_chain(const hipdsp_ctx *ctx, long long N, long long channels, long long warm,
+                         long long *seg_len, int *n_seg)
+{
+    int cus = ctx->n_cus - ctx->chain_reserve_cus;
+    if (cus < 1) cus = 1;                                  // (options set in an order that leaves none: ADVICE round 2)
+    hd_plan_segments_occ(cus, ctx->chain_pairs > 0 ? ctx->chain_pairs : CHAIN_P, 0, ctx->max_segments, N, channels, warm, seg_len,
+                      n_seg);
+}
+
+}  // namespace

@@ -209,10 +209,17 @@ def main():
     want = sys.argv[2:]
     lines = open(path).read().split('\n')
     total, bad, nk = 0, [], 0
-    for name, body in kernels(lines):
-        if want and not any(w in name for w in want):
-            continue
-        n, pr = check(name, body)
+    todo = [(name, body) for name, body in kernels(lines) if not want or any(w in name for w in want)]
+    # the kernels are independent: one worker process per core (155 kernels of the fused sweeps take minutes in one)
+    import multiprocessing as mp
+    import os
+    workers = max(1, min(len(todo), int(os.environ.get('CHECK_ISA_JOBS', '0')) or (os.cpu_count() or 1)))
+    if workers > 1:
+        with mp.get_context('fork').Pool(workers) as pool:
+            results = pool.starmap(check, sorted(todo, key=lambda kb: -len(kb[1])), chunksize=1)
+    else:
+        results = [check(name, body) for name, body in todo]
+    for n, pr in results:
         if n:
             nk += 1
         total += n
