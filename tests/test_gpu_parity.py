@@ -200,6 +200,33 @@ def test_envelope_state_handover_is_exact_for_every_segmentation(oracle, env, ra
             assert rel_err(ge[ch], ref_e[ch]) < 1e-6, (name, ch, n)
 
 
+@pytest.mark.parametrize('order,env,hp', [(6, 40.0, 0.0), (8, 60.0, 0.0), (3, 300.0, 20.0), (4, 800.0, 50.0)])
+def test_envelope_state_handover_with_three_and_four_sections(oracle, order, env, hp):
+    """The same exactness for envelope plans of three and four sections (hipdsp_envelope alone: env_fix_kernel<3>,
+    <4>; low-pass of order 6 / 8, band-pass envelope of order 3 / 4): one segment against one-tile segments."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rate, T, C = 48000.0, 700000, 2
+    rng = np.random.default_rng(order)
+    x = synth(rng, T, C, rate)
+    sos = butter_sos(order, (hp, env), 'bandpass', rate) if hp > 0 else butter_sos(order, env, 'lowpass', rate)
+    assert len(sos) in (3, 4)
+    want = np.zeros((T, C))
+    oracle.envelope_process(sos, x.astype(np.float64), want, 0, highpass_cutoff=hp)
+    c = gh.ctx()
+    try:
+        one = gh.gpu_envelope(sos, x, clamp=hp == 0, max_segments=1)
+        for k, v in (('n_cus', 1024), ('sos_waves_per_cu', 16), ('sos_waves_min', 16)):
+            c.set_option(k, v)
+        many = gh.gpu_envelope(sos, x, clamp=hp == 0)
+    finally:
+        for k, v in (('n_cus', 256), ('sos_waves_per_cu', 0), ('sos_waves_min', 0)):
+            c.set_option(k, v)
+    for ch in range(C):
+        assert rel_err(one[:, ch], want[:, ch]) < TOL and rel_err(many[:, ch], want[:, ch]) < TOL, ch
+        assert rel_err(many[:, ch], one[:, ch]) < 1e-6, ch
+
+
 @pytest.mark.parametrize('T', [2050, 70000, 300000])
 def test_envelope_skip_values_vs_oracle(oracle, T):
     """nbefore (skip) below, at and above tile borders: the backward sweep stops at the tile that
