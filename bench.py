@@ -592,10 +592,9 @@ def main():
         sctx = hipdsp.Context(local_rank, ctx.create_stream())
     ev_filtered, ev_spec = ctx.event(), ctx.event()
     if multi:
-        # The IIR sweeps launch one wave per (channel, segment) and want all of them resident at
-        # once.  Next to RCCL's all-gather kernel a few would have to wait for a second round:
-        # 12 waves per CU (instead of 16) leave a wave slot per SIMD free and cost < 2 % alone
-        # (tools/coresidency_probe.hip: +9 % instead of +18 % next to a spinning kernel).
+        # The IIR sweeps launch one wave per (channel, segment) and want all of them resident at once: at most
+        # 12 waves per CU leave a wave slot per SIMD free for whatever else is resident (round 3: the planner
+        # picks 8 anyway, and the gather no longer runs next to the backward sweep)
         ctx.set_option('sos_waves_per_cu', 12)
 
     def tile_frames_of(name):

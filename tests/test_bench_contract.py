@@ -134,3 +134,48 @@ def test_configs1_line():
     d = json.loads(out.stdout.splitlines()[-1])
     assert 'configs[1]' in d['config']['workload'] and d['config']['channels_per_gpu'] == 4
     assert d['parity_max_rel_err'] < 1e-4 and 'invalid' not in d
+
+
+def test_strong_scaling_flag_parses():
+    sys.path.insert(0, ROOT)
+    import bench
+    argv = sys.argv
+    sys.argv = ['bench.py', '--scaling', 'strong', '--strong-world', '8']
+    try:
+        a = bench.parse()
+    finally:
+        sys.argv = argv
+    assert a.scaling == 'strong' and a.strong_world == 8 and a.channels == 64      # divided over the GPUs in main()
+    assert bench.usable_cores() >= 1
+
+
+@pytest.mark.gpu
+def test_facade_leg_runs_the_fused_launch_and_agrees_with_the_direct_path():
+    """At N = 1 the line carries a leg OUTSIDE the timed region that pushes the same slab through the plug-in surface
+    (ArrayLoader -> BufferedFilter.update() -> recompute_all()): it must issue the fused launch, give the direct
+    path's numbers bit for bit and cost about the same per step."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--seconds', '30', '--steps', '3', '--warmup',
+                          '1', '--no-cpu-baseline'], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.splitlines()[-1])
+    f = d['facade']
+    assert 'failed' not in f, f
+    assert f['launches_per_update'] == {'chain_forward': 1, 'sosfilt_envelope:2': 1}
+    assert f['equals_direct_path_on_sampled_windows'] is True
+    assert d['facade_ms_per_step'] == f['facade_ms_per_step'] < 1.5*d['ms_per_step'] + 0.5
+    assert d['roofline']['traffic_source'] is None or d['roofline']['traffic_source'].startswith('profiles/')
+    assert d['roofline']['device_copy_GBps'] > d['roofline']['hipMemcpy_d2d_GBps'] > 1000
+
+
+@pytest.mark.gpu
+def test_strong_scaling_share_and_graph_leg():
+    """--scaling strong: the config's channels in TOTAL over the GPUs (rehearsed here as one rank's share of eight);
+    a latency-sized job also reports the step as a replayed hipGraph."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--scaling', 'strong', '--strong-world', '8',
+                          '--seconds', '30', '--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--no-facade'],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.splitlines()[-1])
+    assert d['scaling'] == 'strong' and d['config']['channels_per_gpu'] == 8 and 'STRONG' in d['config']['workload']
+    assert d['parity_max_rel_err'] < 1e-4 and 'invalid' not in d
+    assert isinstance(d.get('graph_ms_per_step'), float) and 0 < d['graph_ms_per_step'] < 2*d['ms_per_step']

@@ -31,6 +31,7 @@ res = {}
 for rnd in range(3):
     for w in (8, 10, 12, 14, 16):
         ctx.set_option('sos_waves_per_cu', w)
+        ctx.set_option('sos_waves_min', w)      # exactly that many (round 3: the planner may pick fewer otherwise)
         hipdsp.sosfilt_envelope(ctx, fplan, eplan, dx, T, dy, T, de, T, C, T, phase=1)   # checkpoints of this plan
         res.setdefault(w, []).append(timed(lambda: hipdsp.sosfilt_envelope(ctx, fplan, eplan, dx, T, dy, T, de, T, C, T, phase=2)))
 for w, v in res.items():

@@ -33,6 +33,7 @@ for pf in [int(v) for v in os.environ.get('PREFETCH', '0').split(',')]:
   print('prefetch', pf)
   for w in waves:
       ctx.set_option('sos_waves_per_cu', w)
+      ctx.set_option('sos_waves_min', w)      # exactly that many (round 3: the planner may pick fewer otherwise)
       fw = timed(lambda: hipdsp.sosfilt_envelope(ctx, fplan, eplan, dx, T, dy, T, de, T, C, T, phase=1))
       bw = timed(lambda: hipdsp.sosfilt_envelope(ctx, fplan, eplan, dx, T, dy, T, de, T, C, T, phase=2))
       en = timed(lambda: hipdsp.envelope(ctx, eplan, dx, T, de, T, C, T, 0))

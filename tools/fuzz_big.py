@@ -21,6 +21,7 @@ for seed in range(40):
     es = butter_sos(int(rng.integers(1, 5)), float(rng.uniform(5, 2000)), 'lowpass', rate)
     waves = int(rng.choice([8, 12, 16]))
     c.set_option('sos_waves_per_cu', waves)
+    c.set_option('sos_waves_min', waves)      # exactly that many (round 3: the planner may pick fewer otherwise)
     x = rng.standard_normal((T, C)).astype(np.float32)
     dx = gh.to_planar(c, x)
     yf = hipdsp.DeviceArray(c, (C, T), np.float32)
@@ -43,5 +44,5 @@ for seed in range(40):
             bad += 1
             print('FAIL', seed, T, C, ch, waves, ef, ee, e2, flush=True)
     print(seed, T, C, waves, 'ok', flush=True)
-c.set_option('sos_waves_per_cu', 0)
+c.set_option('sos_waves_per_cu', 0); c.set_option('sos_waves_min', 0)
 print('done, failures', bad)

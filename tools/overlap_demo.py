@@ -41,6 +41,7 @@ def overlapped():
 
 for waves in [int(w) for w in os.environ.get('WAVES', '16,12,8').split(',')]:
     A.set_option('sos_waves_per_cu', waves)
+    A.set_option('sos_waves_min', waves)      # exactly that many (round 3: the planner may pick fewer otherwise)
     for name, f in (('serial', serial), ('overlapped', overlapped), ('serial', serial), ('overlapped', overlapped)):
         for _ in range(3):
             f()

@@ -14,6 +14,7 @@ plan = hipdsp.SosPlan(ctx, butter_sos(2, (300.0, 3000.0), 'bandpass', rate))
 eplan = hipdsp.SosPlan(ctx, butter_sos(2, 20.0, 'lowpass', rate))
 for w in (8, 12, 16, 20, 24, 32, 40):
     ctx.set_option('sos_waves_per_cu', w)
+    ctx.set_option('sos_waves_min', w)      # exactly that many (round 3: the planner may pick fewer otherwise)
     for name, f, nb in (('filt', lambda: hipdsp.sosfilt(ctx, plan, dx, T, dy, T, C, T, 0), 8.0*C*T),
                         ('env', lambda: hipdsp.envelope(ctx, eplan, dx, T, dy, T, C, T, 0), 12.0*C*T)):
         f(); f()
