@@ -162,13 +162,16 @@ class BufferedFilter(BufferedData):
         (buffer_changed, spec_rect, frequencies)."""
         if not self.need_update:
             return
-        if self._source_len() > 0:
-            self.allocate_buffer()
-        self._fuse = self._plan_fusion() if len(self._hostbuf) > 0 else None
-        try:
-            self.reload_buffer()
-        finally:
-            self._fuse = None
+        if not self._builtin(BufferedFilter):
+            self.recompute()                     # a subclass with its own process() / recompute(): the plain walk
+        else:
+            if self._source_len() > 0:           # (what recompute() does, with the fusion planned in between)
+                self.allocate_buffer()
+            self._fuse = self._plan_fusion() if len(self._hostbuf) > 0 else None
+            try:
+                self.reload_buffer()
+            finally:
+                self._fuse = None
         for dest in self.dests:
             dest.recompute_all()
 

@@ -349,3 +349,34 @@ def test_random_scroll_sequences_keep_buffers_consistent(seed):
         assert np.array_equal(b.buffer, 4*ref[b.offset:b.offset + len(b.buffer)])
         want = 4*ref[::8][s.offset:s.offset + len(s.buffer)]
         assert np.array_equal(s.buffer, want)
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_load_geometry_is_what_process_gets(seed):
+    """BufferedData._load_geometry (what a source's fused launch plans the derived traces' slabs with) is the very
+    index arithmetic of load_buffer, quirk included: for random scrolls of random chains, every process() call saw
+    the slab (first, count, lead) that _load_geometry predicts for its (offset, nframes)."""
+    rng = np.random.default_rng(seed)
+
+    class Spy(Doubler):
+        def load_buffer(self, offset, nframes, buffer):
+            self.predicted = self._load_geometry(offset, nframes)
+            super().load_buffer(offset, nframes, buffer)
+
+        def process(self, source, dest, nbefore):
+            first, count, lead = self.predicted
+            assert (self._pending.soffset, len(source), nbefore) == (first, max(count, 0), lead)
+            super().process(source, dest, nbefore)
+
+    step = int(rng.choice([1, 1, 4, 7]))
+    t = Spy(tbefore=float(rng.choice([0, 0.5, 2])), tafter=float(rng.choice([0, 1, 3])), step=step)
+    g = make_graph(t, frames=6000, rate=float(rng.choice([5.0, 100.0, 1000.0])), buffer_time=float(rng.uniform(2, 10)),
+                   back_time=float(rng.uniform(0, 3)))
+    t.plot_items = [Item(), Item()]
+    g.set_need_update()
+    span = 6000/g.data.rate
+    for _ in range(25):
+        t0 = float(rng.uniform(0, span*0.9))
+        g.update_times(t0, min(span, t0 + float(rng.uniform(0.01, 0.3))*span))
+    t.recompute_all()
+    assert len(t.calls) >= 2
