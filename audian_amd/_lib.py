@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libhip_dsp.so')
+LIB_PATH = os.environ.get('AUDIAN_AMD_LIB') or os.path.join(_HERE, 'libhip_dsp.so')     # (AUDIAN_AMD_LIB: another build, tools/ab_two_builds.sh)
 
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_TOO_SHORT, ERR_NOMEM = range(6)
 MAX_SECTIONS = 4
