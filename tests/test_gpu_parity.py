@@ -886,3 +886,19 @@ def test_spectrogram_of_a_slab_shorter_than_one_window(nfft):
         hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(db), 0x7f, 4*C*nd*F)
         hipdsp.spectrogram(c, dx, max(T, 1), C, T, nfft, max(nfft//4, 1), 48000.0, out, nd, db_out=db)
         assert np.all(out.to_host() == 0) and np.all(db.to_host() == -np.inf), (nfft, T)
+
+
+def test_copy_probe_copies():
+    """hipdsp_copy_probe (the measured device-copy ceiling bench.py reports): bit-exact copy, sizes that are not a
+    multiple of the block, misuse rejected."""
+    from audian_amd import hipdsp
+    c = gh.ctx()
+    rng = np.random.default_rng(3)
+    for n in (4, 1024, 1024*257 + 12):
+        x = rng.standard_normal(n).astype(np.float32)
+        src = hipdsp.DeviceArray.from_host(c, x)
+        dst = hipdsp.DeviceArray(c, (n,), np.float32).zero_()
+        hipdsp.check(hipdsp.lib.hipdsp_copy_probe(c.handle, hipdsp._p(dst), hipdsp._p(src), 4*n))
+        assert np.array_equal(dst.to_host(), x)
+    with pytest.raises(ValueError):
+        hipdsp.check(hipdsp.lib.hipdsp_copy_probe(c.handle, hipdsp._p(dst), hipdsp._p(src), 10))
