@@ -49,7 +49,7 @@ class TraceGraph(object):
             raise ValueError('source not found for traces: ' + ', '.join(orphans))
         self.traces, self.sources = ordered, parents
 
-    def open(self, samples, rate, **kwargs):
+    def open(self, samples, rate, unwrap=0.0, unwrap_clip=False, **kwargs):
         """What Data.open does around the loader (data.py:150-204): walk the ordered traces
         from the leaves up, let each add the margins its dependants need to its own
         (expand_times) and pass the sum on to its source; the raw loader is then opened with
@@ -68,6 +68,9 @@ class TraceGraph(object):
         self.tbefore, self.tafter = root
         self.data = ArrayLoader(samples, rate, self.buffer_time + self.tbefore + self.tafter,
                                 self.back_time + self.tbefore, **kwargs)
+        if unwrap > 1e-3:
+            # what Data.open does right behind the loader (data.py:180; CLI -u / -U, audian.py:1485-1512)
+            self.data.set_unwrap(unwrap, unwrap_clip, False, self.data.unit)
         # position 0 is the raw data from now on
         self.traces = [self.data] + self.traces
         self.sources = [None] + [p + 1 for p in self.sources]
