@@ -35,6 +35,8 @@ struct ChainArgs {
     float *db;                // optional: decibel(psd), same layout
     long long psd_pitch;
     long long n_valid;        // frames that lie inside the trace
+    long long tail_end;       // > n_valid: the FFT wave of a channel's last unit also writes the zero tail, frames
+                              // [n_valid, tail_end) (bufferedspectrogram.py:59) -- a few frames, not worth a launch of their own
     const float *tables;      // tw2 | tw3 | twn | window of the 2048-point PSD kernel (fft_tables)
     float scale;              // 1 / (fs * sum w^2)
     int n_iter;
@@ -678,6 +680,12 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             }
             STAMP_AT(10);                                      // the tile's (at most) two frames
         }
+        if (unit_ok && last_seg && a.tail_end > a.n_valid) {
+            for (long long i = a.n_valid * F + lane; i < a.tail_end * F; i += 64) {
+                oc[i] = 0.f;
+                if (DB) dc[i] = -INFINITY;
+            }
+        }
     }
     if (STAMP && lane == 0) {
         long long *dst = reinterpret_cast<long long *>(a.db) + ((long long)blockIdx.x * 2 * NP + wave) * 16;
@@ -1057,7 +1065,9 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
         }
     }
     HD_REQUIRE(blocks <= 0x7fffffffLL, "grid too large");
-    if (frames_out > n_valid) {                                    // zero tail (bufferedspectrogram.py:59)
+    if (frames_out > n_valid && frames_out - n_valid <= 16 && !(ctx->chain_debug & 32)) {
+        a.tail_end = frames_out;                                   // the few frames of the zero tail: inside the launch
+    } else if (frames_out > n_valid) {                             // zero tail (bufferedspectrogram.py:59)
         const long long n = (frames_out - n_valid) * F;
         unsigned gx = (unsigned)((n + 1023) / 1024 > 4096 ? 4096 : (n + 1023) / 1024);
         hipLaunchKernelGGL(zero_rows_kernel, dim3(gx, (unsigned)channels), dim3(256), 0, ctx->stream,
