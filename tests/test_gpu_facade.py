@@ -612,7 +612,8 @@ def launches_during(fn):
     return {k: v - before.get(k, 0) for k, v in hipdsp.launches.items() if v != before.get(k, 0)}
 
 
-@pytest.mark.parametrize('shape', ['configs2', 'configs4', 'default_session', 'envelope_only'])
+@pytest.mark.parametrize('shape', ['configs2', 'configs4', 'default_session', 'envelope_only', 'order4_bandpass_env',
+                                   'lowpass_only'])
 def test_update_takes_the_fused_launch(oracle, shape):
     """BufferedFilter.update() -> recompute_all() (buffereddata.py:149-153, databrowser.py:1264-1288) issues ONE
     forward launch that fills the filtered trace, the spectrogram and the envelope's tile states, plus the
@@ -628,18 +629,23 @@ def test_update_takes_the_fused_launch(oracle, shape):
         rate, secs, C, nfft, env_cut, traces = 192000.0, 2.0, 4, 2048, 20.0, 'fse'
     elif shape == 'default_session':  # plugins.py:11-13: filter + spectrogram(256, 50 %), no envelope
         rate, secs, C, nfft, env_cut, traces = 48000.0, 3.0, 2, 256, None, 'fs'
+    elif shape == 'order4_bandpass_env':   # configs[1]'s filter (four sections), 1024 / 256, a band-pass envelope (two sections, no clamp)
+        rate, secs, C, nfft, env_cut, traces = 48000.0, 3.0, 2, 1024, 300.0, 'fse'
+    elif shape == 'lowpass_only':     # one section in front (hp = 0), 512 / 256
+        rate, secs, C, nfft, env_cut, traces = 48000.0, 3.0, 2, 512, 100.0, 'fse'
     else:
         rate, secs, C, nfft, env_cut, traces = 48000.0, 3.0, 2, 256, 200.0, 'fe'
     x = recording(rate, secs, C, seed=21)
+    overlap = 0.75 if shape == 'order4_bandpass_env' else 0.5
 
     def graph(classes):
         F, E, S = classes
         g = TraceGraph(secs, 0.0)             # the whole recording is resident
         g.add_trace(F())
         if 's' in traces:
-            g.add_trace(S(nfft=nfft))
+            g.add_trace(S(nfft=nfft, overlap_frac=overlap))
         if 'e' in traces:
-            g.add_trace(E(envelope_cutoff=env_cut))
+            g.add_trace(E(envelope_cutoff=env_cut, highpass_cutoff=20.0 if shape == 'order4_bandpass_env' else 0))
         g.setup_traces()
         g.open(x, rate)
         for t in g.traces:
@@ -651,9 +657,12 @@ def test_update_takes_the_fused_launch(oracle, shape):
     g.update_times(0.0, secs)
     o.update_times(0.0, secs)
     for hp, lp in [(300.0, 3000.0), (500.0, 5000.0)]:
+        if shape == 'lowpass_only':
+            hp = 0.0
         for twin in (g, o):
             twin['filtered'].highpass_cutoff = hp
             twin['filtered'].lowpass_cutoff = lp
+            twin['filtered'].filter_order = 4 if shape == 'order4_bandpass_env' else 2
         for t in g.traces:
             t.buffer_changed[:] = False
         got = launches_during(g['filtered'].update)
