@@ -162,18 +162,21 @@ class BufferedFilter(BufferedData):
         (buffer_changed, spec_rect, frequencies)."""
         if not self.need_update:
             return
-        if not self._builtin(BufferedFilter):
-            self.recompute()                     # a subclass with its own process() / recompute(): the plain walk
-        else:
-            if self._source_len() > 0:           # (what recompute() does, with the fusion planned in between)
-                self.allocate_buffer()
-            self._fuse = self._plan_fusion() if len(self._hostbuf) > 0 else None
-            try:
+        try:
+            if not self._builtin(BufferedFilter):
+                self.recompute()                 # a subclass with its own process() / recompute(): the plain walk
+            else:
+                if self._source_len() > 0:       # (what recompute() does, with the fusion planned in between)
+                    self.allocate_buffer()
+                self._fuse = self._plan_fusion() if len(self._hostbuf) > 0 else None
                 self.reload_buffer()
-            finally:
-                self._fuse = None
-        for dest in self.dests:
-            dest.recompute_all()
+            for dest in self.dests:
+                dest.recompute_all()
+        finally:
+            # whatever happened on the way: no token outlives the walk it was issued for
+            self._fuse = None
+            for dest in self.dests:
+                dest._fused_token = False
 
     def update(self):
         """Design the filter for the current cut-offs and order, refresh the device plans and
