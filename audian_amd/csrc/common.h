@@ -21,8 +21,8 @@ struct hipdsp_ctx {
     int force_generic_fft; // tests: use the generic radix-2 kernel for every nfft
     void *fft_tables2[20]; // same for the two-stage kernel: tw2 | twn | window
     int sos_waves_per_cu;  // experiments: resident waves per CU the IIR planner aims for
-    int sos_waves_min;     // experiments: the planner's "a wave is alone with its latency below this many per CU" (0 = 4)
-    int chain_pairs, chain_pairs_min;   // the same two numbers for the fused sweeps' pairs of waves (0 = 8 / 2)
+    int sos_waves_min;     // experiments: >= sos_waves_per_cu forces exactly that many waves per CU (sos.hip: plan_segments)
+    int chain_pairs;       // most pairs of waves per CU the fused sweeps' planner uses (0 = 8; experiments)
     int sos_debug;         // measurements only (results wrong): ablation bits of the envelope's backward sweep
     int sos_single_wave_wg; // experiments (A/B): the envelope's backward sweep as single-wave workgroups, as in rounds 1-2
     int sos_prefetch;      // experiments: register prefetch of the next tile in the envelope sweeps

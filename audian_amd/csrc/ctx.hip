@@ -104,7 +104,6 @@ int hipdsp_ctx_create(int device, void *stream, hipdsp_ctx **out)
     ctx->sos_single_wave_wg = 0;
     ctx->sos_debug = 0;
     ctx->chain_pairs = 0;
-    ctx->chain_pairs_min = 0;
     ctx->spec_no_half = 0;
     ctx->pool = new hd_pool();
     ctx->sos_prefetch = 1;
@@ -185,7 +184,6 @@ int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value)
         ctx->chain_pairs = (int)value;
         return HIPDSP_OK;
     }
-    if (strcmp(name, "chain_pairs_min") == 0) { ctx->chain_pairs_min = (int)value; return HIPDSP_OK; }
     if (strcmp(name, "sos_debug") == 0) { ctx->sos_debug = (int)value; return HIPDSP_OK; }
     if (strcmp(name, "sos_single_wave_wg") == 0) { ctx->sos_single_wave_wg = value != 0; return HIPDSP_OK; }
     if (strcmp(name, "sos_prefetch") == 0) { ctx->sos_prefetch = value != 0; return HIPDSP_OK; }

@@ -1,5 +1,5 @@
 """How many waves (pairs) per CU should the sweeps use when the job does not fill the chip?  Forces the segment planner to
-each level ("sos_waves_per_cu" = "sos_waves_min" = w; "chain_pairs" = "chain_pairs_min" = p) and times the backward sweep
+each level ("sos_waves_per_cu" = "sos_waves_min" = w; "chain_pairs" = p) and times the backward sweep
 and the fused forward sweep, then the planner's own choice.
     python tools/occupancy_sweep.py CHANNELS SECONDS RATE [NFFT HOP ORDER]
 """
@@ -43,9 +43,9 @@ for w in (2, 4, 6, 8, 12, 16):
 ctx.set_option('sos_waves_per_cu', 0); ctx.set_option('sos_waves_min', 0)
 print(f'  backward sweep, planner\'s choice:        {timed(bwd):8.4f} ms')
 for p in (1, 2, 3, 4, 6, 8):
-    ctx.set_option('chain_pairs', p); ctx.set_option('chain_pairs_min', p)
+    ctx.set_option('chain_pairs', p)
     seg, n = hipdsp.chain_plan(ctx, fplan, eplan, C, T)
     print(f'  fused forward sweep forced to {p} pairs per CU ({n} segments of {seg//2048} tiles): {timed(fwd):8.4f} ms')
-ctx.set_option('chain_pairs', 0); ctx.set_option('chain_pairs_min', 0)
+ctx.set_option('chain_pairs', 0)
 seg, n = hipdsp.chain_plan(ctx, fplan, eplan, C, T)
 print(f'  fused forward sweep, planner\'s choice ({n} segments of {seg//2048} tiles):  {timed(fwd):8.4f} ms')
