@@ -114,7 +114,11 @@ int hipdsp_stream_destroy(hipdsp_ctx *ctx, void *stream);
  * call once before capturing (FFT tables, scratch: hipdsp_ctx_reserve) -- nothing may
  * allocate during capture.  Filter cut-offs change between replays through
  * hipdsp_sosplan_set_host + a captured hipdsp_sosplan_upload (DataBrowser.update_filter
- * -> BufferedFilter.update -> recompute_all, databrowser.py:1264-1288). */
+ * -> BufferedFilter.update -> recompute_all, databrowser.py:1264-1288).  The time segmentation and the
+ * number of warm-up tiles are those of the plans AT CAPTURE TIME (the state hand-over between segments
+ * is recomputed on the device from the plan it finds): capture with the slowest-decaying filters of the
+ * sweep -- lowest high-pass and lowest envelope cut-off -- or a replay with a longer memory than the
+ * captured warm-up starts its segments with a history that has not fully decayed. */
 typedef struct hipdsp_graph hipdsp_graph;
 int hipdsp_graph_begin(hipdsp_ctx *ctx);
 int hipdsp_graph_end(hipdsp_ctx *ctx, hipdsp_graph **out);
