@@ -453,8 +453,15 @@ int launch_env_fix(hipdsp_ctx *ctx, const SosPlanDev *edev, int SE, double *ckpt
 // single-wave workgroups (WPB = 1) land wherever the dispatcher's round-robin stands -- a tiny copy kernel in front of
 // the launch (the spectrogram tile of the multi-GPU step) left some SIMDs with three waves and others with one:
 // 2.96 -> 3.8 ms at 32 channels (profiles/r03_forcedist_*), and probably the "two modes" of round 2.
-template <int SE, bool PREFETCH, bool PIN = true, bool TRACE = false, int WPB_ = WPB>
-__global__ __launch_bounds__(64 * WPB_) void env_bwd_kernel(const SosPlanDev *__restrict__ P0, BwdArgs a)
+// REGW (one- and two-section plans): the forward cascade's outputs stay in registers as float64 (w_[32] per lane) and
+// the backward cascade reads them there (CASC_X, walking lanes downwards: CASC_DOWN) -- 96 conversions, 8 LDS stores
+// and 16 LDS loads less per tile and lane, 185-203 VGPRs instead of 135-147: two waves a SIMD, which is what the planner
+// asks for anyway (launch_env_bwd).  It only pays with the scalar tables under control: left alone hipcc fetched both
+// G groups before using either and put the lane-0 branch of the state fold between fetch and use (264 SGPR spills,
+// 6.0-6.1 ms against 5.9); with CASC_CARRY_AFTER_F and the opaque `last` below it has 60 spills and 15 % fewer
+// instructions per tile: 8 % fewer cycles (SQ_BUSY_CYCLES, profiles/r03_bwd_regw_ab.log), 1-5 % less time free-running.
+template <int SE, bool PREFETCH, bool PIN = true, bool TRACE = false, int WPB_ = WPB, bool REGW = (SE <= 2)>
+__global__ __launch_bounds__(64 * WPB_, REGW ? 2 : 1) void env_bwd_kernel(const SosPlanDev *__restrict__ P0, BwdArgs a)
 {
     // TRACE (diagnostic build, option "sos_trace"): shader clocks per part of an iteration, summed per wave
     long long tr_acc[6] = {0, 0, 0, 0, 0, 0};
@@ -635,17 +642,53 @@ __global__ __launch_bounds__(64 * WPB_) void env_bwd_kernel(const SosPlanDev *__
         // ---- forward cascade again, from the state that entered this tile
 #define CASC_S SE
 #define CASC_PLAN() PLAN_OF(P0)
-#define CASC_CARRY cfw_
 #define CASC_IN(v) (v)
 #define CASC_PIN_GROUPS PIN
+      if constexpr (REGW) {
+#define CASC_CARRY_AFTER_F
+        double w_[L];
+#define CASC_CARRY cfw_
+#define CASC_GAIN a.gain
+#define CASC_NO_STORE
+#define CASC_TAP(j, e, y) w_[(j)] = (y)
+#include "sos_cascade.inc"
+#undef CASC_TAP
+#undef CASC_NO_STORE
+#undef CASC_GAIN
+#undef CASC_CARRY
+        WAVE_SYNC();
+        TRACE_AT(2);
+        if (rt == 0) {
+            int last = (int)(T + edge - 1 - tile);
+            asm volatile("" : "+v"(last));              // or its 32 lane masks are hoisted out of the sweep into SGPRs
+            const int lrow = last >> 5, lj = last & 31;
+            double v0 = 0.0;
+#pragma unroll
+            for (int j = 0; j < L; j++) v0 = (j == lj) ? w_[j] : v0;
+            v0 = __shfl(v0, lrow, 64);
+#pragma unroll
+            for (int j = 0; j < L; j++) w_[j] = (L * lane + j > last) ? v0 : w_[j];
+            const SosPlanDev *P = PLAN_OF(P0);
+#pragma unroll
+            for (int r = 0; r < DE; r++) cb_[r] = P->zi[r] * v0;
+        }
+#define CASC_CARRY cb_
+#define CASC_DOWN
+#define CASC_X(j) w_[L - 1 - (j)]
+#include "sos_cascade.inc"
+#undef CASC_X
+#undef CASC_DOWN
+#undef CASC_CARRY
+#undef CASC_CARRY_AFTER_F
+      } else {
+#define CASC_CARRY cfw_
 #define CASC_GAIN a.gain
 #include "sos_cascade.inc"
 #undef CASC_GAIN
 #undef CASC_CARRY
         WAVE_SYNC();
-        TRACE_AT(2);                               // forward cascade
+        TRACE_AT(2);
         if (rt == 0) {
-            // scipy: backward pass starts from zi * y_fwd[-1]; pad the rest of the tile with it
             const int last = (int)(T + edge - 1 - tile);
             const float v0 = ldsf[lds_float_index(last)];
             WAVE_SYNC();
@@ -655,15 +698,15 @@ __global__ __launch_bounds__(64 * WPB_) void env_bwd_kernel(const SosPlanDev *__
             for (int r = 0; r < DE; r++) cb_[r] = P->zi[r] * (double)v0;
             WAVE_SYNC();
         }
-        // ---- backward cascade over the forward outputs, last sample first
 #define CASC_CARRY cb_
 #define CASC_REVERSED
 #include "sos_cascade.inc"
 #undef CASC_REVERSED
+#undef CASC_CARRY
+      }
 #undef CASC_PIN_GROUPS
 #undef CASC_S
 #undef CASC_PLAN
-#undef CASC_CARRY
 #undef CASC_IN
         WAVE_SYNC();
         TRACE_AT(3);                               // backward cascade
@@ -866,7 +909,7 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
     b.fair = ctx->sos_fair;
     const long long used_tiles = n_tiles - skip / TILE;      // tiles below `skip` are never visited
     long long seg_len = 0;
-    plan_segments(ctx, used_tiles * TILE, channels, warmE, &seg_len, &b.n_seg);
+    plan_segments(ctx, used_tiles * TILE, channels, warmE, &seg_len, &b.n_seg, SE <= 2 ? 8 : 16);   // env_bwd_kernel: REGW
     b.seg_tiles = seg_len / TILE;
     b.warm_tiles = warmE / TILE;
     b.units = channels * b.n_seg;

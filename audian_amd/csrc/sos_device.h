@@ -115,6 +115,21 @@ __device__ __forceinline__ double casc_wave_shr32(double x)
     return __builtin_bit_cast(double, ((long long)hi[0] << 32) | (unsigned int)lo[0]);
 }
 
+__device__ __forceinline__ double casc_wave_shl1(double x)
+{
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x130, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x130, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double casc_wave_shl32(double x)
+{
+    const long long b = __builtin_bit_cast(long long, x);
+    const auto lo = __builtin_amdgcn_permlane32_swap((int)b, 0, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((int)(b >> 32), 0, false, false);
+    return __builtin_bit_cast(double, ((long long)hi[1] << 32) | (unsigned int)lo[1]);
+}
+
 // a wave-local fence: LDS operations of one wave execute in order, no workgroup barrier is needed between the
 // phases of a tile that a single wave walks
 #define WAVE_SYNC()                                          \
@@ -217,10 +232,12 @@ __global__ void zero_rows_kernel(float *__restrict__ y, long long y_pitch, long 
 
 // the single-wave sweeps: up to "sos_waves_per_cu" (16) waves per CU, four SIMDs per CU
 // ("sos_waves_min" = w, experiments: force w waves per CU by making every level below it cost the same)
+// (`w_cap`: what the kernel's registers allow -- the register hand-over of the backward sweep holds two waves a SIMD)
 void plan_segments(const hipdsp_ctx *ctx, long long N, long long channels, long long warm,
-                   long long *seg_len, int *n_seg)
+                   long long *seg_len, int *n_seg, int w_cap = 16)
 {
-    const int w_max = ctx->sos_waves_per_cu > 0 ? ctx->sos_waves_per_cu : 16;
+    int w_max = ctx->sos_waves_per_cu > 0 ? ctx->sos_waves_per_cu : 16;
+    if (w_max > w_cap) w_max = w_cap;
     hd_plan_segments_occ(ctx->n_cus, w_max, ctx->sos_waves_min >= w_max ? 0 : 4, ctx->max_segments, N, channels, warm, seg_len, n_seg);
 }
 

@@ -43,7 +43,10 @@ P = lambda a: vp(a.ptr)
 fwdA = lambda: hipdsp.chain_forward(ctx, fplan, eplan, dx, T, df, T, C, T, nfft, hop, rate, ds, nd)
 bwdA = lambda: hipdsp.sosfilt_envelope(ctx, fplan, eplan, dx, T, df, T, de, T, C, T, phase=2)
 fwdB = lambda: okB(B.hipdsp_chain_forward(cb, pf, pe, P(dx), T, P(df), T, C, T, 1, np.pi/2, nfft, hop, rate, P(ds), None, nd, 0, 0))
-bwdB = lambda: okB(B.hipdsp_sosfilt_envelope(cb, pf, pe, P(dx), T, P(df), T, P(de2), T, C, T, 1, np.pi/2, 1, 2))
+# SAME_OUT=1: both builds write the same envelope buffer (where a buffer lies in HBM moves the sweep by several per cent,
+# so two output buffers confound the comparison); the identity check then compares a copy taken after A's last run
+same_out = os.environ.get('SAME_OUT', '0') == '1'
+bwdB = lambda: okB(B.hipdsp_sosfilt_envelope(cb, pf, pe, P(dx), T, P(df), T, P(de if same_out else de2), T, C, T, 1, np.pi/2, 1, 2))
 e0, e1 = ctx.event(), ctx.event()
 
 
@@ -62,7 +65,10 @@ res = {k: [] for k in ('fwd A', 'fwd B', 'bwd A', 'bwd B')}
 for rnd in range(6):
     res['fwd A'].append(timed(fwdA, ctx.synchronize)); res['bwd A'].append(timed(bwdA, ctx.synchronize))
     res['fwd B'].append(timed(fwdB, syncB)); res['bwd B'].append(timed(bwdB, syncB))
-same = np.array_equal(de.view(0, (min(T, 2000000),)).to_host(), de2.view(0, (min(T, 2000000),)).to_host())
+bwdA(); ctx.synchronize(); headA = de.view(0, (min(T, 2000000),)).to_host().copy()
+bwdB(); syncB(); headB = (de if same_out else de2).view(0, (min(T, 2000000),)).to_host()
+same = np.array_equal(headA, headB)
+print('largest difference of the two envelopes, relative to the largest value:', float(np.abs(headA - headB).max()/np.abs(headA).max()))
 for k, v in res.items():
     print(f'{k}: median {np.median(v):7.3f} ms  {[round(x, 3) for x in v]}')
 print('A = audian_amd/libhip_dsp.so, B =', other, '| envelopes identical:', same)
