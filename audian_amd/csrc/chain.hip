@@ -491,7 +491,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
 #pragma unroll
                     for (int r = 0; r < DE; r++) ckpt[(tile / TILE) * DE + r] = ce_[r];
                 }
-                if (!last_tile || !last_seg) {
+                {   // (the trace's very last tile advances the state too: slot n_tiles, see sos_device.h: FloodArgs)
                     {
                         const float4 keep0 = lds[lds_slot(62 + ((lane >> 3) & 1), lane & 7)];
                         WAVE_SYNC();
@@ -525,6 +525,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             }   // SE > 0
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last (dummy) prefetch
+        if (unit_ok && a.c.flags != nullptr && lane == 0) a.c.flags[unit] = state_not_finite(cf_) ? 1 : 0;   // FloodArgs
         STAMP_AT(7);
         if ((a.debug & 16) && blockIdx.x == 0 && wave == 0 && lane == 0) {
             long long *dbg = reinterpret_cast<long long *>(a.psd);
@@ -704,6 +705,20 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
 // line, except that a tile goes into LDS RAW and is rectified on the way into the cascades -- and NP FFT waves
 // with the same pairwise hand-over as in chain_fwd_kernel: H1 "the tile holds the filtered samples", H2 "copied"
 // (the IIR wave may overwrite the tile with the forward cascade's outputs).  nfft 2048 / hop 1024 only.
+// hipdsp_chain_backward: a channel whose forward sweep ended non-finite (slot n_tiles of its tile states, see
+// sos_device.h: FloodArgs) has an envelope that is NaN everywhere
+__global__ __launch_bounds__(256) void env_nan_fill_kernel(const double *__restrict__ ckpt, long long ckpt_pitch, long long n_tiles,
+                                                           int DE, float *__restrict__ env, long long env_pitch, long long T)
+{
+    const long long ch = blockIdx.y;
+    const double *e = ckpt + ch * ckpt_pitch + n_tiles * DE;
+    bool bad = false;
+    for (int r = 0; r < DE; r++) bad = bad || !(fabs(e[r]) <= 1.7976931348623157e308);
+    if (!bad) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < T; i += (long long)gridDim.x * blockDim.x)
+        env[ch * env_pitch + i] = __builtin_nanf("");
+}
+
 struct ChainBwdArgs {
     BwdArgs b;
     float *psd;
@@ -1036,7 +1051,7 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     int rc = hd_fft_tables(ctx, nfft, &a.tables);
     if (rc != HIPDSP_OK) return rc;
     const long long n_tiles = (frames + edge + TILE - 1) / TILE;
-    const long long ckpt_pitch = n_tiles * 2 * SE;                 // the layout the backward sweep expects
+    const long long ckpt_pitch = (n_tiles + 1) * 2 * SE;           // the layout the backward sweep expects
     void *work = nullptr;
     if (SE > 0) {
         rc = hipdsp_scratch(ctx, sizeof(double) * (size_t)ckpt_pitch * (size_t)channels, &work);
@@ -1055,6 +1070,10 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     // (hipdsp_chain_plan reports exactly this segmentation)
     plan_segments_chain(ctx, frames, channels, a.warm_total, &a.c.seg_len, &a.c.n_seg);
     a.units = channels * a.c.n_seg;
+    if (a.c.n_seg > 1) {                                           // non-finite samples: sos_device.h, FloodArgs
+        rc = hd_seg_flags(ctx, (size_t)a.units, &a.c.flags);
+        if (rc != HIPDSP_OK) return rc;
+    }
     a.n_iter = (int)((a.warm_total + a.c.seg_len + edge + TILE - 1) / TILE) + 1;
     long long blocks = (a.units + P - 1) / P;
     {
@@ -1139,8 +1158,15 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
 #undef HD_CHAIN_SHAPE
 #undef HD_CHAIN_ALL
     rc = hd_launch_status("chain_fwd_kernel");
-    if (rc != HIPDSP_OK || SE == 0) return rc;
-    return hd_launch_env_fix(ctx, eplan->dev, SE, (double *)work, ckpt_pitch, channels, a.c.n_seg, a.c.seg_len, n_tiles);
+    if (rc != HIPDSP_OK) return rc;
+    FloodArgs fl;
+    memset(&fl, 0, sizeof(fl));
+    fl.flags = a.c.flags; fl.n_seg = a.c.n_seg; fl.seg_len = a.c.seg_len;
+    fl.y = yf; fl.y_pitch = yf_pitch; fl.T = frames;
+    fl.psd = psd; fl.db = db_out; fl.psd_pitch = psd_pitch; fl.n_valid = n_valid;
+    fl.F = (int)F; fl.nfft = nfft; fl.hop = hop;
+    if (SE == 0) return launch_flood(ctx, fl, channels);
+    return hd_launch_env_fix(ctx, eplan->dev, SE, (double *)work, ckpt_pitch, channels, a.c.n_seg, a.c.seg_len, n_tiles, &fl);
 }
 
 int hipdsp_chain_backward(hipdsp_ctx *ctx, const hipdsp_sosplan *eplan, const float *yf, int64_t yf_pitch, float *env,
@@ -1189,7 +1215,7 @@ int hipdsp_chain_backward(hipdsp_ctx *ctx, const hipdsp_sosplan *eplan, const fl
     int rc = hd_fft_tables(ctx, nfft, &a.tables);
     if (rc != HIPDSP_OK) return rc;
     const long long n_tiles = (frames + edge + TILE - 1) / TILE;
-    const long long ckpt_pitch = n_tiles * 2 * SE;                 // where the forward sweep parked the tile states
+    const long long ckpt_pitch = (n_tiles + 1) * 2 * SE;           // where the forward sweep parked the tile states
     void *work = nullptr;
     rc = hipdsp_scratch(ctx, sizeof(double) * (size_t)ckpt_pitch * (size_t)channels, &work);
     if (rc != HIPDSP_OK) return rc;
@@ -1213,7 +1239,12 @@ int hipdsp_chain_backward(hipdsp_ctx *ctx, const hipdsp_sosplan *eplan, const fl
     dim3 grid((unsigned)blocks), block(128 * P);
     if (SE == 1) hipLaunchKernelGGL((chain_bwd_kernel<1, P>), grid, block, 0, ctx->stream, eplan->dev, a);
     else hipLaunchKernelGGL((chain_bwd_kernel<2, P>), grid, block, 0, ctx->stream, eplan->dev, a);
-    return hd_launch_status("chain_bwd_kernel");
+    rc = hd_launch_status("chain_bwd_kernel");
+    if (rc != HIPDSP_OK) return rc;
+    // (its paired waves cannot leave early like env_bwd_kernel's: the NaN channels are overwritten afterwards)
+    hipLaunchKernelGGL(env_nan_fill_kernel, dim3(64, (unsigned)channels), dim3(256), 0, ctx->stream, (const double *)work,
+                       ckpt_pitch, n_tiles, 2 * SE, env, (long long)env_pitch, (long long)frames);
+    return hd_launch_status("env_nan_fill_kernel");
 }
 
 int hipdsp_chain_backward_plan(hipdsp_ctx *ctx, const hipdsp_sosplan *eplan, int64_t channels, int64_t frames,

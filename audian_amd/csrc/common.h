@@ -43,7 +43,14 @@ struct hipdsp_ctx {
     volatile int *fault_host;
     int *fault_dev;        // the same words as the kernels address them
     int graphs_alive;      // hipGraphs captured on this context that have not been destroyed
+    // one byte per (channel, time segment) of the last forward sweep: did its band-pass end non-finite? (sos_device.h:
+    // FloodArgs).  1 MiB from the start, grown by hd_seg_flags() outside captures only.
+    unsigned char *seg_flags;
+    size_t seg_flags_cap;
 };
+
+// the flags of a forward sweep of `units` (channel, segment) pairs
+int hd_seg_flags(hipdsp_ctx *ctx, size_t units, unsigned char **out);
 
 // fault codes a kernel may leave in hipdsp_ctx::fault_host[0]
 #define HD_FAULT_CHAIN_HANDOVER 1   // chain_fwd_kernel: a wave waited in vain for its partner's LDS flag

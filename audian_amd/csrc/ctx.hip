@@ -111,6 +111,8 @@ int hipdsp_ctx_create(int device, void *stream, hipdsp_ctx **out)
     ctx->fault_host = nullptr;
     ctx->fault_dev = nullptr;
     ctx->graphs_alive = 0;
+    ctx->seg_flags = nullptr;
+    ctx->seg_flags_cap = 0;
     {
         void *h = nullptr, *d = nullptr;
         hipError_t e = hipHostMalloc(&h, 64, hipHostMallocMapped);
@@ -127,6 +129,18 @@ int hipdsp_ctx_create(int device, void *stream, hipdsp_ctx **out)
         ctx->fault_host = (volatile int *)h;
         ctx->fault_dev = (int *)d;
     }
+    {
+        void *f = nullptr;
+        const hipError_t e = hipMalloc(&f, (size_t)1 << 20);
+        if (e != hipSuccess) {
+            (void)hipHostFree((void *)ctx->fault_host);
+            delete ctx->pool;
+            delete ctx;
+            HD_CHECK_HIP(e);
+        }
+        ctx->seg_flags = (unsigned char *)f;
+        ctx->seg_flags_cap = (size_t)1 << 20;
+    }
     *out = ctx;
     return HIPDSP_OK;
 }
@@ -140,6 +154,7 @@ int hipdsp_ctx_destroy(hipdsp_ctx *ctx)
         delete ctx->pool;
     }
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->seg_flags) (void)hipFree(ctx->seg_flags);
     if (ctx->fault_host) (void)hipHostFree((void *)ctx->fault_host);
     for (int i = 0; i < 20; i++)
         if (ctx->fft_tables[i]) (void)hipFree(ctx->fft_tables[i]);
@@ -513,6 +528,35 @@ int hd_device_fault(hipdsp_ctx *ctx)
     else
         hipdsp_set_error("a kernel reported device fault %d (%d, %d, %d)", code, a, b, c);
     return HIPDSP_ERR_HIP;
+}
+
+int hd_seg_flags(hipdsp_ctx *ctx, size_t units, unsigned char **out)
+{
+    if (units > ctx->seg_flags_cap) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (ctx->stream) (void)hipStreamIsCapturing(ctx->stream, &st);
+        if (st != hipStreamCaptureStatusNone || ctx->graphs_alive > 0) {
+            hipdsp_set_error("a sweep of %zu (channel, segment) units during a stream capture or next to captured graphs of "
+                             "this context: run one of that size once before capturing", units);
+            return HIPDSP_ERR_INVALID;
+        }
+        HD_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->seg_flags) HD_CHECK_HIP(hipFree(ctx->seg_flags));
+        ctx->seg_flags = nullptr;
+        ctx->seg_flags_cap = 0;
+        void *f = nullptr;
+        const hipError_t e = hipMalloc(&f, units);
+        if (e == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            hipdsp_set_error("hipMalloc(%zu bytes) for the segment flags: out of memory", units);
+            return HIPDSP_ERR_NOMEM;
+        }
+        HD_CHECK_HIP(e);
+        ctx->seg_flags = (unsigned char *)f;
+        ctx->seg_flags_cap = units;
+    }
+    *out = ctx->seg_flags;
+    return HIPDSP_OK;
 }
 
 int hipdsp_scratch(hipdsp_ctx *ctx, size_t bytes, void **out)

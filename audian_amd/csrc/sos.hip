@@ -87,6 +87,7 @@ __global__ __launch_bounds__(64 * WPB) void sos_scan_kernel(const SosPlanDev *__
         }
         WAVE_SYNC();
     }
+    if (a.flags != nullptr && lane == 0) a.flags[unit] = state_not_finite(carry) ? 1 : 0;   // FloodArgs
 }
 
 // ---- envelope without a forward scratch: state checkpoints + recomputation ----------------
@@ -285,10 +286,8 @@ __global__ __launch_bounds__(64 * WPB) void sos_ckpt_kernel(const SosPlanDev *__
             for (int r = 0; r < DE; r++) ckpt[(tile / TILE) * DE + r] = ce_[r];
         }
         const bool last_tile = tile + TILE >= loop_end;
-        if (last_tile && last_seg) {
-            if (PREFETCH && SF == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            break;
-        }
+        // (the trace's very last tile advances the state too: slot n_tiles receives the state the channel ends with,
+        // where the backward sweep looks for a non-finite one, see FloodArgs)
         // keep the last two rows for an extension that reaches back over the tile border
         {
             const float4 keep0 = lds[lds_slot(62 + ((lane >> 3) & 1), lane & 7)];
@@ -315,6 +314,7 @@ __global__ __launch_bounds__(64 * WPB) void sos_ckpt_kernel(const SosPlanDev *__
         if (PREFETCH && SF == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (last_tile) {
             // the (zero-state, for seg > 0) state this segment ends with: into the slot of the next segment's first tile
+            // (the last segment: into the slot behind the last tile)
             if (lane == 0) {
 #pragma unroll
                 for (int r = 0; r < DE; r++) ckpt[(tile / TILE + 1) * DE + r] = ce_[r];
@@ -322,6 +322,9 @@ __global__ __launch_bounds__(64 * WPB) void sos_ckpt_kernel(const SosPlanDev *__
             break;
         }
         WAVE_SYNC();
+    }
+    if constexpr (SF > 0) {
+        if (a.flags != nullptr && lane == 0) a.flags[unit] = state_not_finite(cf_) ? 1 : 0;   // FloodArgs
     }
 }
 
@@ -333,12 +336,31 @@ __global__ __launch_bounds__(64 * WPB) void sos_ckpt_kernel(const SosPlanDev *__
 // its zero-state one + A^(TILE m) S_k -- added for the tiles of the warm-up length only, beyond which it is below
 // float64 rounding.  One block per channel; segments are taken from the last to the first in chunks of the block
 // size so that every e_k is read before it is overwritten with S_(k+1).
+// Non-finite input (FloodArgs): the block first overwrites what the band-pass segments behind a non-finite one wrote,
+// and if any segment's envelope state ended non-finite it leaves NaN in slot n_tiles for the backward sweep.
 template <int SE>
 __global__ __launch_bounds__(256) void env_fix_kernel(const SosPlanDev *__restrict__ P0, double *ckpt_all, long long ckpt_pitch,
-                                                      int n_seg, long long seg_tiles, long long n_tiles)
+                                                      int n_seg, long long seg_tiles, long long n_tiles, FloodArgs flood)
 {
     constexpr int D = 2 * SE;
     double *ckpt = ckpt_all + (long long)blockIdx.x * ckpt_pitch;
+    flood_channel(flood, blockIdx.x);
+    {
+        __shared__ int any_bad;
+        if (threadIdx.x == 0) any_bad = 0;
+        __syncthreads();
+        // e_j, the end state of segment j: slot (j + 1) seg_tiles, the last one: slot n_tiles
+        for (long long j = threadIdx.x; j < n_seg; j += blockDim.x) {
+            const double *e = ckpt + (j + 1 < n_seg ? (j + 1) * seg_tiles : n_tiles) * D;
+            bool bad = false;
+#pragma unroll
+            for (int r = 0; r < D; r++) bad = bad || !(fabs(e[r]) <= 1.7976931348623157e308);
+            if (bad) atomicOr(&any_bad, 1);
+        }
+        __syncthreads();
+        if (any_bad && threadIdx.x == 0) ckpt[n_tiles * D] = __builtin_nan("");
+        __syncthreads();
+    }
     double AT[D][D], P[D][D];
 #pragma unroll
     for (int r = 0; r < D; r++)
@@ -432,16 +454,19 @@ __global__ __launch_bounds__(256) void env_fix_kernel(const SosPlanDev *__restri
 }
 
 int launch_env_fix(hipdsp_ctx *ctx, const SosPlanDev *edev, int SE, double *ckpt, long long ckpt_pitch, long long channels,
-                   int n_seg, long long seg_len, long long n_tiles)
+                   int n_seg, long long seg_len, long long n_tiles, const FloodArgs *flood)
 {
-    if (n_seg <= 1) return HIPDSP_OK;
+    if (n_seg <= 1) return HIPDSP_OK;       // (one segment: nothing to hand over, nothing to flood, slot n_tiles is true)
     dim3 grid((unsigned)channels), block(256);
     const long long seg_tiles = seg_len / TILE;
+    FloodArgs fl;
+    memset(&fl, 0, sizeof(fl));
+    if (flood) fl = *flood;
     switch (SE) {
-    case 1: hipLaunchKernelGGL((env_fix_kernel<1>), grid, block, 0, ctx->stream, edev, ckpt, ckpt_pitch, n_seg, seg_tiles, n_tiles); break;
-    case 2: hipLaunchKernelGGL((env_fix_kernel<2>), grid, block, 0, ctx->stream, edev, ckpt, ckpt_pitch, n_seg, seg_tiles, n_tiles); break;
-    case 3: hipLaunchKernelGGL((env_fix_kernel<3>), grid, block, 0, ctx->stream, edev, ckpt, ckpt_pitch, n_seg, seg_tiles, n_tiles); break;
-    case 4: hipLaunchKernelGGL((env_fix_kernel<4>), grid, block, 0, ctx->stream, edev, ckpt, ckpt_pitch, n_seg, seg_tiles, n_tiles); break;
+    case 1: hipLaunchKernelGGL((env_fix_kernel<1>), grid, block, 0, ctx->stream, edev, ckpt, ckpt_pitch, n_seg, seg_tiles, n_tiles, fl); break;
+    case 2: hipLaunchKernelGGL((env_fix_kernel<2>), grid, block, 0, ctx->stream, edev, ckpt, ckpt_pitch, n_seg, seg_tiles, n_tiles, fl); break;
+    case 3: hipLaunchKernelGGL((env_fix_kernel<3>), grid, block, 0, ctx->stream, edev, ckpt, ckpt_pitch, n_seg, seg_tiles, n_tiles, fl); break;
+    case 4: hipLaunchKernelGGL((env_fix_kernel<4>), grid, block, 0, ctx->stream, edev, ckpt, ckpt_pitch, n_seg, seg_tiles, n_tiles, fl); break;
     default: return HIPDSP_OK;
     }
     return hd_launch_status("env_fix_kernel");
@@ -502,6 +527,21 @@ __global__ __launch_bounds__(64 * WPB_, REGW ? 2 : 1) void env_bwd_kernel(const 
     double cb_[DE];
 #pragma unroll
     for (int r = 0; r < DE; r++) cb_[r] = 0.0;
+
+    // A channel whose forward sweep ended non-finite is NaN everywhere (sosfiltfilt's backward pass starts from that
+    // end; sos_device.h: FloodArgs): the unit fills its share of the output instead of sweeping.
+    {
+        double end_state[DE];
+#pragma unroll
+        for (int r = 0; r < DE; r++) end_state[r] = ckpt[a.n_tiles * DE + r];
+        if (state_not_finite(end_state)) {
+            long long p_lo = (a.n_tiles - rt_hi) * TILE, p_hi = (a.n_tiles - rt_lo) * TILE;
+            if (p_lo < a.skip) p_lo = a.skip;
+            if (p_hi > T) p_hi = T;
+            for (long long p = p_lo + lane; p < p_hi; p += 64) out[p - a.skip] = __builtin_nanf("");
+            return;
+        }
+    }
 
     // Prefetch: the next tile (one below) and its checkpoint are requested right after this
     // tile went into LDS, i.e. before this tile's arithmetic and stores.  The loads are inline
@@ -830,6 +870,10 @@ int launch_scan(hipdsp_ctx *ctx, const SosPlanDev *dev, int S, SeqArgs a, long l
         return HIPDSP_ERR_INVALID;
     }
     dim3 grid((unsigned)blocks), block(64 * WPB);
+    if (a.n_seg > 1) {                                    // non-finite samples must not be forgotten at a segment border
+        const int frc = hd_seg_flags(ctx, (size_t)a.units, &a.flags);
+        if (frc != HIPDSP_OK) return frc;
+    }
     switch (S) {
     case 1: hipLaunchKernelGGL((sos_scan_kernel<1>), grid, block, 0, ctx->stream, dev, a); break;
     case 2: hipLaunchKernelGGL((sos_scan_kernel<2>), grid, block, 0, ctx->stream, dev, a); break;
@@ -839,7 +883,13 @@ int launch_scan(hipdsp_ctx *ctx, const SosPlanDev *dev, int S, SeqArgs a, long l
         hipdsp_set_error("n_sections %d not in 1..%d", S, MAXS);
         return HIPDSP_ERR_UNSUPPORTED;
     }
-    return hd_launch_status("sos_scan_kernel");
+    const int rc = hd_launch_status("sos_scan_kernel");
+    if (rc != HIPDSP_OK || a.flags == nullptr) return rc;
+    FloodArgs fl;
+    memset(&fl, 0, sizeof(fl));
+    fl.flags = a.flags; fl.n_seg = a.n_seg; fl.seg_len = a.seg_len;
+    fl.y = a.out; fl.y_pitch = a.out_pitch; fl.T = a.N; fl.skip = a.skip;
+    return launch_flood(ctx, fl, channels);
 }
 
 // Envelope by checkpoints: forward sweep (optionally with the band-pass in front), then the
@@ -850,7 +900,7 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
                     long long frames, long long skip, int rectify, double gain, int clamp, int phase)
 {
     const long long n_tiles = (frames + edge + TILE - 1) / TILE;
-    const long long ckpt_pitch = n_tiles * 2 * SE;
+    const long long ckpt_pitch = (n_tiles + 1) * 2 * SE;     // (+ 1: the state the channel ends with, FloodArgs)
     void *work = nullptr;
     int rc = hipdsp_scratch(ctx, sizeof(double) * (size_t)ckpt_pitch * (size_t)channels, &work);
     if (rc != HIPDSP_OK) return rc;
@@ -869,6 +919,10 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
         long long blocks = (fa.units + WPB - 1) / WPB;
         HD_REQUIRE(blocks <= 0x7fffffffLL, "grid too large");
         dim3 grid((unsigned)blocks), block(64 * WPB);
+        if (SF > 0 && fa.n_seg > 1) {
+            rc = hd_seg_flags(ctx, (size_t)fa.units, &fa.flags);
+            if (rc != HIPDSP_OK) return rc;
+        }
         const bool pf = ctx->sos_prefetch && frames >= 4 * TILE;
 #define HD_CKPT(A, B)                                                                                       \
     case (A) * 8 + (B):                                                                                     \
@@ -890,7 +944,11 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
 #undef HD_CKPT
         rc = hd_launch_status("sos_ckpt_kernel");
         if (rc != HIPDSP_OK) return rc;
-        rc = launch_env_fix(ctx, edev, SE, (double *)work, ckpt_pitch, channels, fa.n_seg, fa.seg_len, n_tiles);
+        FloodArgs fl;
+        memset(&fl, 0, sizeof(fl));
+        fl.flags = fa.flags; fl.n_seg = fa.n_seg; fl.seg_len = fa.seg_len;
+        fl.y = yf; fl.y_pitch = yf_pitch; fl.T = frames;
+        rc = launch_env_fix(ctx, edev, SE, (double *)work, ckpt_pitch, channels, fa.n_seg, fa.seg_len, n_tiles, &fl);
         if (rc != HIPDSP_OK) return rc;
     }
     if (phase == 1) return HIPDSP_OK;
@@ -946,9 +1004,9 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
 }  // namespace
 
 int hd_launch_env_fix(hipdsp_ctx *ctx, const SosPlanDev *edev, int SE, double *ckpt, long long ckpt_pitch, long long channels,
-                      int n_seg, long long seg_len, long long n_tiles)
+                      int n_seg, long long seg_len, long long n_tiles, const FloodArgs *flood)
 {
-    return launch_env_fix(ctx, edev, SE, ckpt, ckpt_pitch, channels, n_seg, seg_len, n_tiles);
+    return launch_env_fix(ctx, edev, SE, ckpt, ckpt_pitch, channels, n_seg, seg_len, n_tiles, flood);
 }
 
 extern "C" {

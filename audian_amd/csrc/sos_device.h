@@ -11,9 +11,34 @@ struct hipdsp_sosplan {
     bool valid;
 };
 
+// Non-finite samples (NaN, Inf).  In the reference a band-pass that has seen one stays NaN to the end of the slab
+// (scipy sosfilt: the state is NaN from then on), every spectrogram frame from there on is NaN, and the envelope of that
+// channel is NaN everywhere (sosfiltfilt's backward pass starts from the forward pass's NaN end).  A sweep cut into
+// time segments would recover in the next segment (its warm-up starts from zero state), so
+//  * every unit (channel, segment) of a forward sweep leaves one byte in the context's `seg_flags`: is the band-pass
+//    state it ended with non-finite? -- always written, never accumulated, no reset needed;
+//  * flood_channel() (one block per channel: inside env_fix_kernel when there is one, nan_flood_kernel otherwise)
+//    finds the first such segment and overwrites what the LATER segments wrote with NaN: the filtered trace and the
+//    spectrogram frames (PSD and dB) that reach past that segment's end.  The segment itself is NaN from the bad
+//    sample on by the arithmetic alone;
+//  * the envelope: the state slot behind the last tile (`n_tiles`) holds the state the channel's forward sweep ended
+//    with, and env_fix_kernel puts NaN there if ANY segment ended non-finite; the backward sweeps look at that slot
+//    first and fill the channel with NaN instead of sweeping.
+// (tests/test_gpu_parity.py::test_non_finite_*, against scipy.)
+struct FloodArgs {
+    const unsigned char *flags;  // [channels][n_seg]; NULL: nothing to do
+    int n_seg;
+    long long seg_len;           // input samples per segment
+    float *y;                    // filtered trace, sample p of channel c at y[c * y_pitch + p - skip]; may be NULL
+    long long y_pitch, T, skip;
+    float *psd, *db;             // [channel][frame][F] with psd_pitch floats per channel; may be NULL
+    long long psd_pitch, n_valid;
+    int F, nfft, hop;
+};
+
 // defined in sos.hip: hands the true states over between the time segments of a forward sweep (env_fix_kernel)
 int hd_launch_env_fix(hipdsp_ctx *ctx, const SosPlanDev *edev, int SE, double *ckpt, long long ckpt_pitch, long long channels,
-                      int n_seg, long long seg_len, long long n_tiles);
+                      int n_seg, long long seg_len, long long n_tiles, const FloodArgs *flood);
 
 namespace {
 
@@ -37,6 +62,7 @@ struct SeqArgs {
     // plan's numerator instead of on every sample); launch_scan turns 0 into 1
     double gain;
     long long units;        // channels * n_seg (the grid is rounded up to whole workgroups)
+    unsigned char *flags;   // one byte per unit: did it end with a non-finite state? (FloodArgs)
 };
 
 __device__ __forceinline__ long long opaque_zero()
@@ -149,6 +175,7 @@ struct CkptArgs {
     int n_seg, edge, rectify;
     long long units;        // channels * n_seg (the grid is rounded up to whole workgroups; the fused sweep: ChainArgs::units)
     double gain;            // the envelope filters gain * |y|: folded into its cascade (CASC_GAIN), never into the samples
+    unsigned char *flags;   // one byte per unit: did its band-pass end with a non-finite state? (FloodArgs; SF > 0)
 };
 
 // 16-byte global load the compiler does not track: the caller counts vmcnt by hand, so that the
@@ -221,6 +248,47 @@ struct BwdArgs {
     int fair;                // rotate_issue_priority() per tile (option "sos_fair", default off: no gain measured)
 };
 
+// wave-uniform: is any of the D state values NaN or infinite?
+template <int D>
+__device__ __forceinline__ bool state_not_finite(const double (&c)[D])
+{
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < D; r++) bad = bad || !(fabs(c[r]) <= 1.7976931348623157e308);
+    return bad;
+}
+
+// see FloodArgs; the whole block takes part (barriers inside), any block size
+__device__ void flood_channel(const FloodArgs &f, long long ch)
+{
+    __shared__ int first_bad;
+    if (f.flags == nullptr || f.n_seg <= 1) return;
+    if (threadIdx.x == 0) first_bad = 0x7fffffff;
+    __syncthreads();
+    const unsigned char *fl = f.flags + ch * f.n_seg;
+    for (int s2 = threadIdx.x; s2 < f.n_seg - 1; s2 += blockDim.x)
+        if (fl[s2]) atomicMin(&first_bad, s2);
+    __syncthreads();
+    const int s0 = first_bad;
+    if (s0 == 0x7fffffff) return;
+    const float nan_ = __builtin_nanf("");
+    const long long n1 = (long long)(s0 + 1) * f.seg_len;           // first sample of the first segment to overwrite
+    if (f.y != nullptr) {
+        float *yc = f.y + ch * f.y_pitch;
+        for (long long p = (n1 > f.skip ? n1 : f.skip) + threadIdx.x; p < f.T; p += blockDim.x) yc[p - f.skip] = nan_;
+    }
+    if (f.psd != nullptr || f.db != nullptr) {
+        // frames k with k hop + nfft > n1 (those that only touch the end of segment s0 are NaN already)
+        const long long k0 = n1 >= f.nfft ? (n1 - f.nfft) / f.hop + 1 : 0;
+        for (long long i = k0 * f.F + threadIdx.x; i < f.n_valid * f.F; i += blockDim.x) {
+            if (f.psd != nullptr) f.psd[ch * f.psd_pitch + i] = nan_;
+            if (f.db != nullptr) f.db[ch * f.psd_pitch + i] = nan_;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void nan_flood_kernel(FloodArgs f) { flood_channel(f, blockIdx.x); }
+
 __global__ void zero_rows_kernel(float *__restrict__ y, long long y_pitch, long long n, float value)
 {
     long long ch = blockIdx.y;
@@ -228,6 +296,14 @@ __global__ void zero_rows_kernel(float *__restrict__ y, long long y_pitch, long 
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x)
         yo[i] = value;
+}
+
+// a forward sweep without an envelope behind it (no env_fix_kernel to ride on): the flood as a launch of its own
+int launch_flood(hipdsp_ctx *ctx, const FloodArgs &f, long long channels)
+{
+    if (f.flags == nullptr || f.n_seg <= 1 || channels == 0) return HIPDSP_OK;
+    hipLaunchKernelGGL(nan_flood_kernel, dim3((unsigned)channels), dim3(256), 0, ctx->stream, f);
+    return hd_launch_status("nan_flood_kernel");
 }
 
 // the single-wave sweeps: up to "sos_waves_per_cu" (16) waves per CU, four SIMDs per CU

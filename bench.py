@@ -555,7 +555,7 @@ def main():
     else:
         tspec = None
         ds = hipdsp.DeviceArray(ctx, (C, nd, F), np.float32)
-    ctx.reserve(8*C*((T + edge + 2047)//2048)*2*len(esos))      # envelope state checkpoints
+    ctx.reserve(8*C*((T + edge + 2047)//2048 + 1)*2*len(esos))  # envelope state checkpoints (+ the state a channel ends with)
     hipdsp.synth(ctx, dx, T, C, T, args.rate, 1234 + args.config, c0=rank*C, c_total=world*C)
     ctx.synchronize()
 
@@ -863,7 +863,7 @@ def main():
     if rank == 0 and world == 1 and not multi and fuse3 and dt/args.steps < 2e-3:
         try:
             gctx = hipdsp.Context(local_rank, ctx.create_stream())
-            gctx.reserve(8*C*((T + edge + 2047)//2048)*2*len(esos))
+            gctx.reserve(8*C*((T + edge + 2047)//2048 + 1)*2*len(esos))
 
             def gstep():
                 hipdsp.chain_forward(gctx, plan, eplan, dx, T, df, T, C, T, args.nfft, args.hop, args.rate, ds, nd,

@@ -96,7 +96,7 @@ int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
  * with a message): no path returns HIPDSP_OK for a launch that gave up. */
 int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value);
 /* Pre-size the internal scratch (envelope state checkpoints: 16 * n_sections bytes per
- * 2048-sample tile and channel; four-step FFT work area) so that later calls do not
+ * 2048-sample tile and channel, for ceil((frames + padlen) / 2048) + 1 tiles; four-step FFT work area) so that later calls do not
  * allocate; required before stream capture into a hipGraph.  While a graph captured on the context
  * is alive the scratch cannot grow (the graph holds its address): a call that would need more returns
  * HIPDSP_ERR_INVALID -- reserve the largest size before capturing. */
@@ -222,6 +222,12 @@ int hipdsp_sos_segments_host(int64_t n_cus, int waves_max, int per_simd, int max
 int hipdsp_sosplan_info(hipdsp_ctx *ctx, hipdsp_sosplan *plan, int64_t *warmup, int *edge);
 
 /* ---- the hot path --------------------------------------------------------- */
+
+/* Non-finite samples (NaN, +-Inf) in x, every entry point below: as in the reference, i.e. as scipy does -- the
+ * filtered trace of that channel is NaN from the sample on TO THE END of the call's slab (sosfilt's state stays
+ * NaN), every spectrogram frame that reaches that far is NaN in every bin (dB: NaN), the envelope of that channel
+ * is NaN everywhere (sosfiltfilt's backward pass starts from the NaN end); other channels are not affected.  The
+ * time segments a sweep is cut into do not show (csrc/sos_device.h: FloodArgs). */
 
 /* BufferedFilter.process (bufferedfilter.py:31-36):
  *   y[c, :] = sosfilt(sos, x[c, :])[skip:]      zero initial state, per channel.

@@ -902,3 +902,132 @@ def test_copy_probe_copies():
         assert np.array_equal(dst.to_host(), x)
     with pytest.raises(ValueError):
         hipdsp.check(hipdsp.lib.hipdsp_copy_probe(c.handle, hipdsp._p(dst), hipdsp._p(src), 10))
+
+
+def same_nan_and_close(got, want, what):
+    """NaN exactly where the oracle has NaN; the rest within TOL of the oracle (relative to its largest finite value)."""
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, what
+    bad = ~np.isfinite(want)
+    assert np.array_equal(~np.isfinite(got), bad), (what, int((~np.isfinite(got)).sum()), int(bad.sum()))
+    if (~bad).any() and np.abs(want[~bad]).max() > 0:
+        assert np.abs(got[~bad] - want[~bad]).max()/np.abs(want[~bad]).max() < TOL, what
+
+
+NAN_AT = {'first sample': 0, 'early': 70001, 'last sample of a tile': 40*2048 - 1, 'late': 555555, 'last sample': 599999}
+
+
+@pytest.mark.parametrize('where', list(NAN_AT))
+@pytest.mark.parametrize('value', [np.nan, np.inf])
+def test_non_finite_samples_poison_what_the_reference_poisons(oracle, where, value):
+    """scipy's sosfilt keeps a NaN state for ever: from a NaN (or infinite) sample on the filtered trace is NaN to the end
+    of the slab, so is every spectrogram frame that reaches that far, and the envelope (sosfiltfilt: the backward pass
+    starts from the forward pass's end) is NaN EVERYWHERE in that channel (bufferedfilter.py:36,
+    bufferedspectrogram.py:51-58, bufferedenvelope.py:39-41).  A sweep cut into time segments would recover behind the
+    next segment border; the segment flags, flood_channel() and the end-state slot (sos_device.h: FloodArgs) keep the
+    reference's behaviour -- for one segment, the planner's choice and one-tile segments, through every entry point.
+    The other channels must not notice."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rate, T, C, nfft, hop = 96000.0, 600000, 3, 2048, 1024
+    F, nd = nfft//2 + 1, (T + hop - 1)//hop
+    rng = np.random.default_rng(99)
+    x = synth(rng, T, C, rate)
+    x[NAN_AT[where], 1] = value
+    sos, esos = butter_sos(2, (300.0, 3000.0), 'bandpass', rate), butter_sos(2, 20.0, 'lowpass', rate)
+    x64 = x.astype(np.float64)
+    want_f = oracle.sosfilt(sos, x64)
+    assert not np.isfinite(want_f[NAN_AT[where] + 1:, 1]).any() and np.isfinite(want_f[:, [0, 2]]).all()
+    want_e_alone = np.zeros((T, C))
+    oracle.envelope_process(esos, x64, want_e_alone, 0)
+    assert np.isnan(want_e_alone[:, 1]).all() and np.isfinite(want_e_alone[:, 0]).all()
+    c = gh.ctx()
+    dx = gh.to_planar(c, x)
+    fplan, eplan = hipdsp.SosPlan(c, sos), hipdsp.SosPlan(c, esos)
+    settings = [('one segment', {'max_segments': 1}), ('planner', {}),
+                ('one-tile segments', {'n_cus': 1024, 'sos_waves_per_cu': 16, 'sos_waves_min': 16})]
+    try:
+        for name, opts in settings:
+            for k, v in opts.items():
+                c.set_option(k, v)
+            # BufferedFilter alone, with and without frames dropped in front (nbefore)
+            for skip in (0, 100000):
+                dy = hipdsp.DeviceArray(c, (C, T - skip), np.float32)
+                hipdsp.sosfilt(c, fplan, dx, T, dy, T - skip, C, T, skip)
+                same_nan_and_close(dy.to_host().T, want_f[skip:], (name, 'sosfilt', skip))
+            # BufferedEnvelope alone (the trace itself is rectified)
+            de = hipdsp.DeviceArray(c, (C, T), np.float32)
+            hipdsp.envelope(c, eplan, dx, T, de, T, C, T, 0)
+            same_nan_and_close(de.to_host().T, want_e_alone, (name, 'envelope'))
+            # filter + envelope in the two unfused sweeps
+            yf, ye = hipdsp.DeviceArray(c, (C, T), np.float32), hipdsp.DeviceArray(c, (C, T), np.float32)
+            hipdsp.sosfilt_envelope(c, fplan, eplan, dx, T, yf, T, ye, T, C, T)
+            gf = yf.to_host()
+            same_nan_and_close(gf.T, want_f, (name, 'sosfilt_envelope: filtered'))
+            want_e = np.zeros((T, C))
+            oracle.envelope_process(esos, gf.T.astype(np.float64), want_e, 0)
+            same_nan_and_close(ye.to_host().T, want_e, (name, 'sosfilt_envelope: envelope'))
+            # the fused forward sweep (PSD and dB) + backward sweep, with and without an envelope behind the filter
+            for ep in (eplan, None):
+                yf, ye = hipdsp.DeviceArray(c, (C, T), np.float32), hipdsp.DeviceArray(c, (C, T), np.float32)
+                ps, db = (hipdsp.DeviceArray(c, (C, nd, F), np.float32) for _ in range(2))
+                hipdsp.chain_forward(c, fplan, ep, dx, T, yf, T, C, T, nfft, hop, rate, ps, nd, db_out=db)
+                gf = yf.to_host()
+                same_nan_and_close(gf.T, want_f, (name, 'chain_forward: filtered', ep is None))
+                want_s = np.zeros((nd, C, F))
+                oracle.spectrogram_process(gf.T.astype(np.float64), want_s, rate, nfft, hop)
+                got_s, got_db = ps.to_host(), db.to_host()
+                first_bad = max(0, (NAN_AT[where] - nfft)//hop + 1)
+                assert np.isnan(want_s[first_bad + 1:nd - 4, 1]).all() and np.isfinite(want_s[:, 0]).all()   # (zero tail behind)
+                for ch in range(C):
+                    for k in range(nd):
+                        same_nan_and_close(got_s[ch, k], want_s[k, ch], (name, 'PSD', ch, k))
+                    want_db = oracle.decibel(got_s[ch].astype(np.float64))       # the epilogue: decibel() of the PSD next to it
+                    assert np.array_equal(np.isnan(got_db[ch]), np.isnan(want_db)), (name, 'dB', ch)
+                    assert np.array_equal(np.isneginf(got_db[ch]), np.isneginf(want_db)), (name, 'dB floor and zero tail', ch)
+                    ok = np.isfinite(want_db)
+                    assert not ok.any() or np.abs(got_db[ch][ok] - want_db[ok]).max() < 1e-3, (name, 'dB', ch)
+                if ep is not None:
+                    hipdsp.sosfilt_envelope(c, fplan, eplan, dx, T, yf, T, ye, T, C, T, phase=2)
+                    want_e = np.zeros((T, C))
+                    oracle.envelope_process(esos, gf.T.astype(np.float64), want_e, 0)
+                    same_nan_and_close(ye.to_host().T, want_e, (name, 'chain: envelope'))
+            for k in opts:
+                c.set_option(k, {'n_cus': 256}.get(k, 0))
+    finally:
+        for k, v in (('max_segments', 0), ('n_cus', 256), ('sos_waves_per_cu', 0), ('sos_waves_min', 0)):
+            c.set_option(k, v)
+
+
+def test_non_finite_samples_in_the_split_frames_sweeps(oracle):
+    """The same through hipdsp_chain_forward (even frames) + hipdsp_chain_backward (odd frames + envelope)."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rate, T, C, nfft, hop = 96000.0, 600000, 3, 2048, 1024
+    F, nd = nfft//2 + 1, (T + hop - 1)//hop
+    x = synth(np.random.default_rng(98), T, C, rate)
+    x[123456, 2] = np.nan
+    sos, esos = butter_sos(2, (300.0, 3000.0), 'bandpass', rate), butter_sos(2, 20.0, 'lowpass', rate)
+    want_f = oracle.sosfilt(sos, x.astype(np.float64))
+    c = gh.ctx()
+    dx = gh.to_planar(c, x)
+    fplan, eplan = hipdsp.SosPlan(c, sos), hipdsp.SosPlan(c, esos)
+    yf, ye = hipdsp.DeviceArray(c, (C, T), np.float32), hipdsp.DeviceArray(c, (C, T), np.float32)
+    ps = hipdsp.DeviceArray(c, (C, nd, F), np.float32)
+    c.set_option('chain_split_frames', 1)
+    try:
+        hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, nfft, hop, rate, ps, nd)
+        hipdsp.chain_backward(c, eplan, yf, T, ye, T, C, T, nfft, hop, rate, ps, nd)
+    finally:
+        c.set_option('chain_split_frames', 0)
+    gf = yf.to_host()
+    same_nan_and_close(gf.T, want_f, 'filtered')
+    want_s, want_e = np.zeros((nd, C, F)), np.zeros((T, C))
+    oracle.spectrogram_process(gf.T.astype(np.float64), want_s, rate, nfft, hop)
+    oracle.envelope_process(esos, gf.T.astype(np.float64), want_e, 0)
+    got_s = ps.to_host()
+    for ch in range(C):
+        for k in range(nd):
+            same_nan_and_close(got_s[ch, k], want_s[k, ch], ('PSD', ch, k))
+    same_nan_and_close(ye.to_host().T, want_e, 'envelope')
+    assert np.isnan(want_e[:, 2]).all() and np.isfinite(want_e[:, :2]).all()

@@ -150,3 +150,41 @@ def test_oracle_against_live_scipy_random_cases(oracle):
         fo, to, So = oracle.spectrogram(x, rate, nfft, nfft - hop)
         assert So.shape == want.shape and np.allclose(fo, f)
         assert np.max(np.abs(So - want)) <= 1e-10*np.max(np.abs(want))
+
+
+@pytest.mark.parametrize('value', [np.nan, np.inf, -np.inf])
+def test_non_finite_samples_behave_like_scipy(oracle, value):
+    """The reference has no handling of its own for NaN or infinite samples: it gets what scipy does -- sosfilt's state
+    stays NaN to the end of the slab, sosfiltfilt's output is NaN everywhere in that channel, a spectrogram frame that
+    contains such a sample is NaN in every bin, decibel() passes NaN on.  The restatement must do the same, because the
+    GPU path is checked against it (tests/test_gpu_parity.py::test_non_finite_*)."""
+    ss = pytest.importorskip('scipy.signal')
+    from audian_amd.design import butter_sos
+    rate, T, nfft, hop = 48000.0, 9000, 256, 128
+    x = np.random.default_rng(5).standard_normal((T, 3))
+    x[4000, 1] = value
+    for sos in (butter_sos(2, (300.0, 3000.0), 'bandpass', rate), butter_sos(2, 500.0, 'lowpass', rate),
+                butter_sos(4, (300.0, 3000.0), 'bandpass', rate)):
+        got = oracle.sosfilt(sos, x)
+        want = np.stack([ss.sosfilt(sos, x[:, c]) for c in range(3)], axis=1)
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isfinite(got), np.isfinite(want))
+        assert not np.isfinite(got[4001:, 1]).any() and np.isfinite(got[:4000, 1]).all() and np.isfinite(got[:, [0, 2]]).all()
+        env = np.zeros((T, 3))
+        oracle.envelope_process(sos, x, env, 0)
+        want_e = ss.sosfiltfilt(sos, (np.pi/2)*np.abs(x), axis=0)
+        want_e[want_e < 0] = 0
+        assert np.array_equal(np.isnan(env), np.isnan(want_e))
+        assert np.isnan(env[:, 1]).all() and np.isfinite(env[:, [0, 2]]).all()
+    nd = (T + hop - 1)//hop
+    spec = np.zeros((nd, 3, nfft//2 + 1))
+    oracle.spectrogram_process(x, spec, rate, nfft, hop)
+    with np.errstate(invalid='ignore'):
+        _, _, S = ss.spectrogram(x, fs=rate, window='hann', nperseg=nfft, noverlap=nfft - hop, detrend='constant',
+                                 scaling='density', mode='psd', axis=0)
+    S = np.transpose(S, (2, 1, 0))                     # scipy: (F, C, frames) -> (frames, C, F)
+    assert np.array_equal(np.isnan(spec[:S.shape[0]]), np.isnan(S))
+    hit = [k for k in range(S.shape[0]) if k*hop <= 4000 < k*hop + nfft]
+    assert hit and all(np.isnan(spec[k, 1]).all() for k in hit) and np.isfinite(spec[:, [0, 2]]).all()
+    assert np.isfinite(np.delete(spec[:, 1], hit, axis=0)).all()
+    db = oracle.decibel(spec[:, 1])
+    assert np.array_equal(np.isnan(db), np.isnan(spec[:, 1]))
