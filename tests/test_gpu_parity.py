@@ -1031,3 +1031,26 @@ def test_non_finite_samples_in_the_split_frames_sweeps(oracle):
             same_nan_and_close(got_s[ch, k], want_s[k, ch], ('PSD', ch, k))
     same_nan_and_close(ye.to_host().T, want_e, 'envelope')
     assert np.isnan(want_e[:, 2]).all() and np.isfinite(want_e[:, :2]).all()
+
+
+@pytest.mark.parametrize('nfft,hop', [(2048, 1024), (1024, 256), (256, 128), (4096, 1024), (100, 37)])
+def test_non_finite_samples_in_the_spectrogram_alone(oracle, nfft, hop):
+    """BufferedSpectrogram on a source with a NaN and an infinite sample: exactly the frames that contain one are NaN,
+    in every bin (the frame's mean is NaN, bufferedspectrogram.py:51-56), their dB is NaN, the others do not notice --
+    for every spectrogram kernel (fused-frame, two-stage, workgroup, generic)."""
+    rate, T, C = 48000.0, 90000, 2
+    x = synth(np.random.default_rng(nfft + hop), T, C, rate)
+    x[33333, 0] = np.nan
+    x[70001, 1] = -np.inf
+    nd = (T + hop - 1)//hop
+    want = np.zeros((nd, C, nfft//2 + 1))
+    oracle.spectrogram_process(x.astype(np.float64), want, rate, nfft, hop)
+    got, got_db = gh.gpu_spectrogram(x, rate, nfft, hop, nd, want_db=True)
+    assert np.isnan(want).any() and np.isfinite(want).any()
+    for ch in range(C):
+        for k in range(nd):
+            same_nan_and_close(got[k, ch], want[k, ch], (ch, k))
+    want_db = oracle.decibel(got)
+    assert np.array_equal(np.isnan(got_db), np.isnan(want_db))
+    fin = np.isfinite(want_db)
+    assert np.array_equal(np.isfinite(got_db), fin) and np.abs(got_db[fin] - want_db[fin]).max() < 1e-3
