@@ -757,3 +757,52 @@ def test_fused_launch_only_when_the_slabs_coincide(oracle):
     o['filtered'].update()
     assert got == {'chain_forward': 1, 'sosfilt_envelope:2': 1}, got
     compare(g, o)
+
+
+def compare_with_nan(g, o):
+    """compare() for buffers that may hold NaN: NaN exactly where the twin has it, the rest as compare()."""
+    for name in ('filtered', 'envelope', 'spectrogram'):
+        a, b = g[name], o[name]
+        assert a.offset == b.offset and a.buffer.shape == b.buffer.shape, name
+        ga, gb = np.asarray(a.buffer, dtype=np.float64), np.asarray(b.buffer, dtype=np.float64)
+        assert np.array_equal(~np.isfinite(ga), ~np.isfinite(gb)), (name, int((~np.isfinite(ga)).sum()), int((~np.isfinite(gb)).sum()))
+        ok = np.isfinite(gb)
+        rows = ga.reshape(len(ga), a.channels, -1)
+        want = gb.reshape(len(gb), a.channels, -1)
+        for ch in range(a.channels):
+            m = ok.reshape(want.shape)[:, ch]
+            if name == 'spectrogram':
+                for k in range(len(want)):
+                    if m[k].all() and np.max(np.abs(want[k, ch])) > 0:
+                        assert rel_err(rows[k, ch], want[k, ch]) < TOL, (name, k, ch)
+            elif m.any() and np.abs(want[:, ch][m]).max() > 0:
+                assert np.abs(rows[:, ch][m] - want[:, ch][m]).max()/np.abs(want[:, ch][m]).max() < TOL, (name, ch)
+
+
+def test_a_nan_in_the_recording_shows_where_the_reference_shows_it(oracle):
+    """A NaN sample in one channel of the recording, scrolled through the facade (fused launch and the separate
+    process() calls alike): the filtered trace is NaN from it to the end of the buffer slab, the spectrogram frames from
+    there on are NaN, the envelope of that channel is NaN in the whole slab -- and as soon as the slab no longer holds
+    the sample everything is finite again, as with the reference's per-slab scipy calls."""
+    from audian_amd.bufferedfilter import BufferedFilter
+    from audian_amd.bufferedenvelope import BufferedEnvelope
+    from audian_amd.bufferedspectrogram import BufferedSpectrogram
+    rate = 48000.0
+    x = recording(rate, 90.0, 3)
+    x[int(9.3*rate), 1] = np.nan
+    g = build((BufferedFilter, BufferedEnvelope, BufferedSpectrogram), x, rate, 6.0, 1.0, nfft=1024)
+    o = build(oracle_twins(oracle), x, rate, 6.0, 1.0, nfft=1024)
+    for twin in (g, o):
+        twin['filtered'].highpass_cutoff = 300.0
+        twin['filtered'].lowpass_cutoff = 3000.0
+        twin['filtered'].update()
+    seen_nan = seen_clean = False
+    for t0, t1 in [(0.0, 3.0), (5.0, 8.0), (8.0, 11.0), (9.0, 12.0), (70.0, 73.0), (7.5, 9.5), (84.0, 90.0)]:
+        g.update_times(t0, t1)
+        o.update_times(t0, t1)
+        compare_with_nan(g, o)
+        bad = np.isnan(np.asarray(o['envelope'].buffer))
+        seen_nan = seen_nan or bad[:, 1].all()
+        seen_clean = seen_clean or not bad.any()
+        assert not bad[:, [0, 2]].any()
+    assert seen_nan and seen_clean
