@@ -547,3 +547,75 @@ def test_random_screen_reductions(oracle, seed):
     dst = hipdsp.DeviceArray(c, (Cp, pitch), np.float32)
     hipdsp.pcm_unpack(c, up, nbytes, Tp, Cp, scale, dst, pitch)
     assert np.array_equal(dst.to_host()[:, :Tp], (ints.T.astype(np.float64)*scale).astype(np.float32)), (seed, nbytes)
+
+
+def _same_non_finite(got, want, what):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    bad = ~np.isfinite(want)
+    assert np.array_equal(~np.isfinite(got), bad), (what, int((~np.isfinite(got)).sum()), int(bad.sum()))
+    if (~bad).any() and np.abs(want[~bad]).max() > 0:
+        assert np.abs(got[~bad] - want[~bad]).max()/np.abs(want[~bad]).max() < TOL, what
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_random_non_finite_cases(oracle, seed):
+    """A few NaN / infinite samples at random places of random channels, random lengths, designs, pitches, nbefore,
+    segmentations and spectrogram windows, through hipdsp_sosfilt, hipdsp_envelope and (long traces) the fused sweeps:
+    non-finite exactly where the oracle is, the rest within tolerance."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rng = np.random.default_rng(9100 + seed)
+    rate = float(rng.choice([44100.0, 96000.0, 192000.0]))
+    long_trace = bool(rng.integers(0, 3))
+    T = int(rng.integers(4, 120))*TILE + int(rng.integers(-TILE + 1, TILE)) if long_trace else draw_length(rng, lo=64)
+    T = max(T, 4*TILE) if long_trace else T
+    C = int(rng.integers(1, 6))
+    x = (rng.standard_normal((T, C))*rng.uniform(0.1, 3.0)).astype(np.float32)
+    for _ in range(int(rng.integers(1, 4))):
+        x[int(rng.integers(0, T)), int(rng.integers(0, C))] = rng.choice([np.nan, np.nan, np.inf, -np.inf])
+    x64 = x.astype(np.float64)
+    sos = draw_design(rng, rate, False)
+    esos = draw_design(rng, rate, True)
+    c = gh.ctx()
+    opts = [{}, {'max_segments': 1}, {'max_segments': 3}, {'n_cus': 1024, 'sos_waves_per_cu': 16, 'sos_waves_min': 16}][int(rng.integers(0, 4))]
+    try:
+        for k, v in opts.items():
+            c.set_option(k, v)
+        skip = int(rng.integers(0, T)) if rng.integers(0, 2) else 0
+        dx = gh.to_planar(c, x)
+        plan, eplan = hipdsp.SosPlan(c, sos), hipdsp.SosPlan(c, esos)
+        dy = hipdsp.DeviceArray(c, (C, max(T - skip, 1)), np.float32)
+        hipdsp.sosfilt(c, plan, dx, T, dy, max(T - skip, 1), C, T, skip)
+        want_f = oracle.sosfilt(sos, x64)
+        _same_non_finite(dy.to_host()[:, :T - skip].T, want_f[skip:], (seed, 'sosfilt', skip, opts))
+        edge = oracle.sosfiltfilt_edge(esos)
+        if T > edge:
+            eskip = int(rng.integers(0, T)) if rng.integers(0, 2) else 0
+            de = hipdsp.DeviceArray(c, (C, max(T - eskip, 1)), np.float32)
+            hipdsp.envelope(c, eplan, dx, T, de, max(T - eskip, 1), C, T, eskip)
+            want_e = np.zeros((T - eskip, C))
+            oracle.envelope_process(esos, x64, want_e, eskip)
+            _same_non_finite(de.to_host()[:, :T - eskip].T, want_e, (seed, 'envelope', eskip, opts))
+        if long_trace and len(sos) <= 4 and len(esos) <= 2:
+            nfft, hop = [(2048, 1024), (2048, 512), (1024, 512), (1024, 256), (512, 256), (256, 128)][int(rng.integers(0, 6))]
+            F, nd = nfft//2 + 1, (T + hop - 1)//hop
+            with_env = bool(rng.integers(0, 2))
+            yf, ye = hipdsp.DeviceArray(c, (C, T), np.float32), hipdsp.DeviceArray(c, (C, T), np.float32)
+            ps = hipdsp.DeviceArray(c, (C, nd, F), np.float32)
+            hipdsp.chain_forward(c, plan, eplan if with_env else None, dx, T, yf, T, C, T, nfft, hop, rate, ps, nd)
+            gf = yf.to_host()
+            _same_non_finite(gf.T, want_f, (seed, 'chain: filtered', opts))
+            want_s = np.zeros((nd, C, F))
+            oracle.spectrogram_process(gf.T.astype(np.float64), want_s, rate, nfft, hop)
+            gs = ps.to_host()
+            for ch in range(C):
+                for k in range(nd):
+                    _same_non_finite(gs[ch, k], want_s[k, ch], (seed, 'chain: PSD', ch, k, nfft, hop, opts))
+            if with_env and T > edge:
+                hipdsp.sosfilt_envelope(c, plan, eplan, dx, T, yf, T, ye, T, C, T, phase=2)
+                want_e = np.zeros((T, C))
+                oracle.envelope_process(esos, gf.T.astype(np.float64), want_e, 0)
+                _same_non_finite(ye.to_host().T, want_e, (seed, 'chain: envelope', opts))
+    finally:
+        for k, v in (('max_segments', 0), ('n_cus', 256), ('sos_waves_per_cu', 0), ('sos_waves_min', 0)):
+            c.set_option(k, v)
