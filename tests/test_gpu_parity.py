@@ -1054,3 +1054,28 @@ def test_non_finite_samples_in_the_spectrogram_alone(oracle, nfft, hop):
     assert np.array_equal(np.isnan(got_db), np.isnan(want_db))
     fin = np.isfinite(want_db)
     assert np.array_equal(np.isfinite(got_db), fin) and np.abs(got_db[fin] - want_db[fin]).max() < 1e-3
+
+
+def test_repeated_runs_are_bit_identical():
+    """No atomics, no data-dependent scheduling in the data path: the same call on the same input gives the same bits,
+    whatever ran in between and whichever of two contexts (streams) runs it (tools/soak.py: 13 000 steps)."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rate, T, C, nfft, hop = 96000.0, 700000, 5, 2048, 1024
+    F, nd = nfft//2 + 1, (T + hop - 1)//hop
+    x = synth(np.random.default_rng(31), T, C, rate)
+    sos, esos = butter_sos(2, (300.0, 3000.0), 'bandpass', rate), butter_sos(2, 20.0, 'lowpass', rate)
+    runs = []
+    for c in (gh.ctx(), hipdsp.Context(0), gh.ctx()):
+        dx = gh.to_planar(c, x)
+        fplan, eplan = hipdsp.SosPlan(c, sos), hipdsp.SosPlan(c, esos)
+        yf, ye = hipdsp.DeviceArray(c, (C, T), np.float32), hipdsp.DeviceArray(c, (C, T), np.float32)
+        ps, db = (hipdsp.DeviceArray(c, (C, nd, F), np.float32) for _ in range(2))
+        for _ in range(2):
+            hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, nfft, hop, rate, ps, nd, db_out=db)
+            hipdsp.sosfilt_envelope(c, fplan, eplan, dx, T, yf, T, ye, T, C, T, phase=2)
+            runs.append([a.to_host() for a in (yf, ye, ps, db)])
+            hipdsp.envelope(c, eplan, dx, T, ye, T, C, T, 0)          # something else in between
+    for r in runs[1:]:
+        for a, b in zip(r, runs[0]):
+            assert np.array_equal(a, b)
