@@ -505,8 +505,7 @@ __global__ __launch_bounds__(64 * WPB_, REGW ? 2 : 1) void env_bwd_kernel(const 
     float4 *lds = lds_all[wave];
     float *ldsf = reinterpret_cast<float *>(lds);
     const int lane = threadIdx.x & 63;
-    // (experiment: "sos_debug" bits 4-6 rotate the workgroups over the units, i.e. shift which XCD gets which data)
-    const long long unit = (long long)((blockIdx.x + ((a.debug >> 4) & 7)) % gridDim.x) * WPB_ + wave;
+    const long long unit = (long long)blockIdx.x * WPB_ + wave;
     if (unit >= a.units) return;                    // (no workgroup barrier anywhere: a wave may leave)
     const int seg = (int)(unit % a.n_seg);
     const long long ch = unit / a.n_seg;
