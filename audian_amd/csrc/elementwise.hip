@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void unwrap_apply_kernel(const float *__restri
         for (int k = 0; k < 4; k++) {
             if (p + k < n) {
                 float o = v[k] + step * (float)(before + e[k]);
-                if (clips) o = fminf(fmaxf(o, -0.5f * step), 0.5f * step);
+                if (clips) o = o < -0.5f * step ? -0.5f * step : (o > 0.5f * step ? 0.5f * step : o);   // (np.clip: NaN stays NaN)
                 yc[p + k] = o * scale;
             }
         }

@@ -835,7 +835,7 @@ __global__ void flip_kernel(const float *__restrict__ x, long long x_pitch, long
     float *yc = y + ch * y_pitch;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float v = xc[N - 1 - (first + i)];
-        if (clamp) v = fmaxf(v, 0.f);
+        if (clamp && v < 0.f) v = 0.f;             // env[env < 0] = 0 (bufferedenvelope.py:41): NaN stays NaN, fmaxf would drop it
         yc[i] = v;
     }
 }

@@ -1079,3 +1079,56 @@ def test_repeated_runs_are_bit_identical():
     for r in runs[1:]:
         for a, b in zip(r, runs[0]):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize('pos', [5, 250000, 399990])
+def test_non_finite_samples_in_an_envelope_longer_than_one_plan(oracle, pos):
+    """hipdsp_envelope_multi (cascades of more than four sections, chained plans): a NaN anywhere makes that channel's
+    envelope NaN everywhere, the others do not notice -- with the sweeps cut into one-tile segments."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rate, T, C = 48000.0, 400000, 3
+    x = synth(np.random.default_rng(pos), T, C, rate)
+    x[pos, 0] = np.nan
+    sos = butter_sos(10, 800.0, 'lowpass', rate)                       # five sections: plans of 2 + 2 + 1
+    want = np.zeros((T, C))
+    oracle.envelope_process(sos, x.astype(np.float64), want, 0)
+    assert np.isnan(want[:, 0]).all() and np.isfinite(want[:, 1:]).all()
+    c = gh.ctx()
+    dx = gh.to_planar(c, x)
+    plans = [hipdsp.SosPlan(c, sos[0:2]), hipdsp.SosPlan(c, sos[2:4]), hipdsp.SosPlan(c, sos[4:5])]
+    try:
+        for opts in ({}, {'n_cus': 1024, 'sos_waves_per_cu': 16, 'sos_waves_min': 16}):
+            for k, v in opts.items():
+                c.set_option(k, v)
+            dy = hipdsp.DeviceArray(c, (C, T), np.float32)
+            hipdsp.envelope_multi(c, plans, dx, T, dy, T, C, T, 0)
+            got = dy.to_host().T
+            assert np.isnan(got[:, 0]).all(), opts
+            for ch in (1, 2):
+                assert rel_err(got[:, ch], want[:, ch]) < 2e-4, (opts, ch)     # (float32 hand-over between the plans)
+    finally:
+        for k, v in (('n_cus', 256), ('sos_waves_per_cu', 0), ('sos_waves_min', 0)):
+            c.set_option(k, v)
+
+
+def test_non_finite_samples_through_unwrap(oracle):
+    """hipdsp_unwrap with clipping: np.clip leaves NaN alone (fminf(fmaxf()) would not); an infinite sample clips."""
+    from audian_amd import hipdsp
+    rng = np.random.default_rng(77)
+    T, C = 30000, 2
+    x = np.cumsum(rng.uniform(-0.2, 0.2, (T, C)), axis=0).astype(np.float32)
+    x = ((x + 1.0) % 2.0 - 1.0).astype(np.float32)                    # wrapped into [-1, 1)
+    x[1234, 0] = np.nan
+    x[20000, 1] = np.inf
+    c = gh.ctx()
+    for clips in (False, True):
+        with np.errstate(invalid='ignore'):
+            want = oracle.unwrap(x, 1.5, 1.0, clips=clips, down_scale=True)
+        dx = gh.to_planar(c, x)
+        dy = hipdsp.DeviceArray(c, (C, T), np.float32)
+        hipdsp.unwrap(c, dx, T, C, T, 1.5, dy, T, clips=clips, down_scale=True)
+        got = dy.to_host().T
+        assert np.array_equal(np.isnan(got), np.isnan(want)), clips
+        ok = ~np.isnan(want)
+        assert np.array_equal(got[ok], want[ok]), clips
