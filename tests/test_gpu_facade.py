@@ -549,6 +549,17 @@ def test_random_walks_match_the_oracle_twins(oracle, seed):
     overlap, jumps, the ends of the recording), change the filter cut-offs, the envelope parameters, the
     spectrogram resolution, read parts of buffers in between -- device-backed traces against twins that keep
     the same bookkeeping and compute with the oracle, compared after every action."""
+    _random_walk(oracle, seed, poison=False)
+
+
+@pytest.mark.parametrize('seed', range(100, 104))
+def test_random_walks_over_a_recording_with_non_finite_samples(oracle, seed):
+    """The same walks over recordings that hold a few NaN / infinite samples: non-finite exactly where the twins are
+    (DESIGN 5.1e), whichever launches the walk takes."""
+    _random_walk(oracle, seed, poison=True)
+
+
+def _random_walk(oracle, seed, poison):
     from audian_amd.bufferedfilter import BufferedFilter
     from audian_amd.bufferedenvelope import BufferedEnvelope
     from audian_amd.bufferedspectrogram import BufferedSpectrogram
@@ -557,6 +568,10 @@ def test_random_walks_match_the_oracle_twins(oracle, seed):
     seconds = float(rng.uniform(12.0, 40.0))
     channels = int(rng.integers(1, 4))
     x = recording(rate, seconds, channels, seed=seed)
+    if poison:
+        for _ in range(int(rng.integers(1, 4))):
+            x[int(rng.integers(0, len(x))), int(rng.integers(0, channels))] = rng.choice([np.nan, np.nan, np.inf, -np.inf])
+    same = compare_with_nan if poison else compare
     buffer_time, back_time = float(rng.uniform(2.0, 6.0)), float(rng.uniform(0.0, 1.5))
     nfft = int(rng.choice([64, 256, 512, 1024]))
     g = build((BufferedFilter, BufferedEnvelope, BufferedSpectrogram), x, rate, buffer_time, back_time, nfft=nfft)
@@ -593,15 +608,15 @@ def test_random_walks_match_the_oracle_twins(oracle, seed):
             f, sp = g['filtered'], g['spectrogram']
             if len(f.buffer) > 10:
                 a = int(rng.integers(0, len(f.buffer) - 5))
-                assert np.all(np.isfinite(f.buffer[a:a + 5, 0]))
+                assert poison or np.all(np.isfinite(f.buffer[a:a + 5, 0]))
             if len(sp.buffer) > 2:
-                assert np.all(np.isfinite(sp.buffer[int(rng.integers(0, len(sp.buffer))), 0]))
+                assert np.all(np.isfinite(sp.buffer[int(rng.integers(0, len(sp.buffer))), 0])) or poison
         t1 = min(t0 + float(rng.uniform(0.3, buffer_time*0.6)), seconds)
         g.update_times(t0, t1)
         o.update_times(t0, t1)
         if step % 2 == 1 or action >= 4:
-            compare(g, o)
-    compare(g, o)
+            same(g, o)
+    same(g, o)
 
 
 def launches_during(fn):
