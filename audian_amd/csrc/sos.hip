@@ -862,7 +862,7 @@ __global__ void copy_skip_kernel(const float *__restrict__ x, long long x_pitch,
 int launch_scan(hipdsp_ctx *ctx, const SosPlanDev *dev, int S, SeqArgs a, long long channels, long long warm)
 {
     if (a.gain == 0.0) a.gain = 1.0;
-    plan_segments(ctx, a.N, channels, warm, &a.seg_len, &a.n_seg);
+    plan_segments(ctx, a.N, channels, warm, &a.seg_len, &a.n_seg, -1);
     a.units = channels * a.n_seg;
     long long blocks = (a.units + WPB - 1) / WPB;
     if (blocks > 0x7fffffffLL) {
@@ -914,7 +914,7 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
         // a cascade that forgets (a plan that does not decay is never cut into segments)
         long long warm = warmF;
         if (warmF >= (1LL << 40) || warmE >= (1LL << 40)) warm = 1LL << 50;
-        plan_segments(ctx, frames, channels, warm, &fa.seg_len, &fa.n_seg);
+        plan_segments(ctx, frames, channels, warm, &fa.seg_len, &fa.n_seg, -2);
         fa.units = channels * fa.n_seg;
         long long blocks = (fa.units + WPB - 1) / WPB;
         HD_REQUIRE(blocks <= 0x7fffffffLL, "grid too large");
@@ -967,7 +967,7 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
     b.fair = ctx->sos_fair;
     const long long used_tiles = n_tiles - skip / TILE;      // tiles below `skip` are never visited
     long long seg_len = 0;
-    plan_segments(ctx, used_tiles * TILE, channels, warmE, &seg_len, &b.n_seg, SE <= 2 ? 8 : 16);   // env_bwd_kernel: REGW
+    plan_segments(ctx, used_tiles * TILE, channels, warmE, &seg_len, &b.n_seg, 4, SE <= 2 ? 8 : 16);   // env_bwd_kernel: REGW
     b.seg_tiles = seg_len / TILE;
     b.warm_tiles = warmE / TILE;
     b.units = channels * b.n_seg;

@@ -309,12 +309,13 @@ int launch_flood(hipdsp_ctx *ctx, const FloodArgs &f, long long channels)
 // the single-wave sweeps: up to "sos_waves_per_cu" (16) waves per CU, four SIMDs per CU
 // ("sos_waves_min" = w, experiments: force w waves per CU by making every level below it cost the same)
 // (`w_cap`: what the kernel's registers allow -- the register hand-over of the backward sweep holds two waves a SIMD)
+// (`model`: which sweep -- 4 the backward sweep, -1 sos_scan_kernel, -2 sos_ckpt_kernel: sos_plan.hip, tile_step_cost)
 void plan_segments(const hipdsp_ctx *ctx, long long N, long long channels, long long warm,
-                   long long *seg_len, int *n_seg, int w_cap = 16)
+                   long long *seg_len, int *n_seg, int model, int w_cap = 16)
 {
     int w_max = ctx->sos_waves_per_cu > 0 ? ctx->sos_waves_per_cu : 16;
     if (w_max > w_cap) w_max = w_cap;
-    hd_plan_segments_occ(ctx->n_cus, w_max, ctx->sos_waves_min >= w_max ? 0 : 4, ctx->max_segments, N, channels, warm, seg_len, n_seg);
+    hd_plan_segments_occ(ctx->n_cus, w_max, ctx->sos_waves_min >= w_max ? 0 : model, ctx->max_segments, N, channels, warm, seg_len, n_seg);
 }
 
 // the fused sweeps: up to 8 pairs of waves per workgroup = CU ("chain_pairs": fewer, experiments)

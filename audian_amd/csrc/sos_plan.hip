@@ -170,6 +170,13 @@ int fill_plan(SosPlanDev *p, const double *sos, int S)
 //   * fused sweeps (`per_simd` = 0): the pairs need each other's gaps -- 8 pairs per CU reach 0.66 tile steps per
 //     microsecond, 4 pairs 0.57, 2 pairs 0.37 -- so the CU is filled whenever the job allows:
 //     cost per tile step ~ w_max x (1 + 0.25 (1 - w / w_max)).
+//   * the band-pass alone (sos_scan_kernel, `per_simd` = -1): no prefetch, every tile's load latency is hidden by the
+//     other waves of the CU only -- 64 ch x 600 s take 12.97 / 7.49 / 5.98 / 5.56 ms with 4 / 8 / 12 / 16 waves per CU
+//     (tools/sos_waves.py, profiles/r03_sos_waves.log), i.e. a tile step costs a wave 7 + 0.5625 w (16 at 16 waves);
+//   * the band-pass + envelope-state sweep (sos_ckpt_kernel, prefetching; `per_simd` = -2): 7.46 / 6.31 / 6.01 / 5.93 ms
+//     -- throughput is 80 % at one wave per SIMD already: 1.4 + 0.9125 w.
+//   (Round 3 first planned both with the backward sweep's table: 8 waves per CU, 7.5 instead of 5.6 ms for a
+//   BufferedFilter alone.)
 // With more units than n_cus x w_max the waves run in rounds of that many.
 double tile_step_cost(long long w, int w_max, int per_simd)
 {
@@ -177,6 +184,8 @@ double tile_step_cost(long long w, int w_max, int per_simd)
         const long long sw = (w + per_simd - 1) / per_simd;
         return sw <= 1 ? 0.65 : 0.5 * (double)sw;
     }
+    if (per_simd == -1) return 7.0 + 0.5625 * (double)w;
+    if (per_simd == -2) return 1.4 + 0.9125 * (double)w;
     return (double)w_max * (1.0 + 0.25 * (1.0 - (double)w / (double)w_max));
 }
 
@@ -248,7 +257,7 @@ int hipdsp_sos_plan_host(const double *host_sos, int n_sections, int64_t *warmup
 int hipdsp_sos_segments_host(int64_t n_cus, int waves_max, int per_simd, int max_segments, int64_t frames,
                              int64_t channels, int64_t warmup, int64_t *segment_frames, int *n_segments)
 {
-    HD_REQUIRE(n_cus >= 1 && waves_max >= 1 && per_simd >= 0 && frames >= 1 && channels >= 1 && warmup >= 0 &&
+    HD_REQUIRE(n_cus >= 1 && waves_max >= 1 && per_simd >= -2 && frames >= 1 && channels >= 1 && warmup >= 0 &&
                max_segments >= 0, "bad argument");
     HD_REQUIRE(segment_frames != nullptr && n_segments != nullptr, "NULL output");
     long long len = 0;

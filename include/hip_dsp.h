@@ -209,11 +209,13 @@ int hipdsp_sos_plan_host(const double *host_sos, int n_sections, int64_t *warmup
  * waves each ("sos_waves_per_cu", 16; the fused sweeps: 8 pairs), when a segment has to re-read
  * `warmup` samples before its range.  The count minimises
  *     rounds x (segment + warm-up) x cost of a tile step at w waves per CU
- * (rounds of n_cus x waves_max units when there are more).  per_simd = 4 (the single-wave sweeps, four
- * SIMDs per CU): memory-bound from two waves per SIMD on, so a tile step costs ceil(w / 4) / 2, and 0.65
- * at one wave per SIMD (measured, profiles/r03_occupancy_sweep.log): 8 waves per CU are preferred to 16,
- * short jobs get 4.  per_simd = 0 (the fused sweeps): waves_max x (1 + 0.25 (1 - w / waves_max)) -- the
- * CU is filled whenever the job allows.  segment_frames is a multiple of the 2048-sample tile.
+ * (rounds of n_cus x waves_max units when there are more).  per_simd selects the sweep's measured cost table:
+ * 4 (the envelope's backward sweep, four SIMDs per CU): memory-bound from two waves per SIMD on, so a tile step
+ * costs ceil(w / 4) / 2, and 0.65 at one wave per SIMD (profiles/r03_occupancy_sweep.log): 8 waves per CU are
+ * preferred to 16, short jobs get 4.  0 (the fused sweeps): waves_max x (1 + 0.25 (1 - w / waves_max)) -- the
+ * CU is filled whenever the job allows.  -1 (the band-pass alone, no prefetch): 7 + 0.5625 w, and -2 (band-pass +
+ * envelope states, prefetching): 1.4 + 0.9125 w (profiles/r03_sos_waves.log) -- both fill the CU for long jobs.
+ * segment_frames is a multiple of the 2048-sample tile.
  * Host only (tests, capacity planning). */
 int hipdsp_sos_segments_host(int64_t n_cus, int waves_max, int per_simd, int max_segments, int64_t frames,
                              int64_t channels, int64_t warmup, int64_t *segment_frames,

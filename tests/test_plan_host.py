@@ -83,9 +83,13 @@ def segments(n_cus, w_max, per_simd, frames, channels, warm, max_segments=0):
 
 
 def step_cost(w, w_max, per_simd):
-    if per_simd:
+    if per_simd > 0:
         sw = -(-w//per_simd)
         return 0.65 if sw <= 1 else 0.5*sw
+    if per_simd == -1:
+        return 7.0 + 0.5625*w
+    if per_simd == -2:
+        return 1.4 + 0.9125*w
     return w_max*(1 + 0.25*(1 - w/w_max))
 
 
@@ -105,7 +109,7 @@ def test_segment_planner_properties():
     rng = np.random.default_rng(0)
     for _ in range(300):
         n_cus = int(rng.choice([256, 248, 64]))
-        w_max, per_simd = [(16, 4), (12, 4), (8, 0)][int(rng.integers(0, 3))]
+        w_max, per_simd = [(16, 4), (12, 4), (8, 0), (16, -1), (16, -2), (8, 4)][int(rng.integers(0, 6))]
         channels = int(rng.integers(1, 300))
         frames = int(rng.integers(1, 60_000_000))
         warm = int(rng.choice([0, 2048, 4096, 53248, 400*2048, 2**50*2048]))
@@ -143,6 +147,13 @@ def test_segment_planner_bench_configuration():
     # a short interactive slab is not cut below what the warm-up makes worthwhile
     length, count = segments(256, 16, 4, 200_000, 2, 53248)
     assert count*length >= 200_000 and length >= TILE
+    # the band-pass alone and the band-pass + envelope-state sweep fill the CU at configs[2]'s size: 16 waves = 64 segments
+    for model in (-1, -2):
+        length, count = segments(256, 16, model, 57_600_000, 64, 4096)
+        assert count == 64, model
+    # ... and do not shred a short slab into one-tile segments that mostly warm up (4 ch x 60 s x 48 kHz, warm-up 2 tiles)
+    length, count = segments(256, 16, -2, 2_880_000, 4, 4096)
+    assert length >= 2*TILE
     with pytest.raises(ValueError):
         segments(0, 16, 4, 10, 1, 0)
 

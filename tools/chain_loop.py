@@ -27,6 +27,10 @@ for i in range(n):
         hipdsp.chain_forward(ctx, fplan, eplan, dx, T, df, T, C, T, nfft, hop, rate, ds, nd)
     if which in ('bwd', 'both'):
         hipdsp.sosfilt_envelope(ctx, fplan, eplan, dx, T, df, T, de, T, C, T, phase=2)
+    if which == 'spec':                 # the stand-alone spectrogram kernel on the filtered trace
+        hipdsp.spectrogram(ctx, df, T, C, T, nfft, hop, rate, ds, nd)
+    if which == 'sosfilt':              # the stand-alone band-pass
+        hipdsp.sosfilt(ctx, fplan, dx, T, df, T, C, T, 0)
 ctx.synchronize()
 dt = time.perf_counter() - t0
 print(f'{which}: {n} rounds in {dt:.2f} s = {dt/n*1e3:.3f} ms each')
