@@ -205,6 +205,9 @@ int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value)
     if (strcmp(name, "pool_limit_mb") == 0) {
         HD_REQUIRE(value >= 0, "pool_limit_mb must be >= 0");
         ctx->pool->limit = (size_t)value << 20;
+        // a limit raised beyond the default also lifts the largest block that is cached (256 MiB by default: the
+        // big temporaries of a batch-sized hipdsp_envelope_multi cost a second of hipMalloc + hipFree per call otherwise)
+        ctx->pool->max_block = ctx->pool->limit > ((size_t)256 << 20) ? ctx->pool->limit : ((size_t)256 << 20);
         if (ctx->pool->cached_bytes > ctx->pool->limit) {
             HD_CHECK_HIP(hipStreamSynchronize(ctx->stream));
             pool_trim(ctx->pool);

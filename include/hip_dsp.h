@@ -65,7 +65,9 @@ int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
  *   "sos_waves_per_cu"   most resident waves per CU the IIR segment planner uses (16; see hipdsp_sos_segments_host);
  *                        "sos_waves_min" >= that: exactly that many (experiments); "chain_pairs" (8): most pairs of
  *                        waves per CU of the fused sweeps
- *   "pool_limit_mb"      bytes (MiB) hipdsp_free may keep cached for hipdsp_malloc (1024)
+ *   "pool_limit_mb"      bytes (MiB) hipdsp_free may keep cached for hipdsp_malloc (1024); blocks of up to 256 MiB are
+ *                        cached, with a larger limit blocks of up to the limit (hipdsp_envelope_multi takes two temporaries
+ *                        of the slab's size per call: at tens of GB raise this, or pay a hipMalloc + hipFree each call)
  *   "sos_prefetch"       0: envelope sweeps without the register prefetch of the next tile (1)
  *   "chain_split_frames" non-zero: hipdsp_chain_forward (2048/1024, no db_out) leaves the odd frames to hipdsp_chain_backward
  *   "chain_reserve_cus"  CUs hipdsp_chain_forward plans no workgroup for (0): its 1024-thread workgroups want a
@@ -127,7 +129,7 @@ int hipdsp_graph_destroy(hipdsp_ctx *ctx, hipdsp_graph *graph);
 
 /* ---- device memory helpers (so a non-torch host can keep stages resident) */
 
-/* hipdsp_free keeps blocks of up to 256 MiB in a per-context cache (at most "pool_limit_mb",
+/* hipdsp_free keeps blocks of up to 256 MiB (or "pool_limit_mb", if that is larger) in a per-context cache (at most "pool_limit_mb",
  * default 1024; 0 turns it off) and hipdsp_malloc hands them out again, because hipMalloc /
  * hipFree synchronise the device and an interactive redraw needs temporaries.  The cache is
  * stream-ordered: free a block through a context whose stream is behind all work on it (order

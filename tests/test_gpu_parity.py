@@ -1132,3 +1132,49 @@ def test_non_finite_samples_through_unwrap(oracle):
         assert np.array_equal(np.isnan(got), np.isnan(want)), clips
         ok = ~np.isnan(want)
         assert np.array_equal(got[ok], want[ok]), clips
+
+
+def test_pass_through_copy_any_skip_pitch_and_tail():
+    """BufferedFilter with sos None (the reference's DEFAULT session: cut-offs at 0 and Nyquist, bufferedfilter.py:32-33):
+    dest = source[nbefore:], bit for bit, for every alignment of skip, pitches and length (the copy moves four floats
+    per access with a scalar tail), nothing written past the row."""
+    from audian_amd import hipdsp
+    rng = np.random.default_rng(4)
+    c = gh.ctx()
+    for T, skip, xp_extra, yp_extra, C in [(1, 0, 0, 0, 1), (5, 2, 1, 3, 2), (4096, 1, 0, 0, 3), (4099, 3, 5, 7, 3), (100003, 50001, 2, 1, 4),
+                                           (8, 8, 0, 0, 2), (1 << 20, 7, 0, 1, 2)]:
+        xp, n = T + xp_extra, T - skip
+        yp = max(n, 1) + yp_extra
+        host = rng.standard_normal((C, xp)).astype(np.float32)
+        dx = hipdsp.DeviceArray(c, (C, xp), np.float32)
+        hipdsp.lib.hipdsp_memcpy_h2d(c.handle, hipdsp._p(dx), host.ctypes.data, host.nbytes)
+        dy = hipdsp.DeviceArray(c, (C, yp), np.float32)
+        hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(dy), 0x7f, 4*C*yp)
+        hipdsp.sosfilt(c, None, dx, xp, dy, yp, C, T, skip)
+        got = dy.to_host()
+        assert np.array_equal(got[:, :n], host[:, skip:T]), (T, skip)
+        assert np.all(got[:, n:].view(np.uint32) == 0x7f7f7f7f), (T, skip, 'wrote past the row')
+
+
+def test_decibel_any_length_and_alignment(oracle):
+    """hipdsp_decibel moves four values per access with a scalar tail: every length modulo 4, unaligned views, NaN and
+    the 1e-20 floor, nothing written past the end."""
+    from audian_amd import hipdsp
+    rng = np.random.default_rng(8)
+    c = gh.ctx()
+    for n, off in [(1, 0), (3, 1), (4, 0), (5, 3), (1023, 2), (4096, 1), (100001, 3)]:
+        p = (10.0**rng.uniform(-25, 3, size=n + off + 8)).astype(np.float32)
+        p[rng.integers(0, len(p), 3)] = 0.0
+        p[rng.integers(0, len(p))] = np.nan
+        dp = hipdsp.DeviceArray.from_host(c, p)
+        out = hipdsp.DeviceArray(c, (n + off + 8,), np.float32)
+        hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(out), 0x7f, 4*(n + off + 8))
+        hipdsp.decibel(c, dp.view(off, (n,)), out.view(off, (n,)), n)
+        got = out.to_host()
+        want = oracle.decibel(p[off:off + n].astype(np.float64))
+        assert np.array_equal(np.isnan(got[off:off + n]), np.isnan(want)), (n, off)
+        assert np.array_equal(np.isneginf(got[off:off + n]), np.isneginf(want)), (n, off)
+        fin = np.isfinite(want)
+        assert not fin.any() or np.max(np.abs(got[off:off + n][fin] - want[fin])) < 1e-3, (n, off)
+        rest = np.concatenate([got[:off], got[off + n:]])
+        assert np.all(rest.view(np.uint32) == 0x7f7f7f7f), (n, off)
