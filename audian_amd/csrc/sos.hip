@@ -809,35 +809,51 @@ __global__ __launch_bounds__(64 * WPB_, REGW ? 2 : 1) void env_bwd_kernel(const 
 // ext = odd extension of r = |x| (or x) by `edge` samples on both sides (scipy odd_ext,
 // scipy/signal/_arraytools.py:99-107), float32 arithmetic like the fused kernels; the gain of the rectified trace
 // rides on the first plan's cascade (SeqArgs::gain)
-__global__ void odd_ext_kernel(const float *__restrict__ x, long long x_pitch, long long T, int edge, int rectify,
-                               float *__restrict__ out, long long out_pitch)
+// (both: four values and ONE 16-byte access per thread, no loop -- the form that runs at the device's copy rate, see
+// copy_skip_kernel; f4u only needs 4-byte alignment, so `edge` may be anything)
+__global__ __launch_bounds__(256) void odd_ext_kernel(const float *__restrict__ x, long long x_pitch, long long T, int edge, int rectify,
+                                                      float *__restrict__ out, long long out_pitch)
 {
     const long long ch = blockIdx.y;
     const float *xc = x + ch * x_pitch;
     float *oc = out + ch * out_pitch;
     const long long N = T + 2LL * edge;
     auto r = [&](long long k) { const float v = xc[k]; return rectify ? fabsf(v) : v; };
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
+    const long long i = 4 * ((long long)blockIdx.x * 256 + threadIdx.x);
+    if (i >= N) return;
+    if (i >= edge && i + 4 <= edge + T) {                          // inside the trace: a straight (rectified) copy
+        f4u v = *reinterpret_cast<const f4u *>(xc + (i - edge));
+        if (rectify) { v.x = fabsf(v.x); v.y = fabsf(v.y); v.z = fabsf(v.z); v.w = fabsf(v.w); }
+        *reinterpret_cast<f4u *>(oc + i) = v;
+        return;
+    }
+    for (long long j = i; j < i + 4 && j < N; j++) {
         float v;
-        if (i < edge) v = 2.f * r(0) - r(edge - i);
-        else if (i < edge + T) v = r(i - edge);
-        else v = 2.f * r(T - 1) - r(T - 2 - (i - edge - T));
-        oc[i] = v;
+        if (j < edge) v = 2.f * r(0) - r(edge - j);
+        else if (j < edge + T) v = r(j - edge);
+        else v = 2.f * r(T - 1) - r(T - 2 - (j - edge - T));
+        oc[j] = v;
     }
 }
 
 // y[c][i] = x[c][N - 1 - (first + i)], i < n, optionally clamped at zero: time reversal (and the final trim)
-__global__ void flip_kernel(const float *__restrict__ x, long long x_pitch, long long N, long long first, long long n,
-                            int clamp, float *__restrict__ y, long long y_pitch)
+__global__ __launch_bounds__(256) void flip_kernel(const float *__restrict__ x, long long x_pitch, long long N, long long first, long long n,
+                                                   int clamp, float *__restrict__ y, long long y_pitch)
 {
     const long long ch = blockIdx.y;
     const float *xc = x + ch * x_pitch;
     float *yc = y + ch * y_pitch;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        float v = xc[N - 1 - (first + i)];
-        if (clamp && v < 0.f) v = 0.f;             // env[env < 0] = 0 (bufferedenvelope.py:41): NaN stays NaN, fmaxf would drop it
-        yc[i] = v;
+    // env[env < 0] = 0 (bufferedenvelope.py:41): NaN stays NaN, fmaxf would drop it
+    auto cl = [&](float v) { return (clamp && v < 0.f) ? 0.f : v; };
+    const long long i = 4 * ((long long)blockIdx.x * 256 + threadIdx.x);
+    if (i >= n) return;
+    if (i + 4 <= n) {
+        const f4u v = *reinterpret_cast<const f4u *>(xc + (N - 1 - (first + i) - 3));   // sources i+3, i+2, i+1, i
+        f4u o; o.x = cl(v.w); o.y = cl(v.z); o.z = cl(v.y); o.w = cl(v.x);
+        *reinterpret_cast<f4u *>(yc + i) = o;
+        return;
     }
+    for (long long j = i; j < n; j++) yc[j] = cl(xc[N - 1 - (first + j)]);
 }
 
 // ref[c] = x[c][0]
@@ -1200,7 +1216,8 @@ int hipdsp_envelope_multi(hipdsp_ctx *ctx, const hipdsp_sosplan *const *plans, i
         (void)hipdsp_free(ctx, ref);
     };
     if (rc != HIPDSP_OK) { cleanup(); return rc; }
-    const unsigned gx = (unsigned)((N + 1023) / 1024 > 4096 ? 4096 : (N + 1023) / 1024);
+    HD_REQUIRE((N + 1023) / 1024 <= 0x7fffffffLL, "grid too large");
+    const unsigned gx = (unsigned)((N + 1023) / 1024);            // 256 threads x 4 values per block, no loop
     const dim3 grid(gx, (unsigned)channels);
     hipLaunchKernelGGL(odd_ext_kernel, grid, dim3(256), 0, ctx->stream, x, (long long)x_pitch, (long long)frames, edge,
                        rectify, buf[0], N);
@@ -1228,7 +1245,7 @@ int hipdsp_envelope_multi(hipdsp_ctx *ctx, const hipdsp_sosplan *const *plans, i
         } else {
             // undo the reversal, drop the extensions and the first `skip` frames, clamp
             const long long n = frames - skip;
-            const unsigned gy = (unsigned)((n + 1023) / 1024 > 4096 ? 4096 : (n + 1023) / 1024);
+            const unsigned gy = (unsigned)((n + 1023) / 1024);
             hipLaunchKernelGGL(flip_kernel, dim3(gy, (unsigned)channels), dim3(256), 0, ctx->stream, buf[cur], N, N,
                                (long long)edge + (long long)skip, n, clamp, y, (long long)y_pitch);
         }
