@@ -1030,6 +1030,7 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     HD_REQUIRE(channels <= 65535, "more than 65535 channels");     // grid.y of the zero-tail launch
     HD_REQUIRE(x != nullptr && yf != nullptr && (psd != nullptr || frames_out == 0), "NULL data pointer");
     HD_REQUIRE(x_pitch >= frames && yf_pitch >= frames, "pitch smaller than row length");
+    HD_NO_OVERLAP(x, x_pitch, frames, yf, yf_pitch, frames, channels, "x and yf");
     const long long F = nfft / 2 + 1;
     if (psd_pitch == 0) psd_pitch = frames_out * F;
     HD_REQUIRE(psd_pitch >= frames_out * F, "psd_pitch smaller than one channel");
@@ -1197,6 +1198,7 @@ int hipdsp_chain_backward(hipdsp_ctx *ctx, const hipdsp_sosplan *eplan, const fl
     HD_REQUIRE(channels <= 65535, "more than 65535 channels");
     HD_REQUIRE(yf != nullptr && env != nullptr && (psd != nullptr || frames_out == 0), "NULL data pointer");
     HD_REQUIRE(yf_pitch >= frames && env_pitch >= frames, "pitch smaller than row length");
+    HD_NO_OVERLAP(yf, yf_pitch, frames, env, env_pitch, frames, channels, "yf and env");
     const long long F = nfft / 2 + 1;
     if (psd_pitch == 0) psd_pitch = frames_out * F;
     HD_REQUIRE(psd_pitch >= frames_out * F, "psd_pitch smaller than one channel");

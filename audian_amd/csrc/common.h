@@ -93,6 +93,19 @@ static inline int hd_launch_status(const char *what)
     return HIPDSP_OK;
 }
 
+// Do two planar float arrays (channels rows of `pitch` floats, `frames` used) share memory?  The sweeps are cut into
+// time segments that run concurrently and re-read their warm-up from the input: an output over the input is a race.
+static inline bool hd_planar_overlap(const float *a, long long a_pitch, long long a_frames, const float *b, long long b_pitch,
+                                     long long b_frames, long long channels)
+{
+    if (a == nullptr || b == nullptr || channels <= 0 || a_frames <= 0 || b_frames <= 0) return false;
+    const char *a0 = (const char *)a, *a1 = (const char *)(a + (channels - 1) * a_pitch + a_frames);
+    const char *b0 = (const char *)b, *b1 = (const char *)(b + (channels - 1) * b_pitch + b_frames);
+    return a0 < b1 && b0 < a1;
+}
+#define HD_NO_OVERLAP(a, ap, af, b, bp, bf, channels, what)                                             \
+    HD_REQUIRE(!hd_planar_overlap((a), (ap), (af), (b), (bp), (bf), (channels)), what " must not overlap")
+
 int hipdsp_scratch(hipdsp_ctx *ctx, size_t bytes, void **out);
 // tw2 | tw3 | twn | window of the three-stage PSD kernel, device memory (spectrogram.hip): served for nfft 2048
 // (radix 16 x 16 x 4), 1024 (8 x 8 x 8), 512 (8 x 8 x 4) and 256 (8 x 4 x 4) -- the sizes chain_fwd_kernel is built for

@@ -1125,6 +1125,7 @@ int hipdsp_sosfilt(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const float *x, 
     if (channels == 0 || frames - skip == 0) return HIPDSP_OK;
     HD_REQUIRE(x != nullptr && y != nullptr, "NULL data pointer");
     HD_REQUIRE(x_pitch >= frames && y_pitch >= frames - skip, "pitch smaller than row length");
+    HD_NO_OVERLAP(x, x_pitch, frames, y, y_pitch, frames - skip, channels, "x and y");
     HD_CHECK_HIP(hipSetDevice(ctx->device));
     if (plan == nullptr) {
         long long n = frames - skip;
@@ -1165,6 +1166,8 @@ int hipdsp_sosfilt_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const 
     if (channels == 0) return HIPDSP_OK;
     HD_REQUIRE(x != nullptr && yf != nullptr && env != nullptr, "NULL data pointer");
     HD_REQUIRE(x_pitch >= frames && yf_pitch >= frames && env_pitch >= frames, "pitch smaller than row length");
+    if (phase != 2) HD_NO_OVERLAP(x, x_pitch, frames, yf, yf_pitch, frames, channels, "x and yf");
+    if (phase != 1) HD_NO_OVERLAP(yf, yf_pitch, frames, env, env_pitch, frames, channels, "yf and env");
     return launch_env_ckpt(ctx, fplan->dev, eplan->dev, fplan->host->n_sections, eplan->host->n_sections,
                            fplan->host->warm, eplan->host->warm, edge, x, x_pitch, yf, yf_pitch, env, env_pitch,
                            channels, frames, 0, rectify, gain, clamp, phase);
@@ -1205,7 +1208,7 @@ int hipdsp_envelope_multi(hipdsp_ctx *ctx, const hipdsp_sosplan *const *plans, i
     if (channels == 0 || frames - skip == 0) return HIPDSP_OK;
     HD_REQUIRE(x != nullptr && y != nullptr, "NULL data pointer");
     HD_REQUIRE(x_pitch >= frames && y_pitch >= frames - skip, "pitch smaller than row length");
-    const long long N = frames + 2LL * edge;
+    const long long N = frames + 2LL * edge;                 // (x is fully consumed before y is written: they may overlap)
     float *buf[2] = {nullptr, nullptr}, *ref = nullptr;
     int rc = hipdsp_malloc(ctx, sizeof(float) * (size_t)N * (size_t)channels, (void **)&buf[0]);
     if (rc == HIPDSP_OK) rc = hipdsp_malloc(ctx, sizeof(float) * (size_t)N * (size_t)channels, (void **)&buf[1]);
@@ -1283,6 +1286,7 @@ int hipdsp_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const float *x,
     if (channels == 0) return HIPDSP_OK;
     HD_REQUIRE(x != nullptr && y != nullptr, "NULL data pointer");
     HD_REQUIRE(x_pitch >= frames && y_pitch >= frames - skip, "pitch smaller than row length");
+    HD_NO_OVERLAP(x, x_pitch, frames, y, y_pitch, frames - skip, channels, "x and y");
     return launch_env_ckpt(ctx, nullptr, plan->dev, 0, plan->host->n_sections, 0, plan->host->warm, edge, x,
                            x_pitch, nullptr, 0, y, y_pitch, channels, frames, skip, rectify, gain, clamp, 0);
 }

@@ -233,6 +233,10 @@ int hipdsp_sosplan_info(hipdsp_ctx *ctx, hipdsp_sosplan *plan, int64_t *warmup, 
  * is NaN everywhere (sosfiltfilt's backward pass starts from the NaN end); other channels are not affected.  The
  * time segments a sweep is cut into do not show (csrc/sos_device.h: FloodArgs). */
 
+/* Input and output of a sweep must not overlap (HIPDSP_ERR_INVALID): a sweep is cut into time segments that run
+ * concurrently and re-read their warm-up from the input -- the reference never filters in place either
+ * (dest is a view of the trace's own ring buffer).  hipdsp_envelope_multi copies its input first and may. */
+
 /* BufferedFilter.process (bufferedfilter.py:31-36):
  *   y[c, :] = sosfilt(sos, x[c, :])[skip:]      zero initial state, per channel.
  * x: (channels, x_pitch) with `frames` valid samples; y: (channels, y_pitch) with

@@ -237,6 +237,12 @@ def test_bad_arguments_are_refused_not_launched():
             lambda: hipdsp.decibel_image_decimate(c, s, y, 40, 129, 0, 41, 2),
             lambda: hipdsp.mean_spectrum_db(c, s, 129, 5, 5, y),                    # empty frame range
             lambda: hipdsp.decibel(c, x, y, 100, ref_power=0.0),
+            lambda: hipdsp.sosfilt(c, plan, x, 5000, x, 5000, 2, 5000, 0),          # in place: segments race with each other's warm-up
+            lambda: hipdsp.sosfilt(c, plan, x, 5000, x.view(4000, (1, 5000)), 5000, 1, 5000, 0),   # partial overlap
+            lambda: hipdsp.sosfilt(c, None, x, 5000, x, 5000, 2, 5000, 0),          # the pass-through copy too
+            lambda: hipdsp.envelope(c, plan, x, 5000, x, 5000, 2, 5000, 0),
+            lambda: hipdsp.sosfilt_envelope(c, plan, plan, x, 5000, x, 5000, y, 5000, 2, 5000),
+            lambda: hipdsp.sosfilt_envelope(c, plan, plan, x, 5000, y, 5000, y, 5000, 2, 5000),
     ):
         with pytest.raises((ValueError, IndexError)):
             call()
