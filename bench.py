@@ -14,6 +14,7 @@ HBM.  --config picks the BASELINE.json workload:
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...        (no launcher: bench.py starts its own N ranks, see self_launch())
 
 Rank 0 prints ONE JSON line: whole-job Msamples/s, the HBM roofline of the dominant
 kernel (HIP-event timed inside the timed region) and, at N=1, the reference's scipy
@@ -109,6 +110,10 @@ def parse():
                          'separate launches')
     ap.add_argument('--force-dist', action='store_true',
                     help='rehearsal: take the multi-rank code path even with one rank')
+    ap.add_argument('--rendezvous-only', action='store_true',
+                    help='launcher check without a GPU: every rank joins a gloo process group, one all-reduce, rank 0 '
+                         'prints a JSON line with the world size it saw -- tests/test_bench_contract.py uses it to '
+                         'cover the self-launch of --gpus N on the CPU')
     ap.add_argument('--no-facade', action='store_true',
                     help='N=1: skip the leg (outside the timed region) that runs the same slab through the drop-in '
                          'surface -- ArrayLoader -> BufferedFilter.update() -> recompute_all() -- and reports '
@@ -468,8 +473,69 @@ class AbiGather:
         self.gctx.pool_trim()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves.  This process has not
+    imported torch nor touched HIP (a process that has initialised the GPU must not be replaced or forked into
+    ranks); it starts `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD --
+    fresh processes, one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set by the launcher, rendezvous on
+    127.0.0.1 at a port that is free now -- forwards rank 0's single JSON line to its own stdout and exits with the
+    children's worst return code (no line counts as a failure)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')         # dmabuf IPC: the only kind this pool's driver has
+    env.setdefault('OMP_NUM_THREADS', '1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('bench.py: --gpus %d without a launcher: starting %d ranks (%s)' % (args.gpus, args.gpus, ' '.join(cmd[1:8])),
+          file=sys.stderr)
+    sys.stderr.flush()
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)        # (stderr goes where ours goes)
+    out = proc.communicate()[0].decode(errors='replace')
+    rc = proc.returncode
+    lines = [ln for ln in out.splitlines() if ln.startswith('{') and ln.rstrip().endswith('}')]
+    for ln in out.splitlines():
+        if ln not in lines[-1:]:
+            print(ln, file=sys.stderr)                       # whatever else a rank wrote to stdout
+    if lines:
+        sys.stdout.write(lines[-1] + '\n')
+        sys.stdout.flush()
+    elif rc == 0:
+        rc = 1
+    # a signal-killed launcher has a negative return code; the driver wants non-zero, not a wrapped value
+    sys.exit(rc if 0 <= rc < 256 else 1)
+
+
+def rendezvous_only(args):
+    """--rendezvous-only: the launcher plumbing without a GPU (gloo)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29534')
+    os.environ.setdefault('RANK', '0')
+    os.environ.setdefault('WORLD_SIZE', '1')
+    if os.environ.get('BENCH_RENDEZVOUS_FAIL_RANK') == os.environ['RANK']:
+        sys.exit(3)                                          # test hook: a rank that dies before the rendezvous
+    dist.init_process_group('gloo')
+    t = torch.ones(1, dtype=torch.float64)*(dist.get_rank() + 1)
+    dist.all_reduce(t)
+    dist.barrier()
+    if dist.get_rank() == 0:
+        print(json.dumps({'rendezvous_only': True, 'n_gpus': world, 'gpus_flag': args.gpus,
+                          'rank_sum': float(t.item())}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        self_launch(args)                                    # does not return
+    if args.rendezvous_only:
+        return rendezvous_only(args)
     # stdout carries exactly ONE line, the JSON result: whatever libraries print on the way (RCCL
     # writes a version banner to stdout when its communicator comes up) goes to stderr instead
     sys.stdout.flush()
@@ -480,11 +546,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus N > 1 must be launched with torch.distributed.run '
-                     '(one rank per GPU)')
-        args.gpus = world
+    args.gpus = world        # under a launcher its WORLD_SIZE is authoritative (without one, self_launch() above)
 
     dist = None
     torch = None

@@ -45,13 +45,43 @@ def test_flags_and_defaults():
         assert flag in out.stdout
 
 
-def test_n_gt_1_needs_a_launcher():
+def _no_launcher_env():
     env = dict(os.environ)
-    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'LOCAL_WORLD_SIZE', 'GROUP_RANK'):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True,
-                         text=True, env=env)
-    assert out.returncode != 0 and 'torch.distributed.run' in (out.stderr + out.stdout)
+    return env
+
+
+def test_n_gt_1_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus N` as the driver's N = 1 command is shaped: the parent starts N fresh ranks before
+    anything touches the GPU, forwards rank 0's single JSON line and nothing else (here: the gloo rendezvous check,
+    no GPU needed)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '3', '--rendezvous-only'],
+                         capture_output=True, text=True, env=_no_launcher_env(), timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1, out.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d == {'rendezvous_only': True, 'n_gpus': 3, 'gpus_flag': 3, 'rank_sum': 6.0}
+    assert 'starting 3 ranks' in out.stderr
+
+
+def test_self_launch_passes_the_ranks_failure_on():
+    """A rank that dies makes the parent exit non-zero without a JSON line on stdout."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rendezvous-only'],
+                         capture_output=True, text=True, env=dict(_no_launcher_env(), BENCH_RENDEZVOUS_FAIL_RANK='1'),
+                         timeout=300)
+    assert out.returncode != 0 and out.stdout.strip() == '' and 'starting 2 ranks' in out.stderr
+
+
+def test_under_a_launcher_world_size_wins():
+    """Started by torch.distributed.run (WORLD_SIZE set) bench.py does not launch again."""
+    env = dict(_no_launcher_env(), RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1',
+               MASTER_PORT='29579')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--rendezvous-only'],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads(out.stdout.splitlines()[-1])['n_gpus'] == 1 and 'starting' not in out.stderr
 
 
 @pytest.mark.gpu
@@ -124,6 +154,48 @@ def test_configs3_rehearsal_through_the_c_abi_gather():
     assert d['config']['channels_per_gpu'] == 32 and 'configs[3]' in d['config']['workload']
     assert 'c-abi' in d['config']['parallelism'] and '8 CUs left to RCCL' in d['config']['parallelism']
     assert d['legs']['tile_in_timed_region'] == 'window' and d['parity_max_rel_err'] < 1e-4 and 'invalid' not in d
+
+
+@pytest.mark.gpu
+def test_configs3_shard_at_full_size():
+    """BASELINE configs[3] at the size it states: one rank's shard of 256 ch x 600 s x 96 kHz over 8 GPUs = 32 channels
+    x 57.6 M frames, the multi-rank code path (non-default streams, CUs left to RCCL, the window tile of SURVEY 8e
+    all-gathered through the C ABI every step) with the one rank a one-GPU box has.  bench.py's parity subset compares
+    the first 2 s of channels {0, 16, 31}, a window at an internal segment border of the fused plan and the last 2 s
+    of the last channel with the oracle (filtered trace, envelope, every PSD frame)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--force-dist', '--config', '3', '--steps',
+                          '2', '--warmup', '1', '--no-cpu-baseline', '--gather', 'c-abi', '--tile', 'window'],
+                         capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29581'))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1, out.stdout[:2000]
+    d = json.loads(lines[0])
+    assert 'configs[3]' in d['config']['workload'] and '32 ch/GPU x 600 s x 96 kHz' in d['config']['workload']
+    assert d['config']['channels_per_gpu'] == 32 and d['config']['frames'] == 57600000
+    assert d['config']['spectrogram_frames'] == 56250
+    assert 'c-abi' in d['config']['parallelism'] and '8 CUs left to RCCL' in d['config']['parallelism']
+    assert d['legs']['tile_in_timed_region'] == 'window' and abs(d['legs']['tile_GB_per_rank'] - 0.984) < 0.01
+    assert d['parity_max_rel_err'] < 1e-4 and 'invalid' not in d
+    assert d['roofline']['kernel'].startswith('chain_fwd')
+    assert 0 < d['compute_ms'] <= d['ms_per_step']*1.05
+
+
+@pytest.mark.gpu
+def test_gpus_2_without_a_launcher_on_one_gpu():
+    """The driver's scaling command in the shape of its N = 1 command -- `python bench.py --gpus 2 ...` with no
+    launcher around it -- starts two ranks itself; here both on GPU 0 with gloo as the collective backend (a one-GPU
+    box), so the whole N > 1 path runs: rendezvous, channel shard, tile gather, max over ranks, ONE line."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo',
+                          '--same-device', '--seconds', '20', '--channels', '8', '--steps', '2', '--warmup', '1',
+                          '--no-legs'], capture_output=True, text=True, timeout=900, env=_no_launcher_env())
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1, out.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['channels_per_gpu'] == 8
+    assert d['parity_max_rel_err'] < 1e-4 and 'invalid' not in d
+    assert abs(d['value'] - 2*8*20*96000/(d['ms_per_step']*1e-3)/1e6) < 1e-6*d['value']
 
 
 @pytest.mark.gpu
