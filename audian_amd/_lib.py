@@ -109,8 +109,9 @@ _SIGNATURES = {
     'hipdsp_sosfilt': ([_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64], _int),
     'hipdsp_envelope': ([_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _dbl, _int], _int),
     'hipdsp_envelope_multi': ([_vp, _vp, _int, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _dbl, _int], _int),
-    'hipdsp_sosfilt_envelope': ([_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _int, _dbl, _int, _int], _int),
-    'hipdsp_chain_forward': ([_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _int, _dbl, _int, _int, _dbl, _vp, _vp, _i64, _i64, _i64], _int),
+    'hipdsp_sosfilt_envelope': ([_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _int, _dbl, _int, _int, _i64], _int),
+    'hipdsp_chain_forward': ([_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _int, _dbl, _int, _int, _dbl, _vp, _vp, _i64, _i64, _i64,
+                              _i64, _i64], _int),
     'hipdsp_chain_backward': ([_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _int, _dbl, _int, _int, _int, _dbl, _vp, _i64, _i64], _int),
     'hipdsp_chain_backward_plan': ([_vp, _vp, _i64, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_int)], _int),
     'hipdsp_chain_plan': ([_vp, _vp, _vp, _i64, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_int)], _int),

@@ -29,20 +29,24 @@ class BufferedEnvelope(BufferedData):
         self.update()
 
     def _fusable_with(self, filt):
-        """True if this envelope's whole-buffer recompute is exactly what the filter's fused launch
-        computes (BufferedFilter._plan_fusion): one plan of at most two decaying sections, over the very
-        frames the filter produces (same offset and length: no pre-roll trimmed)."""
+        """The sample of the filtered buffer this envelope starts at if its whole-buffer recompute is what the
+        filter's fused launch can compute (BufferedFilter._plan_fusion), else None: one plan of at most two
+        decaying sections over the filtered frames from that sample to the buffer's end.  At the start of a
+        recording that is sample 0; after a scroll align_buffer trims the envelope's second of pre-roll
+        (buffereddata.py:75-88) and the reference's sosfiltfilt pads and starts there: the launch's env_first."""
         if not self._builtin(BufferedEnvelope) or self.sos is None or self._plans or self._plan is None or \
            len(self.sos) > 2:
-            return False
+            return None
         warm, edge = self._plan.info()
         if warm >= 1 << 40:
-            return False
+            return None
         if len(filt._hostbuf) > 0:
             self.allocate_buffer()               # what recompute() does first
         n = len(self._hostbuf)
-        first, count, lead = self._load_geometry(self.offset, n) if n > 0 else (1, 0, 0)
-        return first == 0 and lead == 0 and count == len(filt._hostbuf) and n == count and count > edge
+        first, count, lead = self._load_geometry(self.offset, n) if n > 0 else (-1, 0, 0)
+        if first < 0 or lead != 0 or first + count != len(filt._hostbuf) or n != count or count <= edge:
+            return None
+        return first
 
     def process(self, source, dest, nbefore):
         """dest = sosfiltfilt(sos, (pi/2)|source|, axis=0)[nbefore:], negatives clamped to

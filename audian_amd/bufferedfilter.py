@@ -96,11 +96,12 @@ class BufferedFilter(BufferedData):
     def _plan_fusion(self):
         """Which of the traces derived from this one can be computed by the filter's own launch:
         a spectrogram whose frames the fused forward sweep covers (hipdsp_chain_forward) and/or an
-        envelope of at most two sections over the same frames (its state sweep rides along, the
-        backward sweep follows).  None when there is nothing to fuse; everything else -- no filter,
-        a cascade longer than one plan, short buffers, other windows, an envelope that starts later
-        than the filtered buffer (pre-roll trimmed after a scroll), subclasses with their own
-        process() -- keeps the separate process() calls of the dependency walk."""
+        envelope of at most two sections over the filtered frames up to the buffer's end (its state
+        sweep rides along, the backward sweep follows) -- wherever the user has scrolled to: the
+        spectrogram's first frame and the envelope (pre-roll trimmed after a scroll) may start anywhere
+        inside the filtered buffer (spec_first / env_first).  None when there is nothing to fuse;
+        everything else -- no filter, a cascade longer than one plan, short buffers, other windows,
+        subclasses with their own process() -- keeps the separate process() calls of the dependency walk."""
         from .bufferedspectrogram import BufferedSpectrogram
         from .bufferedenvelope import BufferedEnvelope
         if not self._builtin(BufferedFilter) or self.sos is None or len(self._plans) != 1:
@@ -120,8 +121,9 @@ class BufferedFilter(BufferedData):
                 if geom is not None:
                     spec = (dest, geom)
             elif env is None and isinstance(dest, BufferedEnvelope):
-                if dest._fusable_with(self):
-                    env = dest
+                env_first = dest._fusable_with(self)
+                if env_first is not None:
+                    env = (dest, env_first)
         if spec is None and env is None:
             return None
         return {'spec': spec, 'env': env, 'done': False}
@@ -131,22 +133,26 @@ class BufferedFilter(BufferedData):
         from . import hipdsp
         plan = self._plans[0]
         spec, env = fuse['spec'], fuse['env']
+        env, env_first = env if env is not None else (None, 0)
         eplan = env._plan if env is not None else None
         edev = env._mirror() if env is not None else None
         clamp = env is not None and env.highpass_cutoff == 0
         try:
             if spec is not None:
-                trace, (nd, spec_frames) = spec
+                trace, (nd, spec_first, spec_frames) = spec
                 F = trace.nfft//2 + 1
                 hipdsp.chain_forward(self.ctx, plan, eplan, dsrc, spitch, ddst, dpitch, self.channels, ns,
                                      trace.nfft, trace.hop, self.rate, trace._mirror(), nd, psd_pitch=nd*F,
-                                     rectify=True, gain=np.pi/2, spec_frames=spec_frames)
+                                     rectify=True, gain=np.pi/2, spec_frames=spec_frames, spec_first=spec_first,
+                                     env_first=env_first)
                 if env is not None:
-                    hipdsp.sosfilt_envelope(self.ctx, plan, eplan, dsrc, spitch, ddst, dpitch, edev, ns,
-                                            self.channels, ns, rectify=True, gain=np.pi/2, clamp=clamp, phase=2)
+                    hipdsp.sosfilt_envelope(self.ctx, plan, eplan, dsrc, spitch, ddst, dpitch, edev, ns - env_first,
+                                            self.channels, ns, rectify=True, gain=np.pi/2, clamp=clamp, phase=2,
+                                            env_first=env_first)
             else:
-                hipdsp.sosfilt_envelope(self.ctx, plan, eplan, dsrc, spitch, ddst, dpitch, edev, ns,
-                                        self.channels, ns, rectify=True, gain=np.pi/2, clamp=clamp, phase=0)
+                hipdsp.sosfilt_envelope(self.ctx, plan, eplan, dsrc, spitch, ddst, dpitch, edev, ns - env_first,
+                                        self.channels, ns, rectify=True, gain=np.pi/2, clamp=clamp, phase=0,
+                                        env_first=env_first)
         except NotImplementedError:
             return False
         if spec is not None:

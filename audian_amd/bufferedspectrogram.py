@@ -67,9 +67,11 @@ class BufferedSpectrogram(BufferedData):
         self.ampl_min, self.ampl_max = 0, 0.5*self.source.rate
 
     def _fusable_with(self, filt):
-        """(frames, source samples) of this spectrogram's whole-buffer recompute if the filter's fused
-        forward sweep can write it (BufferedFilter._plan_fusion), else None: the window must be one of the
-        sweep's and the first frame must start at the first sample of the filtered buffer."""
+        """(frames, first source sample, source samples) of this spectrogram's whole-buffer recompute if the
+        filter's fused forward sweep can write it (BufferedFilter._plan_fusion), else None: the window must be
+        one of the sweep's.  After a scroll the filtered buffer starts at an arbitrary sample of the recording and
+        frame 0 `first` = ceil(offset / hop) hop - offset samples into it (align_buffer, buffereddata.py:75-88):
+        the sweep shifts its tile grid by that (hipdsp_chain_forward's spec_first)."""
         if not self._builtin(BufferedSpectrogram) or (self.nfft, self.hop) not in FUSED_WINDOWS:
             return None
         if len(filt._hostbuf) > 0:
@@ -78,9 +80,9 @@ class BufferedSpectrogram(BufferedData):
         if nd == 0:
             return None
         first, count, lead = self._load_geometry(self.offset, nd)
-        if first != 0 or lead != 0 or count <= 0:
+        if first < 0 or lead != 0 or count <= 0 or first + count > len(filt._hostbuf):
             return None
-        return nd, count
+        return nd, first, count
 
     def process(self, source, dest, nbefore):
         """dest[k, c, :] = one-sided PSD of source[k*hop : k*hop + nfft, c]; frames that do

@@ -49,6 +49,7 @@ struct ChainArgs {
     int split;                // frame split: only the even frames are written here, chain_bwd_kernel writes the odd ones
     long long unit_stride;    // 0: unit = block * NP + pair; else unit = pair * unit_stride + block -- fewer units than the
                               // chip has pairs are spread over all CUs, the pairs of a workgroup that get none idle
+    int frame_off;            // frame k of psd / db is frame k + frame_off of the sweep's grid (sos_device.h: GridShift)
 };
 
 // One frame of NFFT samples per group of LPF lanes (2048: LPF 64, radix 16 x 16 x 4; 1024: 64, 8 x 8 x 8; 512: two
@@ -247,10 +248,14 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
     long long hi = lo + a.c.seg_len;
     const bool last_seg = hi >= T;
     if (hi > T) hi = T;
-    // no envelope warm-up: zero-state tile states + env_fix_kernel, exactly as in sos_ckpt_kernel
-    const long long env_start = lo;
-    const bool env_true = seg == 0;
-    long long start = env_start - PF0->warm;
+    // no envelope warm-up: zero-state tile states + env_fix_kernel, exactly as in sos_ckpt_kernel.  The envelope
+    // starts at p' = env0 (sos_device.h: GridShift): the unit whose range holds that tile starts it from the true
+    // state there, units in front of it have no envelope work, units behind it start from zero state at `lo`.
+    const long long lead = a.c.lead;
+    const long long env_tile0 = a.c.env0 - a.c.env0 % TILE;
+    const bool env_true = lo <= env_tile0 && env_tile0 < hi;
+    const long long env_start = env_true ? env_tile0 : (lo > env_tile0 ? lo : (1LL << 62));
+    long long start = lo - PF0->warm;
     if (start < 0) start = 0;
     long long loop_end = last_seg ? T + edge : hi;
     if (!unit_ok) loop_end = start;                     // a pair without a unit only takes the barriers
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             for (int k = 0; k < 8; k++) nx[k] = asm_load16(in + t0 + 256 * k + 4 * lane);
         };
         // what iteration k + 1 will read: its tile if that is a full tile of this unit, else a dummy
-        auto prefetchable = [&](long long t0) { return t0 >= start && t0 < loop_end && t0 + TILE <= T; };
+        auto prefetchable = [&](long long t0) { return t0 >= start && t0 < loop_end && t0 + TILE <= T && t0 >= lead; };
         pre = prefetchable(base);
         fetch(pre ? base : top_full);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -315,19 +320,22 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                         lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = make_float4(nx[k].x, nx[k].y, nx[k].z, nx[k].w);
                     }
                 } else {
-                    // a tile that reaches past T: untracked loads from clamped addresses, zeros past T
+                    // a tile that reaches past T (or holds the `lead` samples in front of the trace): untracked loads
+                    // from clamped addresses, zeros outside [lead, T)
 #pragma unroll 1
                     for (int k = 0; k < 8; k++) {
                         const long long p = tile + 256 * k + 4 * lane;
+                        auto at = [&](long long q) { return in + (q < lead ? lead : (q < T ? q : T - 1)); };
+                        auto ok = [&](long long q) { return q >= lead && q < T; };
                         v4f t;
-                        t.x = asm_load4(in + (p < T ? p : T - 1));
-                        t.y = asm_load4(in + (p + 1 < T ? p + 1 : T - 1));
-                        t.z = asm_load4(in + (p + 2 < T ? p + 2 : T - 1));
-                        t.w = asm_load4(in + (p + 3 < T ? p + 3 : T - 1));
+                        t.x = asm_load4(at(p));
+                        t.y = asm_load4(at(p + 1));
+                        t.z = asm_load4(at(p + 2));
+                        t.w = asm_load4(at(p + 3));
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         asm volatile("" : "+v"(t));
                         lds[lds_slot(8 * k + (lane >> 3), lane & 7)] =
-                            make_float4(p < T ? t.x : 0.f, p + 1 < T ? t.y : 0.f, p + 2 < T ? t.z : 0.f, p + 3 < T ? t.w : 0.f);
+                            make_float4(ok(p) ? t.x : 0.f, ok(p + 1) ? t.y : 0.f, ok(p + 2) ? t.z : 0.f, ok(p + 3) ? t.w : 0.f);
                     }
                 }
             }
@@ -382,7 +390,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             WAVE_SYNC();
             if (FLAGS) { if (active) CHAIN_POST(ready, it + 1); }
             else __syncthreads();                              // B1: the tile holds the filtered samples
-            if (active && tile >= lo && tile + TILE <= hi) {
+            if (active && tile >= lo && tile + TILE <= hi && tile >= lead) {
                 // interior tile: exactly 8 vector stores, then the counted wait
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
@@ -397,7 +405,8 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                 if (active && tile + TILE > lo && tile < hi) {
 #pragma unroll
                     for (int k = 0; k < 8; k++)
-                        store_four(yf, tile + 256 * k + 4 * lane, lds[lds_slot(8 * k + (lane >> 3), lane & 7)], lo, hi, 0);
+                        store_four(yf, tile + 256 * k + 4 * lane, lds[lds_slot(8 * k + (lane >> 3), lane & 7)],
+                                   lo > lead ? lo : lead, hi, 0);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -408,10 +417,10 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             // to the next segment by env_fix_kernel)
             const bool last_tile = tile + TILE >= loop_end;
             const bool quiet = SE > 0 && active && tile >= env_start && a.c.rectify && tile + 2 * TILE <= T &&
-                               !(env_true && tile == 0) && (!last_tile || !last_seg) && !(a.debug & 2);
+                               !(env_true && tile == env_start) && (!last_tile || !last_seg) && !(a.debug & 2);
             if (FLAGS) {
                 if (active) {
-                    if (quiet || SE == 0) pending = it + 1;
+                    if (quiet || SE == 0 || tile < env_start) pending = it + 1;   // (nothing touches the tile before the next one)
                     else CHAIN_WAIT_FOR(taken, it + 1, it);
                 }
             } else {
@@ -419,7 +428,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             }
             if constexpr (SE > 0) {
             if (quiet) {
-                if ((tile > lo || env_true) && lane == 0) {
+                if ((tile > lo || env_true) && lane == 0) {     // (quiet: never the envelope's first tile)
 #pragma unroll
                     for (int r = 0; r < DE; r++) ckpt[(tile / TILE) * DE + r] = ce_[r];
                 }
@@ -470,7 +479,19 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                     if (lane < edge && pj >= tile && pj < tile + TILE) ldsf[lds_float_index((int)(pj - tile))] = pv;
                     WAVE_SYNC();
                 }
-                if (env_true && tile == 0) {
+                if (env_true && tile == env_start && a.c.env0 > 0) {
+                    // the envelope starts inside this tile, at q = env0 - tile (host: edge <= q < TILE - edge): scipy's
+                    // left odd extension ext[i] = 2 r(q) - r(q + edge - i), i < edge, goes into the edge samples in
+                    // front of q, and everything in front of THAT becomes ext[0] -- a constant input for which
+                    // zi * ext[0], the state sosfiltfilt starts from, is the cascade's steady state: the tile is then
+                    // scanned like any other and the state arrives at q as if the cascade had started at q - edge.
+                    // The backward sweep rebuilds exactly this tile from the filtered trace (env_left_fill).
+                    const SosPlanDev *Pz = PLAN_OF(PE0);
+                    const float e0 = env_left_fill(ldsf, lane, (int)(a.c.env0 - tile), edge);
+                    const double x0 = a.c.gain * (double)e0;
+#pragma unroll
+                    for (int r = 0; r < DE; r++) ce_[r] = Pz->zi[r] * x0;
+                } else if (env_true && tile == env_start) {
                     const SosPlanDev *Pz = PLAN_OF(PE0);
                     const double r0 = (double)ldsf[lds_float_index(0)];
                     const double x0 = a.c.gain * (2.0 * r0 - (double)ldsf[lds_float_index(edge)]);
@@ -608,7 +629,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         // lane group gq: frame m = 4 gq + q of the tile = its blocks q and q + 1
-                        const long long f = t * FPT + 4 * gq + q + 1 - NFFT / HOP;
+                        const long long f = t * FPT + 4 * gq + q + 1 - NFFT / HOP - a.frame_off;
                         const bool keep = (4 * gq + q > 0 || have_prev) && f >= 0 && f < a.n_valid;
                         if (__builtin_amdgcn_ballot_w64(keep) != 0) {               // (wave-uniform: some group has a frame)
                             v2f w[8];
@@ -625,7 +646,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                         const int j0 = ((m + 1) * HOP - NFFT) / 128;          // compile-time after unrolling
                         auto reg = [&](int j) -> v2f { return j < 0 ? prv_[(PREV + j) < 0 ? 0 : (PREV + j)] : cur_[j < 0 ? 0 : j]; };
                         if constexpr (G == 1) {
-                            const long long f = t * FPT + m + 1 - NFFT / HOP;
+                            const long long f = t * FPT + m + 1 - NFFT / HOP - a.frame_off;
                             if ((j0 >= 0 || have_prev) && f >= 0 && f < a.n_valid && !(a.split && (f & 1))) {
                                 v2f w[PPL];
 #pragma unroll
@@ -647,10 +668,10 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                             // frame, lower (t even) or upper (t odd) half of the wave: v_permlane32_swap of the two frames'
                             // registers gives {X.lo | Y.lo} and {X.hi | Y.hi} in one instruction per dword.
                             const int gq = lane / LPF;
-                            const long long f = t * FPT + m + gq + 1 - NFFT / HOP;
+                            const long long f = t * FPT + m + gq + 1 - NFFT / HOP - a.frame_off;
                             const bool ok0 = (j0 >= 0 || have_prev), ok1 = (j0 + HOP / 128 >= 0 || have_prev);
                             const bool keep = (gq == 0 ? ok0 : ok1) && f >= 0 && f < a.n_valid;
-                            const long long fa = t * FPT + m + 1 - NFFT / HOP;
+                            const long long fa = t * FPT + m + 1 - NFFT / HOP - a.frame_off;
                             if ((ok0 && fa >= 0 && fa < a.n_valid) || (ok1 && fa + 1 >= 0 && fa + 1 < a.n_valid)) {
                                 v2f w[2 * PPL];
 #pragma unroll
@@ -1001,12 +1022,17 @@ extern "C" {
 int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hipdsp_sosplan *eplan,
                          const float *x, int64_t x_pitch, float *yf, int64_t yf_pitch, int64_t channels,
                          int64_t frames, int rectify, double gain, int nfft, int hop, double fs, float *psd,
-                         float *db_out, int64_t frames_out, int64_t psd_pitch, int64_t spec_frames)
+                         float *db_out, int64_t frames_out, int64_t psd_pitch, int64_t spec_frames,
+                         int64_t spec_first, int64_t env_first)
 {
     HD_REQUIRE(ctx != nullptr && fplan != nullptr, "NULL argument");
     HD_REQUIRE(channels >= 0 && frames >= 0 && frames_out >= 0, "negative size");
-    HD_REQUIRE(spec_frames >= 0 && spec_frames <= frames, "spec_frames %lld not in [0, frames=%lld]",
-               (long long)spec_frames, (long long)frames);
+    HD_REQUIRE(spec_first >= 0 && spec_first <= frames, "spec_first %lld not in [0, frames=%lld]", (long long)spec_first,
+               (long long)frames);
+    HD_REQUIRE(spec_frames >= 0 && spec_first + spec_frames <= frames, "spec_first %lld + spec_frames %lld beyond frames=%lld",
+               (long long)spec_first, (long long)spec_frames, (long long)frames);
+    HD_REQUIRE(env_first >= 0 && env_first <= frames, "env_first %lld not in [0, frames=%lld]", (long long)env_first,
+               (long long)frames);
     HD_REQUIRE(fs > 0, "fs must be positive");
     const int SF = fplan->host->n_sections, SE = eplan ? eplan->host->n_sections : 0;
     HD_REQUIRE(SF > 0 && (SE > 0 || eplan == nullptr), "plan has no coefficients");
@@ -1026,6 +1052,10 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
         if (frc != HIPDSP_OK) return frc;
     }
     const int edge = eplan ? eplan->host->edge : 0;
+    if (eplan && frames - env_first <= edge) {
+        hipdsp_set_error("The length of the input vector x must be greater than padlen, which is %d.", edge);
+        return HIPDSP_ERR_TOO_SHORT;
+    }
     if (channels == 0) return HIPDSP_OK;
     HD_REQUIRE(channels <= 65535, "more than 65535 channels");     // grid.y of the zero-tail launch
     HD_REQUIRE(x != nullptr && yf != nullptr && (psd != nullptr || frames_out == 0), "NULL data pointer");
@@ -1036,7 +1066,7 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     HD_REQUIRE(psd_pitch >= frames_out * F, "psd_pitch smaller than one channel");
     // frames inside the trace, as in hipdsp_spectrogram (bufferedspectrogram.py:46-49); the spectrogram may be
     // handed fewer samples than the filter produces (spec_frames: BufferedData.load_buffer's one frame "after")
-    const long long sframes = spec_frames > 0 ? spec_frames : frames;
+    const long long sframes = spec_frames > 0 ? spec_frames : frames - spec_first;
     long long nsource = (frames_out - 1) * (long long)hop + nfft;
     if (nsource > sframes) nsource = sframes;
     long long n_valid = 0;
@@ -1051,25 +1081,32 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     memset(&a, 0, sizeof(a));
     int rc = hd_fft_tables(ctx, nfft, &a.tables);
     if (rc != HIPDSP_OK) return rc;
-    const long long n_tiles = (frames + edge + TILE - 1) / TILE;
+    // the sweep's tile grid: frame 0 of the spectrogram and the envelope's first sample wherever the caller has
+    // scrolled to (sos_device.h: GridShift) -- the kernel walks T = frames + lead samples, x and yf shifted by -lead
+    const GridShift gs = hd_grid_shift(spec_first, env_first, hop, edge, SE > 0);
+    HD_REQUIRE(gs.lead < TILE, "grid shift %lld", gs.lead);
+    const long long T = frames + gs.lead;
+    const long long n_tiles = (T + edge + TILE - 1) / TILE;
     const long long ckpt_pitch = (n_tiles + 1) * 2 * SE;           // the layout the backward sweep expects
     void *work = nullptr;
     if (SE > 0) {
         rc = hipdsp_scratch(ctx, sizeof(double) * (size_t)ckpt_pitch * (size_t)channels, &work);
         if (rc != HIPDSP_OK) return rc;
     }
-    a.c.in = x; a.c.yf = yf; a.c.ckpt = (double *)work;
+    hd_note_sweep(ctx, gs.lead, gs.env0, frames, channels, SE);    // what a backward sweep (phase 2) must agree with
+    a.c.in = x - gs.lead; a.c.yf = yf - gs.lead; a.c.ckpt = (double *)work;
     a.c.in_pitch = x_pitch; a.c.yf_pitch = yf_pitch; a.c.ckpt_pitch = ckpt_pitch;
-    a.c.T = frames; a.c.edge = edge; a.c.rectify = rectify; a.c.gain = rectify ? gain : 1.0;
+    a.c.T = T; a.c.edge = edge; a.c.rectify = rectify; a.c.gain = rectify ? gain : 1.0;
+    a.c.lead = gs.lead; a.c.env0 = gs.env0; a.frame_off = gs.frame_off;
     a.psd = psd; a.db = db_out; a.psd_pitch = psd_pitch; a.n_valid = n_valid;
     a.scale = (float)(1.0 / (fs * wss));
     a.warm_total = fplan->host->warm;              // the envelope's states are handed over exactly (env_fix_kernel)
     a.debug = ctx->chain_debug;
     a.fault = ctx->fault_dev;
-    a.split = (ctx->chain_split_frames && nfft == 2048 && hop == 1024 && !db_out) ? 1 : 0;
+    a.split = (ctx->chain_split_frames && nfft == 2048 && hop == 1024 && !db_out && gs.lead == 0 && gs.env0 == 0) ? 1 : 0;
     constexpr int P = 8;                                           // IIR waves (and FFT waves) per workgroup, one per CU
     // (hipdsp_chain_plan reports exactly this segmentation)
-    plan_segments_chain(ctx, frames, channels, a.warm_total, &a.c.seg_len, &a.c.n_seg);
+    plan_segments_chain(ctx, T, channels, a.warm_total, &a.c.seg_len, &a.c.n_seg);
     a.units = channels * a.c.n_seg;
     if (a.c.n_seg > 1) {                                           // non-finite samples: sos_device.h, FloodArgs
         rc = hd_seg_flags(ctx, (size_t)a.units, &a.c.flags);
@@ -1163,11 +1200,12 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     FloodArgs fl;
     memset(&fl, 0, sizeof(fl));
     fl.flags = a.c.flags; fl.n_seg = a.c.n_seg; fl.seg_len = a.c.seg_len;
-    fl.y = yf; fl.y_pitch = yf_pitch; fl.T = frames;
+    fl.y = yf; fl.y_pitch = yf_pitch; fl.T = T; fl.skip = gs.lead;       // (sample p' of the sweep is yf[p' - lead])
     fl.psd = psd; fl.db = db_out; fl.psd_pitch = psd_pitch; fl.n_valid = n_valid;
-    fl.F = (int)F; fl.nfft = nfft; fl.hop = hop;
+    fl.F = (int)F; fl.nfft = nfft; fl.hop = hop; fl.frame_off = gs.frame_off;
     if (SE == 0) return launch_flood(ctx, fl, channels);
-    return hd_launch_env_fix(ctx, eplan->dev, SE, (double *)work, ckpt_pitch, channels, a.c.n_seg, a.c.seg_len, n_tiles, &fl);
+    return hd_launch_env_fix(ctx, eplan->dev, SE, (double *)work, ckpt_pitch, channels, a.c.n_seg, a.c.seg_len, n_tiles, &fl,
+                             (int)((gs.env0 - gs.env0 % TILE) / a.c.seg_len));
 }
 
 int hipdsp_chain_backward(hipdsp_ctx *ctx, const hipdsp_sosplan *eplan, const float *yf, int64_t yf_pitch, float *env,

@@ -47,6 +47,10 @@ struct hipdsp_ctx {
     // FloodArgs).  1 MiB from the start, grown by hd_seg_flags() outside captures only.
     unsigned char *seg_flags;
     size_t seg_flags_cap;
+    // The tile grid of the last forward sweep that parked envelope tile states in `scratch` (sos_device.h: GridShift,
+    // hd_note_sweep): the backward sweep that consumes them (hipdsp_sosfilt_envelope phase 2) walks the same grid.
+    long long sweep_lead, sweep_env0, sweep_frames, sweep_channels;
+    int sweep_sections;
 };
 
 // the flags of a forward sweep of `units` (channel, segment) pairs

@@ -135,9 +135,13 @@ __global__ __launch_bounds__(64 * WPB) void sos_ckpt_kernel(const SosPlanDev *__
     // tile, its tile states are therefore the ZERO-STATE ones, and the state it ends with goes where the next
     // segment's first (always zero) tile state would go; env_fix_kernel then hands the true states over from
     // segment to segment and corrects the tile states (exact) -- only the band-pass still warms up.
-    const long long env_start = lo;
-    const bool env_true = seg == 0;
-    long long start = env_start;
+    // The envelope starts at p' = env0 (sos_device.h: GridShift): the unit whose range holds that tile starts it from
+    // the true state there, units in front of it have no envelope work, units behind it start from zero state at `lo`.
+    const long long lead = a.lead;
+    const long long env_tile0 = a.env0 - a.env0 % TILE;
+    const bool env_true = lo <= env_tile0 && env_tile0 < hi;
+    const long long env_start = env_true ? env_tile0 : (lo > env_tile0 ? lo : (1LL << 62));
+    long long start = SF > 0 ? lo : (env_start < hi ? env_start : hi);      // (no band-pass: nothing to do in front of the envelope)
     if (SF > 0) start -= PF0->warm;
     if (start < 0) start = 0;               // zero state at sample 0 is the filter's true state
     const long long loop_end = last_seg ? T + edge : hi;   // the right extension may need a tile more
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(64 * WPB) void sos_ckpt_kernel(const SosPlanDev *__
         for (int k = 0; k < 8; k++) nx[k] = asm_load16(in + t0 + 256 * k + 4 * lane);
     };
     if (PREFETCH) {
-        pre = start < loop_end && start + TILE <= T;
+        pre = start < loop_end && start + TILE <= T && start >= lead;
         fetch(pre ? start : top_full);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -174,29 +178,32 @@ __global__ __launch_bounds__(64 * WPB) void sos_ckpt_kernel(const SosPlanDev *__
                 lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = make_float4(nx[k].x, nx[k].y, nx[k].z, nx[k].w);
             }
         } else if (PREFETCH) {
-            // a tile that reaches past T: untracked loads from clamped addresses, zeros past T
+            // a tile that reaches past T (or holds the `lead` samples in front of the trace): untracked loads from
+            // clamped addresses, zeros outside [lead, T)
 #pragma unroll 1
             for (int k = 0; k < 8; k++) {
                 const long long p = tile + 256 * k + 4 * lane;
+                auto at = [&](long long q) { return in + (q < lead ? lead : (q < T ? q : T - 1)); };
+                auto ok = [&](long long q) { return q >= lead && q < T; };
                 v4f t;
-                t.x = asm_load4(in + (p < T ? p : T - 1));
-                t.y = asm_load4(in + (p + 1 < T ? p + 1 : T - 1));
-                t.z = asm_load4(in + (p + 2 < T ? p + 2 : T - 1));
-                t.w = asm_load4(in + (p + 3 < T ? p + 3 : T - 1));
+                t.x = asm_load4(at(p));
+                t.y = asm_load4(at(p + 1));
+                t.z = asm_load4(at(p + 2));
+                t.w = asm_load4(at(p + 3));
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("" : "+v"(t));
                 lds[lds_slot(8 * k + (lane >> 3), lane & 7)] =
-                    make_float4(p < T ? t.x : 0.f, p + 1 < T ? t.y : 0.f, p + 2 < T ? t.z : 0.f, p + 3 < T ? t.w : 0.f);
+                    make_float4(ok(p) ? t.x : 0.f, ok(p + 1) ? t.y : 0.f, ok(p + 2) ? t.z : 0.f, ok(p + 3) ? t.w : 0.f);
             }
         } else {
 #pragma unroll
             for (int k = 0; k < 8; k++)
-                lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = load_four(in, tile + 256 * k + 4 * lane, T);
+                lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = load_four_from(in, tile + 256 * k + 4 * lane, lead, T);
         }
         WAVE_SYNC();
         if (PREFETCH) {
             const long long next = tile + TILE;
-            pre = next < loop_end && next + TILE <= T;
+            pre = next < loop_end && next + TILE <= T;          // (next > 0 >= ... : never the tile with the lead)
             fetch(pre ? next : top_full);
         }
         if constexpr (SF > 0) {
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(64 * WPB) void sos_ckpt_kernel(const SosPlanDev *__
 #undef CASC_IN
             WAVE_SYNC();
             if (tile + TILE > lo && tile < hi) {
-                if (tile >= lo && tile + TILE <= hi) {
+                if (tile >= lo && tile + TILE <= hi && tile >= lead) {
                     // interior tile: exactly 8 vector stores, then the counted wait
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
@@ -223,7 +230,8 @@ __global__ __launch_bounds__(64 * WPB) void sos_ckpt_kernel(const SosPlanDev *__
                 } else {
 #pragma unroll
                     for (int k = 0; k < 8; k++)
-                        store_four(yf, tile + 256 * k + 4 * lane, lds[lds_slot(8 * k + (lane >> 3), lane & 7)], lo, hi, 0);
+                        store_four(yf, tile + 256 * k + 4 * lane, lds[lds_slot(8 * k + (lane >> 3), lane & 7)],
+                                   lo > lead ? lo : lead, hi, 0);
                     if (PREFETCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
             } else if (PREFETCH) {
@@ -261,7 +269,15 @@ __global__ __launch_bounds__(64 * WPB) void sos_ckpt_kernel(const SosPlanDev *__
             if (lane < edge && pj >= tile && pj < tile + TILE) ldsf[lds_float_index((int)(pj - tile))] = pv;
             WAVE_SYNC();
         }
-        if (env_true && tile == 0) {
+        if (env_true && tile == env_start && a.env0 > 0) {
+            // the envelope starts inside this tile: left odd extension and its steady state in front of it, in the
+            // tile itself (env_left_fill; chain_fwd_kernel has the same lines)
+            const SosPlanDev *P = PLAN_OF(PE0);
+            const float e0 = env_left_fill(ldsf, lane, (int)(a.env0 - tile), edge);
+            const double x0 = a.gain * (double)e0;
+#pragma unroll
+            for (int r = 0; r < DE; r++) ce_[r] = P->zi[r] * x0;
+        } else if (env_true && tile == env_start) {
             // left odd extension: ext[i] = 2 r(0) - r(edge - i), i < edge, from zi * ext[0];
             // wave-uniform serial steps
             const SosPlanDev *P = PLAN_OF(PE0);
@@ -340,8 +356,10 @@ __global__ __launch_bounds__(64 * WPB) void sos_ckpt_kernel(const SosPlanDev *__
 // and if any segment's envelope state ended non-finite it leaves NaN in slot n_tiles for the backward sweep.
 template <int SE>
 __global__ __launch_bounds__(256) void env_fix_kernel(const SosPlanDev *__restrict__ P0, double *ckpt_all, long long ckpt_pitch,
-                                                      int n_seg, long long seg_tiles, long long n_tiles, FloodArgs flood)
+                                                      int n_seg, long long seg_tiles, long long n_tiles, FloodArgs flood,
+                                                      int first_seg)
 {
+    // (first_seg: the segment the envelope starts in -- it holds the true states; the segments in front of it left nothing)
     constexpr int D = 2 * SE;
     double *ckpt = ckpt_all + (long long)blockIdx.x * ckpt_pitch;
     flood_channel(flood, blockIdx.x);
@@ -350,7 +368,7 @@ __global__ __launch_bounds__(256) void env_fix_kernel(const SosPlanDev *__restri
         if (threadIdx.x == 0) any_bad = 0;
         __syncthreads();
         // e_j, the end state of segment j: slot (j + 1) seg_tiles, the last one: slot n_tiles
-        for (long long j = threadIdx.x; j < n_seg; j += blockDim.x) {
+        for (long long j = first_seg + threadIdx.x; j < n_seg; j += blockDim.x) {
             const double *e = ckpt + (j + 1 < n_seg ? (j + 1) * seg_tiles : n_tiles) * D;
             bool bad = false;
 #pragma unroll
@@ -406,15 +424,15 @@ __global__ __launch_bounds__(256) void env_fix_kernel(const SosPlanDev *__restri
     }
     const long long warm_tiles = P0->warm / TILE;                  // ||A^(TILE warm_tiles)|| < 2^-60
     const long long terms = (warm_tiles + seg_tiles - 1) / seg_tiles + 1;
-    for (long long k_hi = n_seg - 1; k_hi >= 1; k_hi -= blockDim.x) {
+    for (long long k_hi = n_seg - 1; k_hi >= first_seg + 1; k_hi -= blockDim.x) {
         const long long k = k_hi - threadIdx.x;
         double S[D];
 #pragma unroll
         for (int r = 0; r < D; r++) S[r] = 0.0;
-        if (k >= 1) {
+        if (k >= first_seg + 1) {
             // Horner from the oldest term: S = e_(k-J) ; S = P S + e_(k-J+1) ; ... ; + e_(k-1); e_j sits in slot (j+1) seg_tiles
             long long j = k - terms;
-            if (j < 0) j = 0;
+            if (j < first_seg) j = first_seg;
             for (; j < k; j++) {
                 const double *e = ckpt + (j + 1) * seg_tiles * D;
                 double t[D];
@@ -430,7 +448,7 @@ __global__ __launch_bounds__(256) void env_fix_kernel(const SosPlanDev *__restri
             }
         }
         __syncthreads();
-        if (k >= 1) {
+        if (k >= first_seg + 1) {
             const long long t0 = k * seg_tiles;
             long long cnt = (k == n_seg - 1) ? n_tiles - t0 : seg_tiles;     // tile slots of segment k
             if (cnt > warm_tiles + 1) cnt = warm_tiles + 1;
@@ -454,7 +472,7 @@ __global__ __launch_bounds__(256) void env_fix_kernel(const SosPlanDev *__restri
 }
 
 int launch_env_fix(hipdsp_ctx *ctx, const SosPlanDev *edev, int SE, double *ckpt, long long ckpt_pitch, long long channels,
-                   int n_seg, long long seg_len, long long n_tiles, const FloodArgs *flood)
+                   int n_seg, long long seg_len, long long n_tiles, const FloodArgs *flood, int first_seg = 0)
 {
     if (n_seg <= 1) return HIPDSP_OK;       // (one segment: nothing to hand over, nothing to flood, slot n_tiles is true)
     dim3 grid((unsigned)channels), block(256);
@@ -463,10 +481,10 @@ int launch_env_fix(hipdsp_ctx *ctx, const SosPlanDev *edev, int SE, double *ckpt
     memset(&fl, 0, sizeof(fl));
     if (flood) fl = *flood;
     switch (SE) {
-    case 1: hipLaunchKernelGGL((env_fix_kernel<1>), grid, block, 0, ctx->stream, edev, ckpt, ckpt_pitch, n_seg, seg_tiles, n_tiles, fl); break;
-    case 2: hipLaunchKernelGGL((env_fix_kernel<2>), grid, block, 0, ctx->stream, edev, ckpt, ckpt_pitch, n_seg, seg_tiles, n_tiles, fl); break;
-    case 3: hipLaunchKernelGGL((env_fix_kernel<3>), grid, block, 0, ctx->stream, edev, ckpt, ckpt_pitch, n_seg, seg_tiles, n_tiles, fl); break;
-    case 4: hipLaunchKernelGGL((env_fix_kernel<4>), grid, block, 0, ctx->stream, edev, ckpt, ckpt_pitch, n_seg, seg_tiles, n_tiles, fl); break;
+    case 1: hipLaunchKernelGGL((env_fix_kernel<1>), grid, block, 0, ctx->stream, edev, ckpt, ckpt_pitch, n_seg, seg_tiles, n_tiles, fl, first_seg); break;
+    case 2: hipLaunchKernelGGL((env_fix_kernel<2>), grid, block, 0, ctx->stream, edev, ckpt, ckpt_pitch, n_seg, seg_tiles, n_tiles, fl, first_seg); break;
+    case 3: hipLaunchKernelGGL((env_fix_kernel<3>), grid, block, 0, ctx->stream, edev, ckpt, ckpt_pitch, n_seg, seg_tiles, n_tiles, fl, first_seg); break;
+    case 4: hipLaunchKernelGGL((env_fix_kernel<4>), grid, block, 0, ctx->stream, edev, ckpt, ckpt_pitch, n_seg, seg_tiles, n_tiles, fl, first_seg); break;
     default: return HIPDSP_OK;
     }
     return hd_launch_status("env_fix_kernel");
@@ -566,7 +584,11 @@ __global__ __launch_bounds__(64 * WPB_, REGW ? 2 : 1) void env_bwd_kernel(const 
     // tile instead and drops it): a conditional asm load would make `nx` a phi of two register
     // sets, and the copies hipcc inserts for it read the registers while the loads are in flight.
     const long long top_full = T / TILE - 1;                     // host guarantees >= 0
-    auto prefetchable = [&](long long tidx) { return tidx >= 0 && tidx <= top_full && tidx * TILE + TILE > a.skip; };
+    auto prefetchable = [&](long long tidx) {
+        return tidx >= 0 && tidx <= top_full && tidx * TILE + TILE > a.skip && tidx * TILE >= a.lead;
+    };
+    // the tile the envelope starts in (GridShift; -1: it starts with the trace, nothing to rebuild)
+    const long long env_tile0 = a.env0 > 0 ? a.env0 - a.env0 % TILE : -1;
     if (PREFETCH) {
         const long long t0 = a.n_tiles - 1 - rt_start;
         pre = rt_start < rt_hi && prefetchable(t0);
@@ -607,22 +629,26 @@ __global__ __launch_bounds__(64 * WPB_, REGW ? 2 : 1) void env_bwd_kernel(const 
             }
             WAVE_SYNC();
         } else if (PREFETCH) {
-            // a tile that touches T (the top one or two of a channel).  Every load of this loop is
+            // a tile that touches T (the top one or two of a channel) or holds the `lead` samples in front of the
+            // trace.  Every load of this loop is
             // an untracked asm load: hipcc's own vmcnt(0) for a tracked one would also drain the
-            // prefetch issued further down.  Clamped addresses are always valid; samples past T
+            // prefetch issued further down.  Clamped addresses are always valid; samples outside [lead, T)
             // become zero.
+            const long long lead = a.lead;
 #pragma unroll 1
             for (int k = 0; k < 8; k++) {
                 const long long p = tile + 256 * k + 4 * lane;
+                auto at = [&](long long q) { return in + (q < lead ? lead : (q < T ? q : T - 1)); };
+                auto ok = [&](long long q) { return q >= lead && q < T; };
                 v4f t;
-                t.x = asm_load4(in + (p < T ? p : T - 1));
-                t.y = asm_load4(in + (p + 1 < T ? p + 1 : T - 1));
-                t.z = asm_load4(in + (p + 2 < T ? p + 2 : T - 1));
-                t.w = asm_load4(in + (p + 3 < T ? p + 3 : T - 1));
+                t.x = asm_load4(at(p));
+                t.y = asm_load4(at(p + 1));
+                t.z = asm_load4(at(p + 2));
+                t.w = asm_load4(at(p + 3));
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("" : "+v"(t));
-                float4 v = make_float4(p < T ? t.x : 0.f, p + 1 < T ? t.y : 0.f, p + 2 < T ? t.z : 0.f,
-                                       p + 3 < T ? t.w : 0.f);
+                float4 v = make_float4(ok(p) ? t.x : 0.f, ok(p + 1) ? t.y : 0.f, ok(p + 2) ? t.z : 0.f,
+                                       ok(p + 3) ? t.w : 0.f);
                 if (a.rectify) v = make_float4(fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w));
                 lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = v;
             }
@@ -630,7 +656,7 @@ __global__ __launch_bounds__(64 * WPB_, REGW ? 2 : 1) void env_bwd_kernel(const 
 #pragma unroll
             for (int i = 0; i < SE; i++) ck[i] = asm_load16(ckpt + tidx * DE + 2 * i);
             float ra = asm_load4(in + (T - 1));
-            float rb = asm_load4(in + (lane < edge ? T - 2 - lane : 0));
+            float rb = asm_load4(in + (lane < edge ? T - 2 - lane : T - 1));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int i = 0; i < SE; i++) {
@@ -652,7 +678,7 @@ __global__ __launch_bounds__(64 * WPB_, REGW ? 2 : 1) void env_bwd_kernel(const 
         } else {
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                float4 v = load_four(in, tile + 256 * k + 4 * lane, T);
+                float4 v = load_four_from(in, tile + 256 * k + 4 * lane, a.lead, T);
                 if (a.rectify) v = make_float4(fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w));
                 lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = v;
             }
@@ -673,6 +699,11 @@ __global__ __launch_bounds__(64 * WPB_, REGW ? 2 : 1) void env_bwd_kernel(const 
             WAVE_SYNC();
         }
         if (PREFETCH) WAVE_SYNC();
+        if (tile == env_tile0) {
+            // the tile the envelope starts in: rebuild what the forward sweep filtered there -- the left odd extension
+            // and its first value in front of it (the tile's state, zi * that value, is in the tile states)
+            (void)env_left_fill(ldsf, lane, (int)(a.env0 - tile), edge);
+        }
         TRACE_AT(0);                               // tile from the prefetch registers into LDS
         if (PREFETCH) {
             pre = rt + 1 < rt_hi && prefetchable(tidx - 1);
@@ -920,8 +951,16 @@ int launch_scan(hipdsp_ctx *ctx, const SosPlanDev *dev, int S, SeqArgs a, long l
 int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *edev, int SF, int SE, long long warmF,
                     long long warmE, int edge, const float *x, long long x_pitch, float *yf,
                     long long yf_pitch, float *env, long long env_pitch, long long channels,
-                    long long frames, long long skip, int rectify, double gain, int clamp, int phase)
+                    long long frames, long long skip, int rectify, double gain, int clamp, int phase,
+                    GridShift gs = GridShift{0, 0, 0})
 {
+    // `gs`: the sweep's tile grid when the envelope does not start with the trace (sos_device.h: GridShift): the kernels
+    // walk T = frames + lead samples through pointers shifted by -lead; `skip` counts from the envelope's first sample
+    const long long real_frames = frames;
+    x -= gs.lead;
+    if (yf) yf -= gs.lead;
+    frames += gs.lead;
+    skip += gs.env0;
     const long long n_tiles = (frames + edge + TILE - 1) / TILE;
     const long long ckpt_pitch = (n_tiles + 1) * 2 * SE;     // (+ 1: the state the channel ends with, FloodArgs)
     void *work = nullptr;
@@ -933,6 +972,8 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
         fa.in = x; fa.yf = yf; fa.ckpt = (double *)work;
         fa.in_pitch = x_pitch; fa.yf_pitch = yf_pitch; fa.ckpt_pitch = ckpt_pitch;
         fa.T = frames; fa.edge = edge; fa.rectify = rectify; fa.gain = rectify ? gain : 1.0;
+        fa.lead = gs.lead; fa.env0 = gs.env0;
+        hd_note_sweep(ctx, gs.lead, gs.env0, real_frames, channels, SE);
         // only the band-pass warms up; the envelope's states are handed over exactly (env_fix_kernel), which needs
         // a cascade that forgets (a plan that does not decay is never cut into segments)
         long long warm = warmF;
@@ -970,8 +1011,9 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
         FloodArgs fl;
         memset(&fl, 0, sizeof(fl));
         fl.flags = fa.flags; fl.n_seg = fa.n_seg; fl.seg_len = fa.seg_len;
-        fl.y = yf; fl.y_pitch = yf_pitch; fl.T = frames;
-        rc = launch_env_fix(ctx, edev, SE, (double *)work, ckpt_pitch, channels, fa.n_seg, fa.seg_len, n_tiles, &fl);
+        fl.y = yf ? yf + gs.lead : nullptr; fl.y_pitch = yf_pitch; fl.T = frames; fl.skip = gs.lead;
+        rc = launch_env_fix(ctx, edev, SE, (double *)work, ckpt_pitch, channels, fa.n_seg, fa.seg_len, n_tiles, &fl,
+                            (int)((gs.env0 - gs.env0 % TILE) / fa.seg_len));
         if (rc != HIPDSP_OK) return rc;
     }
     if (phase == 1) return HIPDSP_OK;
@@ -983,6 +1025,7 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
     b.out = env; b.out_pitch = env_pitch;
     b.ckpt = (const double *)work; b.ckpt_pitch = ckpt_pitch;
     b.T = frames; b.skip = skip; b.n_tiles = n_tiles; b.edge = edge;
+    b.lead = gs.lead; b.env0 = gs.env0;
     b.rectify = rectify; b.clamp = clamp; b.gain = rectify ? gain : 1.0;
     b.trace = ctx->sos_trace;
     b.trace_rows = ctx->sos_trace_rows;
@@ -1027,9 +1070,9 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
 }  // namespace
 
 int hd_launch_env_fix(hipdsp_ctx *ctx, const SosPlanDev *edev, int SE, double *ckpt, long long ckpt_pitch, long long channels,
-                      int n_seg, long long seg_len, long long n_tiles, const FloodArgs *flood)
+                      int n_seg, long long seg_len, long long n_tiles, const FloodArgs *flood, int first_seg)
 {
-    return launch_env_fix(ctx, edev, SE, ckpt, ckpt_pitch, channels, n_seg, seg_len, n_tiles, flood);
+    return launch_env_fix(ctx, edev, SE, ckpt, ckpt_pitch, channels, n_seg, seg_len, n_tiles, flood, first_seg);
 }
 
 extern "C" {
@@ -1147,11 +1190,13 @@ int hipdsp_sosfilt(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const float *x, 
 int hipdsp_sosfilt_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hipdsp_sosplan *eplan,
                             const float *x, int64_t x_pitch, float *yf, int64_t yf_pitch, float *env,
                             int64_t env_pitch, int64_t channels, int64_t frames, int rectify, double gain,
-                            int clamp, int phase)
+                            int clamp, int phase, int64_t env_first)
 {
     HD_REQUIRE(ctx != nullptr && fplan != nullptr && eplan != nullptr, "NULL argument");
     HD_REQUIRE(phase >= 0 && phase <= 2, "phase must be 0 (both), 1 (forward) or 2 (backward)");
     HD_REQUIRE(channels >= 0 && frames >= 0, "negative size");
+    HD_REQUIRE(env_first >= 0 && env_first <= frames, "env_first %lld not in [0, frames=%lld]", (long long)env_first,
+               (long long)frames);
     HD_REQUIRE(fplan->host->n_sections > 0 && eplan->host->n_sections > 0, "plan has no coefficients");
     HD_CHECK_HIP(hipSetDevice(ctx->device));
     {   // phase 2 consumes what a forward sweep left behind: not if that sweep reported a fault
@@ -1159,18 +1204,37 @@ int hipdsp_sosfilt_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const 
         if (frc != HIPDSP_OK) return frc;
     }
     const int edge = eplan->host->edge;
-    if (frames <= edge) {
+    if (frames - env_first <= edge) {
         hipdsp_set_error("The length of the input vector x must be greater than padlen, which is %d.", edge);
         return HIPDSP_ERR_TOO_SHORT;
     }
     if (channels == 0) return HIPDSP_OK;
     HD_REQUIRE(x != nullptr && yf != nullptr && env != nullptr, "NULL data pointer");
-    HD_REQUIRE(x_pitch >= frames && yf_pitch >= frames && env_pitch >= frames, "pitch smaller than row length");
+    HD_REQUIRE(x_pitch >= frames && yf_pitch >= frames && env_pitch >= frames - env_first, "pitch smaller than row length");
     if (phase != 2) HD_NO_OVERLAP(x, x_pitch, frames, yf, yf_pitch, frames, channels, "x and yf");
-    if (phase != 1) HD_NO_OVERLAP(yf, yf_pitch, frames, env, env_pitch, frames, channels, "yf and env");
+    if (phase != 1) HD_NO_OVERLAP(yf, yf_pitch, frames, env, env_pitch, frames - env_first, channels, "yf and env");
+    GridShift gs;
+    if (phase == 2) {
+        // the tile states in the scratch belong to the grid of the forward sweep that left them
+        // (hipdsp_chain_forward or phase 1): same trace, same envelope start
+        const long long lead = ctx->sweep_lead;
+        if (ctx->sweep_frames != frames || ctx->sweep_channels != channels || ctx->sweep_sections != eplan->host->n_sections ||
+            ctx->sweep_env0 - lead != env_first) {
+            hipdsp_set_error("hipdsp_sosfilt_envelope(phase = 2): the last forward sweep on this context left tile states for "
+                             "%lld channels x %lld frames, %d sections, envelope from frame %lld -- not for %lld x %lld, %d, %lld",
+                             ctx->sweep_channels, ctx->sweep_frames, ctx->sweep_sections,
+                             ctx->sweep_env0 - ctx->sweep_lead, (long long)channels, (long long)frames,
+                             eplan->host->n_sections, (long long)env_first);
+            return HIPDSP_ERR_INVALID;
+        }
+        gs.lead = lead; gs.env0 = ctx->sweep_env0; gs.frame_off = 0;
+    } else {
+        gs = hd_grid_shift(0, env_first, 0, edge, true);
+    }
+    HD_REQUIRE(gs.lead < TILE, "grid shift %lld", gs.lead);
     return launch_env_ckpt(ctx, fplan->dev, eplan->dev, fplan->host->n_sections, eplan->host->n_sections,
                            fplan->host->warm, eplan->host->warm, edge, x, x_pitch, yf, yf_pitch, env, env_pitch,
-                           channels, frames, 0, rectify, gain, clamp, phase);
+                           channels, frames, 0, rectify, gain, clamp, phase, gs);
 }
 
 int hipdsp_envelope_multi(hipdsp_ctx *ctx, const hipdsp_sosplan *const *plans, int n_plans, const float *x,

@@ -34,11 +34,13 @@ struct FloodArgs {
     float *psd, *db;             // [channel][frame][F] with psd_pitch floats per channel; may be NULL
     long long psd_pitch, n_valid;
     int F, nfft, hop;
+    int frame_off;               // frame k of psd / db is frame k + frame_off of the sweep's grid (GridShift)
 };
 
 // defined in sos.hip: hands the true states over between the time segments of a forward sweep (env_fix_kernel)
+// (first_seg: the segment the envelope starts in, GridShift -- segments in front of it left no states)
 int hd_launch_env_fix(hipdsp_ctx *ctx, const SosPlanDev *edev, int SE, double *ckpt, long long ckpt_pitch, long long channels,
-                      int n_seg, long long seg_len, long long n_tiles, const FloodArgs *flood);
+                      int n_seg, long long seg_len, long long n_tiles, const FloodArgs *flood, int first_seg = 0);
 
 namespace {
 
@@ -95,6 +97,18 @@ __device__ __forceinline__ float4 load_four(const float *in, long long p, long l
     v.y = p + 1 < n ? in[p + 1] : 0.f;
     v.z = p + 2 < n ? in[p + 2] : 0.f;
     v.w = p + 3 < n ? in[p + 3] : 0.f;
+    return v;
+}
+
+// the same for a row whose samples in front of `first` do not exist either (zeros there too)
+__device__ __forceinline__ float4 load_four_from(const float *in, long long p, long long first, long long n)
+{
+    if (p >= first) return load_four(in, p, n);
+    float4 v;
+    v.x = 0.f;
+    v.y = (p + 1 >= first && p + 1 < n) ? in[p + 1] : 0.f;
+    v.z = (p + 2 >= first && p + 2 < n) ? in[p + 2] : 0.f;
+    v.w = (p + 3 >= first && p + 3 < n) ? in[p + 3] : 0.f;
     return v;
 }
 
@@ -176,7 +190,41 @@ struct CkptArgs {
     long long units;        // channels * n_seg (the grid is rounded up to whole workgroups; the fused sweep: ChainArgs::units)
     double gain;            // the envelope filters gain * |y|: folded into its cascade (CASC_GAIN), never into the samples
     unsigned char *flags;   // one byte per unit: did its band-pass end with a non-finite state? (FloodArgs; SF > 0)
+    // A sweep whose tile grid does not start at the first sample (GridShift below): the kernel walks sample
+    // coordinates p' = sample + lead of a trace of T = frames + lead samples whose first `lead` samples do not exist
+    // (`in` and `yf` are shifted by -lead on the host; p' < lead is never dereferenced: zero on the way in, masked
+    // on the way out -- zero input from zero state is the band-pass's true state at the first real sample).
+    long long lead;         // 0 <= lead < TILE: only tile 0 holds such samples
+    long long env0;         // p' of the first sample the envelope is taken of (0: the trace's first, the classic case)
 };
+
+// Where a forward sweep puts its tile grid.  The fused sweep's spectrogram frames are register windows of its tiles,
+// so frame k -- samples spec_first + k hop ... of the filtered buffer -- must start at a multiple of hop in the sweep's
+// coordinates p' = sample + lead; the envelope may start at sample env_first (BufferedData.align_buffer trims its
+// pre-roll after a scroll, buffereddata.py:75-88): its first tile then holds scipy's left odd extension and, in front
+// of that, the extension's first value, for which zi * value is the cascade's steady state -- which needs the whole
+// extension and its sources (edge samples either side of p' = env0) inside ONE tile.  Both are a matter of choosing
+// lead (< TILE); `step` is what lead may move by (the hop with a spectrogram in the launch, 128 samples without).
+struct GridShift {
+    long long lead, env0;
+    int frame_off;          // frame k of the output is frame k + frame_off of the sweep's grid
+};
+inline GridShift hd_grid_shift(long long spec_first, long long env_first, int hop, int edge, bool with_env)
+{
+    GridShift g;
+    const long long step = hop > 0 ? hop : 128;
+    g.lead = hop > 0 ? (step - spec_first % step) % step : 0;
+    if (with_env && env_first + g.lead > 0) {
+        for (int tries = 0; tries < 4; tries++) {
+            const long long r = (env_first + g.lead) % TILE;
+            if (r >= edge && r + edge < TILE) break;
+            g.lead += step;
+        }
+    }
+    g.env0 = with_env ? env_first + g.lead : 0;
+    g.frame_off = hop > 0 ? (int)((spec_first + g.lead) / step) : 0;
+    return g;
+}
 
 // 16-byte global load the compiler does not track: the caller counts vmcnt by hand, so that the
 // wait for a prefetched tile does not also wait for the stores issued after it.
@@ -230,6 +278,31 @@ __device__ __forceinline__ unsigned wave_slot_of_simd()
     return hw;
 }
 
+// a forward sweep has parked the envelope's tile states in the context scratch: remember its grid for phase 2
+inline void hd_note_sweep(hipdsp_ctx *ctx, long long lead, long long env0, long long frames, long long channels, int SE)
+{
+    ctx->sweep_lead = lead; ctx->sweep_env0 = env0; ctx->sweep_frames = frames; ctx->sweep_channels = channels;
+    ctx->sweep_sections = SE;
+}
+
+// The first tile of an envelope that starts inside it, at sample q of the tile (see GridShift): the tile holds the
+// rectified trace r; writes scipy's left odd extension ext[i] = 2 r(q) - r(q + edge - i), i < edge
+// (scipy/signal/_arraytools.py:99-107) into samples q - edge .. q - 1 and ext[0] into everything in front of them,
+// and returns ext[0] (wave-uniform).  Requires edge <= q and q + edge < TILE.  float32 like the right extension;
+// the forward and the backward sweep call this on the same float32 samples, so both see the same tile.
+__device__ __forceinline__ float env_left_fill(float *ldsf, int lane, int q, int edge)
+{
+    const float r0 = ldsf[lds_float_index(q)];
+    const float e0 = 2.f * r0 - ldsf[lds_float_index(q + edge)];
+    float ev = 0.f;
+    if (lane < edge) ev = 2.f * r0 - ldsf[lds_float_index(q + edge - lane)];
+    WAVE_SYNC();
+    if (lane < edge) ldsf[lds_float_index(q - edge + lane)] = ev;
+    for (int s2 = lane; s2 < q - edge; s2 += 64) ldsf[lds_float_index(s2)] = e0;
+    WAVE_SYNC();
+    return e0;
+}
+
 struct BwdArgs {
     const float *in;         // the trace the envelope is taken of (before rectification)
     float *out;
@@ -241,6 +314,7 @@ struct BwdArgs {
     int n_seg, edge, rectify, clamp;
     double gain;             // as in CkptArgs
     long long units;         // channels * n_seg (the grid is rounded up to whole workgroups)
+    long long lead, env0;    // as in CkptArgs: the grid of the forward sweep that left the tile states (skip >= env0)
     long long *trace;        // option "sos_trace": 9 words per wave (start, end in 100 MHz ticks, HW_ID, 6 clock sums)
     long long trace_rows;    // rows of `trace` (option "sos_trace_rows"): waves beyond it do not report
     int debug;               // measurements only, results wrong (option "sos_debug"): 1 = every interior tile is stored into
@@ -279,7 +353,8 @@ __device__ void flood_channel(const FloodArgs &f, long long ch)
     }
     if (f.psd != nullptr || f.db != nullptr) {
         // frames k with k hop + nfft > n1 (those that only touch the end of segment s0 are NaN already)
-        const long long k0 = n1 >= f.nfft ? (n1 - f.nfft) / f.hop + 1 : 0;
+        long long k0 = (n1 >= f.nfft ? (n1 - f.nfft) / f.hop + 1 : 0) - f.frame_off;
+        if (k0 < 0) k0 = 0;
         for (long long i = k0 * f.F + threadIdx.x; i < f.n_valid * f.F; i += blockDim.x) {
             if (f.psd != nullptr) f.psd[ch * f.psd_pitch + i] = nan_;
             if (f.db != nullptr) f.db[ch * f.psd_pitch + i] = nan_;

@@ -319,25 +319,32 @@ def envelope_multi(ctx, plans, x, x_pitch, y, y_pitch, channels, frames, skip=0,
 
 
 def sosfilt_envelope(ctx, fplan, eplan, x, x_pitch, yf, yf_pitch, env, env_pitch, channels, frames,
-                     rectify=True, gain=np.pi/2, clamp=True, phase=0):
+                     rectify=True, gain=np.pi/2, clamp=True, phase=0, env_first=0):
+    """yf = sosfilt(fplan, x); env = sosfiltfilt(eplan, gain*|yf[env_first:]|) (hipdsp_sosfilt_envelope): env rows hold
+    frames - env_first samples.  phase 0 = both sweeps, 1 = forward only, 2 = backward only (after phase 1 or
+    chain_forward with the same env_first)."""
     _count('sosfilt_envelope:%d' % phase)
     check(lib.hipdsp_sosfilt_envelope(ctx.handle, fplan.handle, eplan.handle, _p(x), int(x_pitch),
                                       _p(yf), int(yf_pitch), _p(env), int(env_pitch), int(channels),
                                       int(frames), int(bool(rectify)), float(gain), int(bool(clamp)),
-                                      int(phase)))
+                                      int(phase), int(env_first)))
 
 
 def chain_forward(ctx, fplan, eplan, x, x_pitch, yf, yf_pitch, channels, frames, nfft, hop, fs, psd,
-                  frames_out, psd_pitch=0, rectify=True, gain=np.pi/2, db_out=None, spec_frames=0):
+                  frames_out, psd_pitch=0, rectify=True, gain=np.pi/2, db_out=None, spec_frames=0, spec_first=0,
+                  env_first=0):
     """Band-pass + envelope state sweep + spectrogram of the filtered trace in one pass over x
     (nfft/hop 2048/1024, 2048/512, 1024/512, 1024/256, 512/256, 256/128; NotImplementedError otherwise).  The envelope follows with
     sosfilt_envelope(..., phase=2).  eplan None: no envelope (filter + spectrogram only); spec_frames: the
-    spectrogram is handed only that many samples of the filtered trace (0 = all)."""
+    spectrogram is handed only that many samples of the filtered trace (0 = all); spec_first: frame 0 of the
+    spectrogram starts at that sample of the filtered trace (spec_frames counts from there); env_first: the envelope
+    is that of yf[env_first:] (pass the same env_first to sosfilt_envelope(phase=2))."""
     _count('chain_forward')
     check(lib.hipdsp_chain_forward(ctx.handle, fplan.handle, _plan(eplan), _p(x), int(x_pitch), _p(yf),
                                    int(yf_pitch), int(channels), int(frames), int(bool(rectify)),
                                    float(gain), int(nfft), int(hop), float(fs), _p(psd), _p(db_out),
-                                   int(frames_out), int(psd_pitch), int(spec_frames)))
+                                   int(frames_out), int(psd_pitch), int(spec_frames), int(spec_first),
+                                   int(env_first)))
 
 
 def chain_backward(ctx, eplan, yf, yf_pitch, env, env_pitch, channels, frames, nfft, hop, fs, psd, frames_out,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HIPDSP_VERSION 101          /* 0.1.1 */
+#define HIPDSP_VERSION 102          /* 0.1.2 */
 
 #define HIPDSP_OK               0
 #define HIPDSP_ERR_INVALID      1   /* bad argument */
@@ -270,12 +270,17 @@ int hipdsp_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const float *x,
  * phase: 0 = both sweeps; 1 = forward sweep only (yf complete, states parked in the context
  * scratch); 2 = backward sweep only (env from yf and those states) -- so that other work on yf
  * (the spectrogram) can be enqueued in between; no call that uses the scratch of THIS context
- * (envelope, nfft > 32768, mean_spectrum_db) may come between phase 1 and phase 2. */
+ * (envelope, nfft > 32768, mean_spectrum_db) may come between phase 1 and phase 2.
+ * env_first: the envelope is taken of yf[env_first:] -- env rows hold frames - env_first samples, env[i] belongs
+ * to sample env_first + i of yf -- which is what BufferedEnvelope's buffer is after a scroll (its second of
+ * pre-roll trimmed by BufferedData.align_buffer, buffereddata.py:75-88; sosfiltfilt then pads and starts at that
+ * sample).  Phase 2 must be given the env_first of the forward sweep whose tile states it consumes (phase 1 or
+ * hipdsp_chain_forward; HIPDSP_ERR_INVALID otherwise).  HIPDSP_ERR_TOO_SHORT when frames - env_first <= padlen. */
 int hipdsp_sosfilt_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan,
                             const hipdsp_sosplan *eplan, const float *x, int64_t x_pitch,
                             float *yf, int64_t yf_pitch, float *env, int64_t env_pitch,
                             int64_t channels, int64_t frames, int rectify, double gain, int clamp,
-                            int phase);
+                            int phase, int64_t env_first);
 
 /* BufferedEnvelope.process for cascades LONGER than HIPDSP_MAX_SECTIONS (the reference accepts any
  * filter_order: bufferedenvelope.py:13-16,44-55; a band-pass envelope of order >= 5 or a low-pass of
@@ -311,12 +316,23 @@ int hipdsp_envelope_multi(hipdsp_ctx *ctx, const hipdsp_sosplan *const *plans, i
  * spec_frames: the spectrogram is handed only the first spec_frames samples of yf (0 = all `frames`): through
  * BufferedData.load_buffer (buffereddata.py:91-109) BufferedSpectrogram.process sees its own frames times hop
  * plus ONE sample of the filtered buffer, so its last frame(s) are zero although the filter has the samples;
- * this is what lets one launch serve BufferedFilter.recompute_all() (buffereddata.py:149-153). */
+ * this is what lets one launch serve BufferedFilter.recompute_all() (buffereddata.py:149-153).
+ * spec_first, env_first: where the derived traces start inside the filtered buffer once the user has scrolled
+ * (DataBrowser.set_times -> Data.update_times -> align_buffer, buffereddata.py:75-88, data.py:225-236): the filtered
+ * buffer then starts at an arbitrary sample of the recording, the spectrogram's frame 0 at the next multiple of hop
+ * -- sample spec_first = ceil(offset / hop) hop - offset of yf, frame k = yf[spec_first + k hop : + nfft], and
+ * spec_frames counts from there -- and the envelope is taken of yf[env_first:] only (its one second of pre-roll is
+ * trimmed: sosfiltfilt's odd extension and zi * ext[0] sit at sample env_first; the tile states parked for
+ * hipdsp_sosfilt_envelope(..., phase = 2, env_first) belong to that envelope).  Any 0 <= spec_first, env_first <=
+ * frames; the sweep shifts its tile grid (by less than one tile of zeros in front of the trace) so that frames stay
+ * register windows of its tiles, and the tile the envelope starts in holds the odd extension in front of sample
+ * env_first and the extension's first value in front of that, for which zi * value is the cascade's steady state. */
 int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan,
                          const hipdsp_sosplan *eplan, const float *x, int64_t x_pitch, float *yf,
                          int64_t yf_pitch, int64_t channels, int64_t frames, int rectify,
                          double gain, int nfft, int hop, double fs, float *psd, float *db_out,
-                         int64_t frames_out, int64_t psd_pitch, int64_t spec_frames);
+                         int64_t frames_out, int64_t psd_pitch, int64_t spec_frames, int64_t spec_first,
+                         int64_t env_first);
 
 /* Frame split of the batch chain (nfft 2048 / hop 1024): with the context option "chain_split_frames" set,
  * hipdsp_chain_forward writes only the EVEN frames 2t of psd (frame 2t is tile t of its sweep) and this call,

@@ -740,10 +740,11 @@ def test_update_takes_the_fused_launch(oracle, shape):
 
 
 def test_fused_launch_only_when_the_slabs_coincide(oracle):
-    """After a scroll into the recording the envelope's buffer starts one second later than the filtered
-    buffer (its pre-roll is trimmed, buffereddata.py:75-88): the reference then starts sosfiltfilt there, so the
-    envelope keeps its own call while the spectrogram still rides the filter's launch; at the start of the file all
-    three coincide again."""
+    """(The name is history: the launch no longer needs coinciding slabs.)  After a scroll into the recording the
+    filtered buffer starts at an arbitrary sample, the spectrogram's first frame somewhere inside the first hop of it,
+    and the envelope's buffer one second later (its pre-roll is trimmed, buffereddata.py:75-88: the reference then
+    starts sosfiltfilt there).  BufferedFilter.update() -> recompute_all() still issues ONE fused forward launch and
+    the envelope's backward sweep (hipdsp_chain_forward's spec_first / env_first), as at the start of the file."""
     from audian_amd.bufferedfilter import BufferedFilter
     from audian_amd.bufferedenvelope import BufferedEnvelope
     from audian_amd.bufferedspectrogram import BufferedSpectrogram
@@ -755,17 +756,20 @@ def test_fused_launch_only_when_the_slabs_coincide(oracle):
         twin['filtered'].highpass_cutoff = 300.0
         twin['filtered'].lowpass_cutoff = 3000.0
         twin['filtered'].update()
-    g.update_times(30.0, 32.0)
-    o.update_times(30.0, 32.0)
-    assert g['envelope'].offset > g['filtered'].offset > 0
-    got = launches_during(g['filtered'].update)
-    o['filtered'].update()
-    aligned = g['spectrogram']._load_geometry(g['spectrogram'].offset, len(g['spectrogram']._hostbuf))[0] == 0
-    if aligned:
-        assert got == {'chain_forward': 1, 'envelope': 1}, got
-    else:
-        assert got == {'sosfilt': 1, 'spectrogram': 1, 'envelope': 1}, got
-    compare(g, o)
+    unaligned = 0
+    for t0 in (30.0, 30.0137, 41.30001, 47.77):
+        g.update_times(t0, t0 + 2.0)
+        o.update_times(t0, t0 + 2.0)
+        assert g['envelope'].offset > g['filtered'].offset > 0
+        got = launches_during(g['filtered'].update)
+        o['filtered'].update()
+        spec = g['spectrogram']
+        first = spec._load_geometry(spec.offset, len(spec._hostbuf))[0]
+        assert 0 <= first < spec.hop
+        unaligned += first != 0
+        assert got == {'chain_forward': 1, 'sosfilt_envelope:2': 1}, (t0, got)
+        compare(g, o)
+    assert unaligned >= 2
     g.update_times(0.0, 2.0)
     o.update_times(0.0, 2.0)
     got = launches_during(g['filtered'].update)

@@ -25,7 +25,7 @@ def synth(rng, n, channels, rate):
 
 def test_library_and_device():
     from audian_amd import _lib, hipdsp
-    assert _lib.lib.hipdsp_version() == 101
+    assert _lib.lib.hipdsp_version() == 102
     c = gh.ctx()
     a = hipdsp.DeviceArray.from_host(c, np.arange(10, dtype=np.float32))
     assert np.array_equal(a.to_host(), np.arange(10, dtype=np.float32))
@@ -800,6 +800,139 @@ def test_chain_forward_other_windows_and_longer_bandpasses(oracle, T, max_segmen
             assert np.array_equal(ps2.to_host(), gs) and np.array_equal(y2.to_host(), gf)
     finally:
         c.set_max_segments(0)
+
+
+SCROLLED = [(0, 48000), (777, 48000), (1, 0), (255, 2047), (1000, 2040), (127, 100003), (5, 2049), (1023, 14), (300, 16),
+            (64, 4095), (0, 1), (511, 6144)]
+
+
+@pytest.mark.parametrize('nfft,hop', [(2048, 1024), (1024, 256), (256, 128), (512, 256), (2048, 512)])
+@pytest.mark.parametrize('T,max_segments', [(8192, 0), (70001, 0), (300000, 0), (300000, 1), (300000, 37), (1500000, 0)])
+def test_chain_forward_at_any_scroll_position(oracle, T, max_segments, nfft, hop):
+    """After a scroll the filtered buffer starts at an arbitrary sample of the recording: the spectrogram's frame 0
+    then starts spec_first = ceil(offset / hop) hop - offset samples into it and the envelope, whose second of pre-roll
+    BufferedData.align_buffer trims (buffereddata.py:75-88), is sosfiltfilt of filtered[env_first:] only.  The fused
+    launch takes both offsets (its tile grid shifts; the tile the envelope starts in holds scipy's odd extension and
+    its steady state): against the oracle on the sliced filtered trace and against the separate calls on the same
+    slices, for offsets on both sides of tile, lane-row and hop borders, one and many segments, with and without
+    spec_frames, and through hipdsp_sosfilt_envelope's own forward sweep (sos_ckpt_kernel) as well."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rate, C = 48000.0, 2
+    rng = np.random.default_rng(T + max_segments + nfft + hop)
+    x = (synth(rng, T, C, rate) + np.float32(0.05)).astype(np.float32)
+    c = gh.ctx()
+    c.set_max_segments(max_segments)
+    F = nfft//2 + 1
+    sos = butter_sos(2, (300.0, 3000.0), 'bandpass', rate)
+    fplan = hipdsp.SosPlan(c, sos)
+    want_f = oracle.sosfilt(sos, x.astype(np.float64))
+    try:
+        dx = gh.to_planar(c, x)
+        f1 = hipdsp.DeviceArray(c, (C, T), np.float32)
+        hipdsp.sosfilt(c, fplan, dx, T, f1, T, C, T, 0)
+        sf = f1.to_host()
+        for i, (spec_first, env_first) in enumerate(SCROLLED):
+            if env_first + 200 >= T or spec_first + nfft >= T:
+                continue
+            esos = butter_sos(*[(2, 20.0), (4, 300.0), (2, (5.0, 200.0))][i % 3],
+                              'bandpass' if i % 3 == 2 else 'lowpass', rate)
+            eplan = hipdsp.SosPlan(c, esos)
+            clamp = i % 3 != 2
+            nsrc = T - spec_first
+            nd = (nsrc + hop - 1)//hop + 1
+            spec_frames = 0 if i % 2 == 0 else max(nfft, nsrc - 3*hop - 7)
+            yf = hipdsp.DeviceArray(c, (C, T), np.float32)
+            ye = hipdsp.DeviceArray(c, (C, T - env_first), np.float32)
+            ps = hipdsp.DeviceArray(c, (C, nd, F), np.float32)
+            for arr, n in ((yf, C*T), (ye, C*(T - env_first)), (ps, C*nd*F)):
+                hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(arr), 0x7f, 4*n)            # every value must be written
+            hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, nfft, hop, rate, ps, nd, spec_frames=spec_frames,
+                                 spec_first=spec_first, env_first=env_first)
+            hipdsp.sosfilt_envelope(c, fplan, eplan, dx, T, yf, T, ye, T - env_first, C, T, clamp=clamp, phase=2,
+                                    env_first=env_first)
+            gf, ge, gs = yf.to_host(), ye.to_host(), ps.to_host()
+            want_e = np.zeros((T - env_first, C))
+            oracle.envelope_process(esos, sf.T[env_first:].astype(np.float64), want_e, 0)
+            if not clamp:
+                want_e = oracle.sosfiltfilt(esos, (np.pi/2)*np.abs(sf.T[env_first:].astype(np.float64)))
+            want_s = np.zeros((nd, C, F))
+            src = sf.T[spec_first:spec_first + (spec_frames or nsrc)].astype(np.float64)
+            oracle.spectrogram_process(src, want_s, rate, nfft, hop)
+            # the separate calls on the same slices
+            e1 = hipdsp.DeviceArray(c, (C, T - env_first), np.float32)
+            hipdsp.envelope(c, eplan, f1.view(env_first, (1,)), T, e1, T - env_first, C, T - env_first, 0, clamp=clamp)
+            se = e1.to_host()
+            what = (T, max_segments, nfft, hop, spec_first, env_first)
+            for ch in range(C):
+                assert rel_err(gf[ch], sf[ch]) < 1e-6, what
+                assert rel_err(gf[ch], want_f[:, ch]) < TOL, what
+                assert np.all(np.isfinite(ge[ch])), what
+                assert rel_err(ge[ch], se[ch]) < 5e-6, what
+                assert rel_err(ge[ch], want_e[:, ch]) < TOL, what
+                # ... also right at the envelope's first samples, where the extension and its steady state act
+                scale = np.max(np.abs(want_e[:, ch]))
+                assert np.max(np.abs(ge[ch][:4096] - want_e[:4096, ch])) < TOL*scale, what
+                for j in range(nd):
+                    if np.max(np.abs(want_s[j, ch])) == 0:
+                        assert np.all(gs[ch, j] == 0), what + (j,)
+                    else:
+                        assert rel_err(gs[ch, j], want_s[j, ch]) < TOL, what + (j,)
+            # the same envelope through hipdsp_sosfilt_envelope's own forward sweep (phase 0, and phases 1 + 2)
+            for phases in ((0,), (1, 2)):
+                y2 = hipdsp.DeviceArray(c, (C, T), np.float32)
+                e2 = hipdsp.DeviceArray(c, (C, T - env_first), np.float32)
+                hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(e2), 0x7f, 4*C*(T - env_first))
+                for ph in phases:
+                    hipdsp.sosfilt_envelope(c, fplan, eplan, dx, T, y2, T, e2, T - env_first, C, T, clamp=clamp, phase=ph,
+                                            env_first=env_first)
+                g2, gy = e2.to_host(), y2.to_host()
+                for ch in range(C):
+                    assert rel_err(gy[ch], sf[ch]) < 1e-6, what
+                    assert rel_err(g2[ch], se[ch]) < 5e-6, what + (phases,)
+                    assert rel_err(g2[ch], want_e[:, ch]) < TOL, what + (phases,)
+            # a backward sweep must be given the envelope start of the forward sweep whose tile states it consumes
+            with pytest.raises(ValueError):
+                hipdsp.sosfilt_envelope(c, fplan, eplan, dx, T, yf, T, ye, T - env_first, C, T, phase=2,
+                                        env_first=env_first + 1)
+            # without an envelope behind the filter, and with the dB epilogue
+            if i % 4 == 0:
+                db = hipdsp.DeviceArray(c, (C, nd, F), np.float32)
+                ps2 = hipdsp.DeviceArray(c, (C, nd, F), np.float32)
+                y3 = hipdsp.DeviceArray(c, (C, T), np.float32)
+                hipdsp.chain_forward(c, fplan, None, dx, T, y3, T, C, T, nfft, hop, rate, ps2, nd, spec_frames=spec_frames,
+                                     spec_first=spec_first, db_out=db)
+                g3 = ps2.to_host()
+                assert np.array_equal(y3.to_host(), gf), what
+                for ch in range(C):
+                    for j in range(nd):
+                        assert np.all(g3[ch, j] == 0) if np.max(np.abs(want_s[j, ch])) == 0 else \
+                            rel_err(g3[ch, j], gs[ch, j]) < 1e-5, what + (j,)
+                gdb, wdb = db.to_host(), oracle.decibel(g3.astype(np.float64))
+                fin = np.isfinite(wdb)
+                assert np.array_equal(np.isfinite(gdb), fin) and np.max(np.abs(gdb[fin] - wdb[fin])) < 1e-3, what
+    finally:
+        c.set_max_segments(0)
+
+
+def test_envelope_start_inside_the_trace_too_short_raises():
+    """frames - env_first <= padlen: scipy's ValueError, as for a slab of that length."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    c = gh.ctx()
+    rate, C, T = 48000.0, 1, 20000
+    fplan = hipdsp.SosPlan(c, butter_sos(2, (300.0, 3000.0), 'bandpass', rate))
+    eplan = hipdsp.SosPlan(c, butter_sos(2, 20.0, 'lowpass', rate))
+    edge = eplan.info()[1]
+    dx = gh.to_planar(c, np.ones((T, C), dtype=np.float32))
+    yf, ye = hipdsp.DeviceArray(c, (C, T), np.float32), hipdsp.DeviceArray(c, (C, T), np.float32)
+    ps = hipdsp.DeviceArray(c, (C, 20, 1025), np.float32)
+    with pytest.raises(ValueError, match='padlen'):
+        hipdsp.sosfilt_envelope(c, fplan, eplan, dx, T, yf, T, ye, T, C, T, env_first=T - edge)
+    with pytest.raises(ValueError, match='padlen'):
+        hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, 2048, 1024, rate, ps, 20, env_first=T - edge)
+    hipdsp.sosfilt_envelope(c, fplan, eplan, dx, T, yf, T, ye, T, C, T, env_first=T - edge - 1)
+    c.synchronize()
 
 
 @pytest.mark.parametrize('T,max_segments', [(8192, 0), (20481, 0), (70001, 0), (300000, 0), (300000, 3), (1500000, 0),

@@ -69,6 +69,27 @@ f.ctx.synchronize()
 dt = (time.perf_counter() - t0)/steps
 print(f'scroll by 5 s: {dt*1e3:.2f} ms per step (raw buffer moved {(g.data.offset - off0)/rate:.0f} s in total)', flush=True)
 
+# the same cut-off sweep in the MIDDLE of the recording: the filtered buffer starts at an arbitrary sample, the
+# spectrogram's frame grid inside its first hop, the envelope one second later (pre-roll trimmed) -- still the fused
+# launch (hipdsp_chain_forward's spec_first / env_first)
+from audian_amd import hipdsp
+g.update_times(130.0137, 140.0137)
+f.update()
+f.ctx.synchronize()
+sp, en = g['spectrogram'], g['envelope']
+before = dict(hipdsp.launches)
+t0 = time.perf_counter()
+for i in range(n):
+    f.highpass_cutoff = 100.0 + 60*i
+    f.lowpass_cutoff = 20000.0 - 500*i
+    f.update()
+f.ctx.synchronize()
+dt_mid = (time.perf_counter() - t0)/n
+per = {k: (v - before.get(k, 0))/n for k, v in hipdsp.launches.items() if v != before.get(k, 0)}
+print(f'facade update_filter mid-recording (filtered offset {f.offset}, spectrogram first frame at sample '
+      f'{sp._load_geometry(sp.offset, len(sp._hostbuf))[0]}, envelope at sample {en.offset - f.offset}): '
+      f'{dt_mid*1e3:.2f} ms per recompute, launches per update {per}', flush=True)
+
 # what audian's own plot items do, unchanged (specitem.py:36, traceitem.py:55-61): they slice one
 # channel out of the buffer -- which now crosses PCIe as that one channel only
 from audian_amd.bufferedspectrogram import decibel
