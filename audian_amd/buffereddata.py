@@ -210,6 +210,7 @@ class BufferedData(BufferedArray):
     _carry = None
     _ctx = None
     _fused_token = False       # the source's own launch has already filled this trace's whole buffer (mirror)
+    _alias_pitch = None        # the mirror is a VIEW of another device array with this row pitch (_alias_mirror)
 
     def __init__(self, name, source_name, tbefore=0, tafter=0, panel='none', panel_type='trace',
                  color='#00ee00', lw_thin=1.1, lw_thick=2):
@@ -243,6 +244,7 @@ class BufferedData(BufferedArray):
         self._stale = []
         self._dev = None
         self._dev_valid = []
+        self._alias_pitch = None
 
     def _buf(self):
         return self._hostbuf
@@ -280,21 +282,45 @@ class BufferedData(BufferedArray):
             n *= int(s)
         return n
 
+    def _pitch(self):
+        """Elements between the rows (channels) of the device mirror."""
+        return self._alias_pitch if self._alias_pitch is not None else len(self._hostbuf)*self._inner()
+
     def _mirror(self):
-        """The device mirror of the current host buffer, allocated on demand."""
+        """The device mirror of the current host buffer, allocated on demand (a mirror that is only a view of
+        another array, _alias_mirror, becomes a real one first: whoever asks is about to write into it)."""
         from . import hipdsp
+        if self._dev is not None and self._alias_pitch is not None:
+            view, pitch, valid = self._dev, self._alias_pitch, list(self._dev_valid)
+            self._dev, self._alias_pitch = None, None
+            n = max(1, len(self._hostbuf)*self._inner())
+            self._dev = hipdsp.DeviceArray(self.ctx, (max(1, self.channels), n), np.float32)
+            for a, b in valid:
+                hipdsp.memcpy2d(self.ctx, self._dev.view(a, (1,)), 4*n, view.view(a, (1,)), 4*pitch, 4*(b - a),
+                                self.channels)
+            self._dev_valid = valid
+            self.ctx.synchronize()
         if self._dev is None:
             n = max(1, len(self._hostbuf)*self._inner())
             self._dev = hipdsp.DeviceArray(self.ctx, (max(1, self.channels), n), np.float32)
             self._dev_valid = []
         return self._dev
 
+    def _alias_mirror(self, array, pitch, call):
+        """The whole buffer of this trace IS frames [0, dnframes) of the rows of `array` (a device array that is not
+        written again while this trace points at it: a slab's device copy, replaced -- never rewritten -- when the slab
+        changes): no copy, the mirror becomes a view that keeps `array` alive.  Any write into the mirror, a buffer
+        move or a new host buffer turns it back into (or replaces it with) a real one."""
+        self._dev, self._alias_pitch = array, int(pitch)
+        self._dev_valid = [[0, call.dnframes]]
+        self._stale = [[0, call.dnframes]]
+
     def _flush(self):
         """Copy the stale frame ranges from the mirror into the host buffer."""
         from . import hipdsp
         stale, self._stale = self._stale, []
         inner = self._inner()
-        pitch = len(self._hostbuf)*inner
+        pitch = self._pitch()
         for a, b in stale:
             n = b - a
             tmp = hipdsp.DeviceArray(self.ctx, (n, self.channels, inner) if inner > 1
@@ -333,8 +359,8 @@ class BufferedData(BufferedArray):
             ch += self.channels
         if not 0 <= ch < self.channels:
             return None                                   # let numpy raise its IndexError
-        inner, n = self._inner(), len(self._hostbuf)
-        block = self._dev.view((ch*n + a)*inner, ((b - a)*inner,)).to_host().astype(np.float64)
+        inner = self._inner()
+        block = self._dev.view(ch*self._pitch() + a*inner, ((b - a)*inner,)).to_host().astype(np.float64)
         block = block.reshape((b - a,) + tuple(self._hostbuf.shape[2:]))
         if isinstance(first, slice):
             out = block[::step]
@@ -363,7 +389,7 @@ class BufferedData(BufferedArray):
     def _adopt_buffer(self, new, offset, old_offset, old_nframes, keep0, keep1):
         """move_buffer recycled the host buffer: recycle the mirror the same way."""
         from . import hipdsp
-        old_dev, old_valid = self._dev, list(self._dev_valid)
+        old_dev, old_valid, old_pitch = self._dev, list(self._dev_valid), self._pitch()
         self.buffer = new            # setter drops mirror and stale marks (host is current)
         self.offset = offset
         if old_dev is not None and keep1 > keep0 and \
@@ -371,7 +397,7 @@ class BufferedData(BufferedArray):
             inner = self._inner()
             dev = self._mirror()
             hipdsp.memcpy2d(self.ctx, dev.view((keep0 - offset)*inner, (1,)), 4*len(new)*inner,
-                            old_dev.view((keep0 - old_offset)*inner, (1,)), 4*old_nframes*inner,
+                            old_dev.view((keep0 - old_offset)*inner, (1,)), 4*old_pitch,
                             4*(keep1 - keep0)*inner, self.channels)
             self._dev_valid = [[keep0 - offset, keep1 - offset]]
             if self._carry:
@@ -414,7 +440,7 @@ class BufferedData(BufferedArray):
         if call is not None and isinstance(src, BufferedData) and src._dev is not None and \
            _covers(src._dev_valid, call.soffset, call.soffset + call.snframes):
             inner = src._inner()
-            return src._dev.view(call.soffset*inner, (1,)), len(src._hostbuf)*inner, None
+            return src._dev.view(call.soffset*inner, (1,)), src._pitch(), None
         if call is not None and isinstance(src, BufferedData) and src._stale:
             source = src.buffer[call.soffset:call.soffset + call.snframes]     # flushes
         n = len(source)
@@ -501,7 +527,7 @@ class BufferedData(BufferedArray):
             return np.zeros(0) if channel is not None else np.zeros((self.channels, 0))
         if self._dev is not None and _covers(self._dev_valid, a, b):
             out = hipdsp.DeviceArray(self.ctx, (self.channels, 2*nseg), np.float32)
-            hipdsp.minmax_decimate(self.ctx, self._dev, n, self.channels, a, b, step, out, 2*nseg)
+            hipdsp.minmax_decimate(self.ctx, self._dev, self._pitch(), self.channels, a, b, step, out, 2*nseg)
             res = out.to_host().astype(np.float64)
         else:
             seg = np.arange(0, b - a, step)

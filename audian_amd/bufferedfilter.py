@@ -69,6 +69,17 @@ class BufferedFilter(BufferedData):
         if len(dest) == 0:
             return
         dsrc, spitch, keep = self._device_source(source, call)
+        if self.sos is None and call is not None and call.doffset == 0 and call.dnframes == len(self._hostbuf) and \
+           not isinstance(self.source, BufferedData) and self._builtin(BufferedFilter) and keep is None and \
+           dsrc.shape == (max(1, self.channels), spitch):
+            # No filter set -- the state a session opens in (bufferedfilter.py:40-42, 32-33: dest = source[nbefore:])
+            # -- and the whole buffer is being (re)computed: nothing is copied.  The filtered trace's device mirror
+            # becomes a VIEW of the raw slab's device copy (kept between recomputes, _device_source: replaced, never
+            # rewritten, when the loader's slab changes), so the spectrogram behind it is the only launch of the
+            # update.  The host semantics are unchanged: the host copy is stale and is read back lazily, like any result.
+            self._fuse = None
+            self._alias_mirror(dsrc.view(nbefore, (dsrc.shape[0]*spitch - nbefore,)), spitch, call)
+            return
         ddst, dpitch, is_mirror = self._device_dest(dest, call)
         fuse, self._fuse = self._fuse, None
         if fuse is not None and is_mirror and nbefore == 0 and call.doffset == 0 and \

@@ -40,7 +40,7 @@ def play_data(trace, t0, t1, show_channels, heterodyne_freq=None):
             raise NotImplementedError('heterodyne playback needs the trace on the device')
         return play, rate
     ctx = trace.ctx
-    cap = len(trace._hostbuf)
+    cap = trace._pitch() if isinstance(trace, BufferedData) else len(trace._hostbuf)
     cps = float(heterodyne_freq)/rate if heterodyne_freq else 0.0
     mixed = hipdsp.DeviceArray(ctx, (len(groups), n), np.float32)
     for k, grp in enumerate(groups):
