@@ -28,6 +28,7 @@ struct hipdsp_ctx {
     int sos_prefetch;      // experiments: register prefetch of the next tile in the envelope sweeps
     int spec_no_half;      // experiments/tests: do not reuse the overlapped half frame
     int spec_fpw, spec_kernel;   // experiments (tools/), 0 = defaults
+    int spec_debug;        // measurements only (results wrong): ablation bits of spec_pack_kernel (spec_pack.h)
     int chain_debug;       // experiments: ablation bits of the fused forward kernel
     int chain_split_frames; // hipdsp_chain_forward writes only the even frames (hipdsp_chain_backward the odd ones)
     int chain_reserve_cus; // CUs hipdsp_chain_forward leaves without a workgroup (room for a co-resident RCCL kernel)

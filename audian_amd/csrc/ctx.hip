@@ -216,6 +216,7 @@ int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value)
     }
     if (strcmp(name, "spec_no_half") == 0) { ctx->spec_no_half = value != 0; return HIPDSP_OK; }
     if (strcmp(name, "spec_kernel") == 0) { ctx->spec_kernel = (int)value; return HIPDSP_OK; }
+    if (strcmp(name, "spec_debug") == 0) { ctx->spec_debug = (int)value; return HIPDSP_OK; }
     if (strcmp(name, "chain_debug") == 0) { ctx->chain_debug = (int)value; return HIPDSP_OK; }
     if (strcmp(name, "sos_no_pin") == 0) { ctx->sos_no_pin = value != 0; return HIPDSP_OK; }
     if (strcmp(name, "sos_fair") == 0) { ctx->sos_fair = value != 0; return HIPDSP_OK; }

@@ -18,14 +18,46 @@
 
 typedef float f4p __attribute__((ext_vector_type(4), aligned(4)));     // float4 that only needs 4-byte alignment
 
+// sum over the LPF (a power of two <= 16) lanes of a lane group, in every lane of the group: DPP adds inside the VALU
+// (the first steps of wave_sum) instead of trips through the LDS crossbar
+template <int LPF>
+__device__ __forceinline__ float group_sum(float v)
+{
+    static_assert(LPF == 1 || LPF == 2 || LPF == 4 || LPF == 8 || LPF == 16, "a lane group is part of a DPP row");
+    if (LPF >= 2) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    if (LPF >= 4) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    if (LPF >= 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+    if (LPF >= 16) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));  // row_mirror
+    return v;
+}
+
+// the value of lane (LPF - l) mod LPF of the same lane group.  Sixteen lanes are one DPP row: mirror (l -> 15 - l), then
+// rotate right by one (l -> l - 1): two VALU moves per dword instead of a ds_bpermute
+template <int LPF>
+__device__ __forceinline__ float2 group_partner(float2 z, int partner)
+{
+    if (LPF == 1) return z;
+    if (LPF == 16) {
+        auto one = [](float x) {
+            const int m = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xf, 0xf, false);      // row_mirror
+            return __int_as_float(__builtin_amdgcn_update_dpp(0, m, 0x121, 0xf, 0xf, false));             // row_ror:1
+        };
+        return make_float2(one(z.x), one(z.y));
+    }
+    return make_float2(__shfl(z.x, partner, 64), __shfl(z.y, partner, 64));
+}
+
 template <int NFFT, int LPF, int R1, int R2, int R3, bool DB>
 __global__ __launch_bounds__(256, 3) void spec_pack_kernel(
     const float *__restrict__ x, long long x_pitch, long long frames, long long n_valid, long long frames_out,
     long long out_pitch, int hop, float scale, const float *__restrict__ tables, float *__restrict__ out,
-    float *__restrict__ db_out, int batches_per_wave)
+    float *__restrict__ db_out, int batches_per_wave, int debug)
 {
+    // debug (option "spec_debug", measurements only, results wrong): 1 = no global stores, 2 = no fetches, 4 = no transform
+
     constexpr int M = NFFT / 2, PPL = M / LPF, G = 64 / LPF, F = M + 1, MP = M + M / 16;
     constexpr bool THREE = R3 > 1;
+    constexpr bool INLANE = NFFT == 256 && LPF == 16 && R1 == 8 && R2 == 4 && R3 == 4;    // see the split step
     static_assert(R1 * R2 * R3 == M && PPL % R1 == 0 && PPL % R2 == 0 && PPL % R3 == 0, "radices");
     constexpr int TW2 = (R2 - 1) * R1, TW3 = THREE ? R1 * R2 : 0, TWN = M / 2 + 1, NTAB = TW2 + TW3 + TWN + M;
     constexpr int RB = 2048;                               // ring: a batch's span (<= 1024 samples) + one fetch
@@ -56,9 +88,62 @@ __global__ __launch_bounds__(256, 3) void spec_pack_kernel(
     float *dc = DB ? db_out + ch * out_pitch : nullptr;
     const long long f0 = ((long long)blockIdx.x * 4 + wave) * (long long)batches_per_wave * G;
     if (f0 >= frames_out) return;                          // (no workgroup barrier below)
-    // samples [ring_end - RB, ring_end) of the channel may sit in the ring; fetches are 1024 samples from a multiple of 4
-    long long ring_end = (f0 * (long long)hop) & ~3LL;
+    // samples [ring_end - RB, ring_end) of the channel may sit in the ring; a fetch is the 1024 samples from a multiple of
+    // 1024 (one half of the ring, 16-byte aligned in the row; a run's first fetch starts up to 4 KB in front of its
+    // first sample -- samples of the same row that the run before this one has just pulled through L2)
+    long long ring_end = (f0 * (long long)hop) & ~(long long)(CHUNK - 1);
     const int partner = g * LPF + ((LPF - l) & (LPF - 1));
+    // what batch `fbx` needs to see in the ring, and what the whole run will need (nothing is fetched beyond that)
+    auto need_of = [&](long long fbx) -> long long {
+        long long nvx = n_valid - fbx;
+        if (nvx > G) nvx = G;
+        return nvx > 0 ? (fbx + nvx - 1) * (long long)hop + NFFT : 0;
+    };
+    long long run_end = 0;
+    {
+        long long lastf = f0 + (long long)batches_per_wave * G;
+        if (lastf > n_valid) lastf = n_valid;
+        if (lastf > f0) run_end = (lastf - 1) * (long long)hop + NFFT;
+    }
+    // The next fetch is always in flight: it is requested as soon as the one before it has gone into the ring and
+    // consumed when the ring runs short -- between a batch's arithmetic and its stores, a batch or two later.
+    float4 pend[CHUNK / 256];
+    bool pend_ok = false;
+    auto request = [&](long long pos) {
+        if (pos + CHUNK <= frames) {                           // (wave-uniform) the whole fetch lies inside the trace
+#pragma unroll
+            for (int k = 0; k < CHUNK / 256; k++) {
+                const f4p t = *reinterpret_cast<const f4p *>(xc + pos + 256 * k + 4 * lane);
+                pend[k] = make_float4(t.x, t.y, t.z, t.w);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < CHUNK / 256; k++) {
+                const long long p = pos + 256 * k + 4 * lane;
+                pend[k].x = p < frames ? xc[p] : 0.f;
+                pend[k].y = p + 1 < frames ? xc[p + 1] : 0.f;
+                pend[k].z = p + 2 < frames ? xc[p + 2] : 0.f;
+                pend[k].w = p + 3 < frames ? xc[p + 3] : 0.f;
+            }
+        }
+    };
+    auto refill = [&](long long need) {
+        while (ring_end < need) {
+            if (debug & 2) { ring_end += CHUNK; continue; }
+            if (!pend_ok) request(ring_end);
+            const int rbase = (int)(ring_end & (RB - 1));      // 0 or CHUNK: no wrap inside a fetch
+#pragma unroll
+            for (int k = 0; k < CHUNK / 256; k++)
+                *reinterpret_cast<float4 *>(ring + rbase + 256 * k + 4 * lane) = pend[k];
+            if (rbase == 0 && lane == 0) ring[RB] = pend[0].x;
+            ring_end += CHUNK;
+            pend_ok = ring_end < run_end;
+            if (pend_ok) request(ring_end);
+        }
+    };
+    refill(need_of(f0));
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
     for (int b = 0; b < batches_per_wave; b++) {
         const long long fb0 = f0 + (long long)b * G;       // first frame of the batch (wave-uniform)
@@ -68,59 +153,105 @@ __global__ __launch_bounds__(256, 3) void spec_pack_kernel(
         long long nv = n_valid - fb0;
         const int nval = nv <= 0 ? 0 : (nv < G ? (int)nv : G);   // of which hold a spectrum
         const bool valid = g < nval;
-        if (nval > 0) {
-            const long long need_end = (fb0 + nval - 1) * (long long)hop + NFFT;      // <= frames
-            while (ring_end < need_end) {
-#pragma unroll
-                for (int k = 0; k < CHUNK / 256; k++) {
-                    const long long p = ring_end + 256 * k + 4 * lane;
-                    float4 v;
-                    if (p + 4 <= frames) {
-                        const f4p t = *reinterpret_cast<const f4p *>(xc + p);
-                        v = make_float4(t.x, t.y, t.z, t.w);
-                    } else {
-                        v.x = p < frames ? xc[p] : 0.f;
-                        v.y = p + 1 < frames ? xc[p + 1] : 0.f;
-                        v.z = p + 2 < frames ? xc[p + 2] : 0.f;
-                        v.w = p + 3 < frames ? xc[p + 3] : 0.f;
-                    }
-                    const int ri = (int)(p & (RB - 1));
-                    *reinterpret_cast<float4 *>(ring + ri) = v;
-                    if (ri == 0) ring[RB] = v.x;
-                }
-                ring_end += CHUNK;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
         // ---- the batch's frames, one per lane group, out of the ring
         float2 v[PPL];
         {
-            const long long s0 = (fb0 + (valid ? g : 0)) * (long long)hop;
-            float s = 0.f;
+            const int r0 = (int)(((fb0 + (valid ? g : 0)) * (long long)hop) & (RB - 1)) + 2 * l;
+            v2f acc = {0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < PPL / R1; u++)
 #pragma unroll
                 for (int t = 0; t < R1; t++) {
-                    const int n = l + LPF * u + t * (M / R1);
-                    const int ri = (int)((s0 + 2 * n) & (RB - 1));
-                    const float a = ring[ri], c = ring[ri + 1];
-                    v[u * R1 + t] = make_float2(a, c);
-                    s += a + c;
+                    const int ri = (r0 + 2 * (LPF * u + t * (M / R1))) & (RB - 1);
+                    const v2f e = {ring[ri], ring[ri + 1]};
+                    v[u * R1 + t] = as_f2(e);
+                    acc += e;
                 }
-#pragma unroll
-            for (int d = LPF / 2; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-            const float mean = s * (1.0f / (float)NFFT);
+            const float mean = group_sum<LPF>(acc.x + acc.y) * (1.0f / (float)NFFT);
+            const v2f mean2 = {mean, mean};
 #pragma unroll
             for (int u = 0; u < PPL / R1; u++)
 #pragma unroll
                 for (int t = 0; t < R1; t++) {
-                    const float2 w = win[l + LPF * u + t * (M / R1)];
                     float2 &e = v[u * R1 + t];
-                    e = make_float2((e.x - mean) * w.x, (e.y - mean) * w.y);
+                    e = as_f2((as_v2f(e) - mean2) * as_v2f(win[l + LPF * u + t * (M / R1)]));
                 }
         }
         constexpr int RL = THREE ? R3 : R2, NBL = PPL / RL;          // the last stage's radix
+        float *sg = stage + g * F;
+        const bool full = nval == G;                                 // (wave-uniform: the masks only in a run's last batch)
+        const v2f hscale2 = {0.5f * scale, 0.5f * scale};
+        // one pair of bins: X[k] = E + W^k O, X[M-k] = conj(E - W^k O) from Z[k] and Z[M-k]; the halves go into the scale
+        auto pair_psd = [&](float2 zk, float2 zm, int k, float &pk, float &pm) {
+            const v2f e = pk_add_conj(as_v2f(zk), as_v2f(zm));
+            const v2f t = pk_cmul_negi(pk_sub_conj(as_v2f(zk), as_v2f(zm)), as_v2f(twn[k]));
+            const v2f re = pk_sumdiff_x(e, t), im = pk_sumdiff_y(e, t);
+            const v2f pw = (re * re + im * im) * hscale2;
+            pk = pw.x; pm = pw.y;
+        };
+        if (debug & 4) {
+#pragma unroll
+            for (int m = 0; m < PPL; m++) { sg[l + LPF * m] = v[m].x; }
+            if (l == 0) sg[M] = v[0].y;
+        } else if constexpr (INLANE) {
+            // nfft 256 (M = 128 = 8 x 4 x 4, sixteen lanes per frame): the last stage's butterfly j produces the bins
+            // j + 32 t, and the partner of bin k is bin 128 - k: butterfly j pairs with butterfly 32 - j.  Which
+            // butterflies a lane takes is only a matter of the LDS addresses it loads from, so lane l takes j = l AND
+            // j = 32 - l (lane 0: the two self-paired ones, 0 and 16) and finds every partner in its own registers --
+            // no exchange between lanes in the split step at all.
+            stockham_stage<R1, 1, M, LPF, false, true>(v, fb, tw2, l);
+            stockham_stage<R2, R1, M, LPF, true, true>(v, fb, tw2, l);
+            const int jb = (l == 0) ? 16 : 32 - l;
+            float2 A[4], B[4];
+            {
+                const int pa = pad16(l), pb = pad16(jb);
+#pragma unroll
+                for (int t = 0; t < 4; t++) {                        // pad16(j + 32 t) = pad16(j) + 34 t
+                    A[t] = fb[pa + 34 * t];
+                    B[t] = fb[pb + 34 * t];
+                }
+                const v2f wa = as_v2f(tw3[l]), wb = as_v2f(tw3[jb]);
+                v2f qa = wa, qb = wb;
+#pragma unroll
+                for (int t = 1; t < 4; t++) {
+                    A[t] = as_f2(pk_cmul(as_v2f(A[t]), qa));
+                    B[t] = as_f2(pk_cmul(as_v2f(B[t]), qb));
+                    if (t < 3) { qa = pk_cmul(qa, wa); qb = pk_cmul(qb, wb); }
+                }
+                dft<4>(A);
+                dft<4>(B);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // pairs (low bin k < 64, its partner 128 - k): lanes 1..15: (A0, B3) k = l; (A1, B2) k = 32 + l; (B1, A2)
+            // k = 64 - l; (B0, A3) k = 32 - l.  Lane 0: A0 = DC and Nyquist; (A1, A3) k = 32; (B1, B2) k = 48;
+            // (B0, B3) k = 16; A2 = bin 64, which pairs with itself.
+            const bool l0 = l == 0;
+            float pk[4], pm[4];
+            int kk[4];
+            kk[0] = l; kk[1] = 32 + l; kk[2] = l0 ? 48 : 64 - l; kk[3] = l0 ? 16 : 32 - l;
+            pair_psd(A[0], B[3], kk[0], pk[0], pm[0]);
+            pair_psd(A[1], l0 ? A[3] : B[2], kk[1], pk[1], pm[1]);
+            pair_psd(B[1], l0 ? B[2] : A[2], kk[2], pk[2], pm[2]);
+            pair_psd(B[0], l0 ? B[3] : A[3], kk[3], pk[3], pm[3]);
+            {
+                const float dc0 = A[0].x + A[0].y, ny = A[0].x - A[0].y;     // DC and Nyquist, not doubled
+                pk[0] = l0 ? dc0 * dc0 * scale : pk[0];
+                pm[0] = l0 ? ny * ny * scale : pm[0];
+            }
+            float ph = 2.f * scale * (A[2].x * A[2].x + A[2].y * A[2].y);
+            if (!full) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) { pk[t] = valid ? pk[t] : 0.f; pm[t] = valid ? pm[t] : 0.f; }
+                ph = valid ? ph : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                sg[kk[t]] = pk[t];
+                sg[M - kk[t]] = pm[t];
+            }
+            if (l0) sg[M / 2] = ph;
+        } else {
         if constexpr (THREE) {
             stockham_stage<R1, 1, M, LPF, false, true>(v, fb, tw2, l);
             stockham_stage<R2, R1, M, LPF, true, true>(v, fb, tw2, l);
@@ -132,70 +263,82 @@ __global__ __launch_bounds__(256, 3) void spec_pack_kernel(
         // v[(m % NBL) * RL + m / NBL] = Z[k], k = l + LPF m.  Split step for m < PPL / 2 (k < M / 2); the partner bin
         // M - k sits in lane LPF - l at m' = PPL - 1 - m (lane 0: in itself at m' = PPL - m).  The bins go into the
         // staging area (the frame buffers are dead: every lane's last LDS load of the transform has been issued, and
-        // LDS operations of a wave execute in order).
+        // LDS operations of a wave execute in order).  Same packed arithmetic as spec_fast_kernel.
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        float *sg = stage + g * F;
+        float pk_last = 0.f;
 #pragma unroll
         for (int m = 0; m < PPL / 2; m++) {
             const int k = l + LPF * m;
             const float2 zk = v[(m % NBL) * RL + m / NBL];
             const int mp = PPL - 1 - m;
             const float2 zsrc = v[(mp % NBL) * RL + mp / NBL];
-            float2 zm;
-            if (LPF > 1) {
-                zm.x = __shfl(zsrc.x, partner, 64);
-                zm.y = __shfl(zsrc.y, partner, 64);
-            } else {
-                zm = zsrc;
-            }
+            float2 zm = group_partner<LPF>(zsrc, partner);
             if (m > 0) {
                 const int m0 = PPL - m;                              // lane 0 pairs inside itself
                 const float2 z0 = v[(m0 % NBL) * RL + m0 / NBL];
-                if (l == 0) zm = z0;
+                zm = (l == 0) ? z0 : zm;
             }
             float pk, pm;
-            if (m == 0 && l == 0) {
-                const float a = zk.x + zk.y, c = zk.x - zk.y;        // DC and Nyquist, not doubled
-                pk = a * a * scale;
-                pm = c * c * scale;
-            } else {
-                const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-                const float2 o = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
-                const float2 t = cmul(o, twn[k]);
-                const float2 a = cadd(e, t), c = csub(e, t);
-                pk = 2.f * scale * (a.x * a.x + a.y * a.y);
-                pm = 2.f * scale * (c.x * c.x + c.y * c.y);
+            pair_psd(zk, zm, k, pk, pm);
+            if (m == 0) {
+                const float dc0 = zk.x + zk.y, ny = zk.x - zk.y;     // DC and Nyquist, not doubled
+                pk = (l == 0) ? dc0 * dc0 * scale : pk;
+                pm = (l == 0) ? ny * ny * scale : pm;
             }
-            sg[k] = valid ? pk : 0.f;
-            sg[M - k] = valid ? pm : 0.f;
+            if (!full) { pk = valid ? pk : 0.f; pm = valid ? pm : 0.f; }
+            sg[k] = pk;
+            sg[M - k] = pm;
+            pk_last = pk;
         }
-        if (l == 0) {                                                // k = M / 2 pairs with itself
+        {   // bin M / 2 pairs with itself (lane 0); the other lanes repeat their last store
             constexpr int mh = PPL / 2;
             const float2 z = v[(mh % NBL) * RL + mh / NBL];
-            sg[M / 2] = valid ? 2.f * scale * (z.x * z.x + z.y * z.y) : 0.f;
+            float ph = 2.f * scale * (z.x * z.x + z.y * z.y);
+            if (!full) ph = valid ? ph : 0.f;
+            sg[(l == 0) ? M / 2 : l + LPF * (PPL / 2 - 1)] = (l == 0) ? ph : pk_last;
         }
+        }
+        // the ring for the NEXT batch (this batch has read its frames): the fetch consumed here was requested a batch or
+        // two ago, and this batch's stores are not yet in the queue behind it
+        if (b + 1 < batches_per_wave) refill(need_of(fb0 + G));
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ---- nfr * F consecutive floats of the channel's spectrogram
         {
-            const int total = nfr * F;
-            float *o = oc + fb0 * (long long)F;
-            float *od = DB ? dc + fb0 * (long long)F : nullptr;
-            for (int i = 4 * lane; i < total; i += 256) {
+            float *o = oc + ((debug & 1) ? 0 : fb0 * (long long)F);    // (1: every batch lands on the channel's first frames)
+            float *od = DB ? dc + ((debug & 1) ? 0 : fb0 * (long long)F) : nullptr;
+            auto put4 = [&](int i) {
                 const float4 p = *reinterpret_cast<const float4 *>(stage + i);
-                if (i + 4 <= total) {
-                    f4p t; t.x = p.x; t.y = p.y; t.z = p.z; t.w = p.w;
-                    *reinterpret_cast<f4p *>(o + i) = t;
-                    if (DB) {
-                        f4p d; d.x = to_db(p.x); d.y = to_db(p.y); d.z = to_db(p.z); d.w = to_db(p.w);
-                        *reinterpret_cast<f4p *>(od + i) = d;
-                    }
-                } else {
-                    const float e[4] = {p.x, p.y, p.z, p.w};
-                    for (int q = 0; q < 4 && i + q < total; q++) {
-                        o[i + q] = e[q];
-                        if (DB) od[i + q] = to_db(e[q]);
+                f4p t; t.x = p.x; t.y = p.y; t.z = p.z; t.w = p.w;
+                *reinterpret_cast<f4p *>(o + i) = t;
+                if (DB) {
+                    f4p d; d.x = to_db(p.x); d.y = to_db(p.y); d.z = to_db(p.z); d.w = to_db(p.w);
+                    *reinterpret_cast<f4p *>(od + i) = d;
+                }
+            };
+            if (nfr == G) {
+                constexpr int TOTAL = G * F, NV = TOTAL / 4;         // whole float4s, then up to three floats
+#pragma unroll
+                for (int k = 0; k < (NV + 63) / 64; k++) {
+                    const int i = 4 * (lane + 64 * k);
+                    if (k < NV / 64 || lane + 64 * k < NV) put4(i);
+                }
+                if (lane < TOTAL - 4 * NV) {
+                    const float e = stage[4 * NV + lane];
+                    o[4 * NV + lane] = e;
+                    if (DB) od[4 * NV + lane] = to_db(e);
+                }
+            } else {
+                const int total = nfr * F;
+                for (int i = 4 * lane; i < total; i += 256) {
+                    if (i + 4 <= total) {
+                        put4(i);
+                    } else {
+                        for (int q = 0; i + q < total; q++) {
+                            o[i + q] = stage[i + q];
+                            if (DB) od[i + q] = to_db(stage[i + q]);
+                        }
                     }
                 }
             }
@@ -225,9 +368,9 @@ int run_pack(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long chann
     const dim3 grid((unsigned)bx, (unsigned)channels), block(256);
     if (db_out)
         hipLaunchKernelGGL((spec_pack_kernel<NFFT, LPF, R1, R2, R3, true>), grid, block, 0, ctx->stream, x, x_pitch, frames,
-                           n_valid, frames_out, out_pitch, hop, scale, tables, out, db_out, (int)bpw);
+                           n_valid, frames_out, out_pitch, hop, scale, tables, out, db_out, (int)bpw, ctx->spec_debug);
     else
         hipLaunchKernelGGL((spec_pack_kernel<NFFT, LPF, R1, R2, R3, false>), grid, block, 0, ctx->stream, x, x_pitch, frames,
-                           n_valid, frames_out, out_pitch, hop, scale, tables, out, db_out, (int)bpw);
+                           n_valid, frames_out, out_pitch, hop, scale, tables, out, db_out, (int)bpw, ctx->spec_debug);
     return hd_launch_status("spec_pack_kernel");
 }

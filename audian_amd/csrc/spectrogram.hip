@@ -1082,6 +1082,8 @@ int run_fast(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long chann
                                                      hop, scale, tables, out, db_out);
 }
 
+#include "spec_pack.h"
+
 template <int NFFT, int LPF, int R1, int R2, int R3, int OCC>
 int run_wg(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long channels, long long n_valid,
            long long frames_out, long long out_pitch, int hop, float scale, float *out, float *db_out)
@@ -1170,16 +1172,27 @@ extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pit
         // spec_kernel: 0 = default choice per size, 2 = two-stage kernel, 3 = three-stage kernel
         const int want = ctx->spec_kernel;
         switch (nfft) {
-        // short windows: 64 (one frame per lane), 32, 16 or 8 frames side by side in a wave
-        // (two-stage kernel)
-        case 8: return run_fast2<8, 1, 2, 2, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
-        case 16: return run_fast2<16, 1, 4, 2, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
-        case 32: return run_fast2<32, 2, 8, 2, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
-        case 64: return run_fast2<64, 4, 8, 4, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
-        case 128: return run_fast2<128, 8, 8, 8, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+        // short windows: 64 (one frame per lane), 32, 16, 8 or 4 frames side by side in a wave that streams a run of
+        // consecutive frames through LDS (spec_pack.h); "spec_kernel" 2 / 3: the kernels they replaced, as cross-checks
+        case 8:
+            if (want == 2) return run_fast2<8, 1, 2, 2, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+            return run_pack<8, 1, 2, 2, 1>(ctx, x, x_pitch, channels, frames, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+        case 16:
+            if (want == 2) return run_fast2<16, 1, 4, 2, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+            return run_pack<16, 1, 4, 2, 1>(ctx, x, x_pitch, channels, frames, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+        case 32:
+            if (want == 2) return run_fast2<32, 2, 8, 2, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+            return run_pack<32, 2, 8, 2, 1>(ctx, x, x_pitch, channels, frames, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+        case 64:
+            if (want == 2) return run_fast2<64, 4, 8, 4, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+            return run_pack<64, 4, 8, 4, 1>(ctx, x, x_pitch, channels, frames, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+        case 128:
+            if (want == 2) return run_fast2<128, 8, 8, 8, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+            return run_pack<128, 8, 8, 8, 1>(ctx, x, x_pitch, channels, frames, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
         case 256:
             if (want == 2) return run_fast2<256, 8, 16, 8, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
-            return run_fast<256, 16, 8, 4, 4, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+            if (want == 3) return run_fast<256, 16, 8, 4, 4, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+            return run_pack<256, 16, 8, 4, 4>(ctx, x, x_pitch, channels, frames, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
         case 512:
             if (want == 2) return run_fast2<512, 16, 16, 16, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
             return run_fast<512, 32, 8, 8, 4, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);

@@ -297,6 +297,62 @@ def test_spectrogram_fast_and_generic_vs_oracle(oracle, nfft, hop):
                     assert rel_err(res[j, ch], want[j, ch]) < TOL, (nfft, hop, j, ch)
 
 
+@pytest.mark.parametrize('nfft', [8, 16, 32, 64, 128, 256])
+def test_short_windows_stream_runs_of_frames_through_lds(oracle, nfft):
+    """nfft 8 ... 256 (the reference's default is 256 / 128; its selector starts at 8, databrowser.py:516): a wave
+    streams a run of consecutive frames through an LDS ring and stores whole batches of frames (spec_pack.h).  Every
+    overlap the spin box can produce (databrowser.py:522-529: hop 1 ... nfft), runs long enough that every wave walks
+    many batches and the ring wraps many times, odd channel pitches (4-byte aligned rows only), more output frames than
+    the trace holds (zero tail), the dB image next to the PSD, against the oracle and the kernels replaced."""
+    from audian_amd import hipdsp
+    rate, C = 48000.0, 3
+    c = gh.ctx()
+    rng = np.random.default_rng(nfft)
+    hops = sorted({1, 2, 3, nfft//4, nfft//2, nfft//2 + 1, nfft - 1, nfft, max(1, int(nfft*0.37))})
+    for hop in hops:
+        nframes = 5000 if hop > 2 else 1500
+        T = (nframes - 1)*hop + nfft + int(rng.integers(0, hop + 1))
+        pitch = T + int(rng.integers(0, 7))
+        x = (synth(rng, T, C, rate) + np.float32(0.1)).astype(np.float32)
+        dx = hipdsp.DeviceArray(c, (C, pitch), np.float32)
+        dx.copy_from_host(np.pad(x.T, ((0, 0), (0, pitch - T)), constant_values=np.float32(7e9)))
+        nd = (T + hop - 1)//hop + 3
+        F = nfft//2 + 1
+        want = np.zeros((nd, C, F))
+        oracle.spectrogram_process(x.astype(np.float64), want, rate, nfft, hop)
+        out = hipdsp.DeviceArray(c, (C, nd, F), np.float32)
+        db = hipdsp.DeviceArray(c, (C, nd, F), np.float32)
+        for fpw in (0, 1, 3):
+            c.set_option('spec_fpw', fpw)
+            try:
+                for arr in (out, db):
+                    hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(arr), 0x7f, 4*C*nd*F)
+                hipdsp.spectrogram(c, dx, pitch, C, T, nfft, hop, rate, out, nd, db_out=db if fpw != 1 else None)
+            finally:
+                c.set_option('spec_fpw', 0)
+            got = out.to_host()
+            for ch in range(C):
+                zero = np.max(np.abs(want[:, ch]), axis=1) == 0
+                assert np.all(got[ch][zero] == 0), (nfft, hop, fpw)
+                num = np.max(np.abs(got[ch][~zero] - want[~zero, ch]), axis=1)
+                den = np.max(np.abs(want[~zero, ch]), axis=1)
+                assert np.max(num/den) < TOL, (nfft, hop, fpw, ch, int(np.argmax(num/den)))
+            if fpw != 1:
+                gdb, wdb = db.to_host(), oracle.decibel(got.astype(np.float64))
+                fin = np.isfinite(wdb)
+                assert np.array_equal(np.isfinite(gdb), fin) and np.all(gdb[~fin] == -np.inf), (nfft, hop)
+                assert np.max(np.abs(gdb[fin] - wdb[fin])) < 1e-3, (nfft, hop)
+        c.set_option('spec_kernel', 2)
+        try:
+            old = hipdsp.DeviceArray(c, (C, nd, F), np.float32)
+            hipdsp.spectrogram(c, dx, pitch, C, T, nfft, hop, rate, old, nd)
+        finally:
+            c.set_option('spec_kernel', 0)
+        o = old.to_host()
+        scale = np.maximum(np.max(np.abs(o), axis=2, keepdims=True), 1e-30)
+        assert np.max(np.abs(got - o)/scale) < 1e-5, (nfft, hop)
+
+
 def test_spectrogram_short_source_and_db(oracle):
     x = np.ones((100, 2), dtype=np.float32)
     got = gh.gpu_spectrogram(x, 48000.0, 256, 128, 3)

@@ -65,3 +65,50 @@ for nfft, hop in ((2048, 1024), (1024, 256), (256, 128), (8192, 4096), (65536, 3
         line('hipdsp_decibel over the PSD', timed(lambda: hipdsp.decibel(ctx, ds, out, C*nd*F)), 8.0*C*nd*F)
         del out
     del ds
+
+# ---- the reference's DEFAULT session through the plug-in surface: no filter set (bufferedfilter.py:40-42) + spectrogram
+# 256 / 128 (plugins.py:11-13, bufferedspectrogram.py:14-16), whole recording resident: BufferedFilter.update() ->
+# recompute_all().  The filtered trace's mirror is a view of the raw slab's device copy (no launch), the spectrogram is
+# the only launch.
+if os.environ.get('FACADE', '1') == '1':
+    import time
+    from audian_amd.bufferedfilter import BufferedFilter
+    from audian_amd.bufferedspectrogram import BufferedSpectrogram
+    from audian_amd.tracegraph import TraceGraph
+    del df, de
+    host = np.empty((T, C), dtype=np.float32)
+    chunk = 1 << 20
+    tmp = hipdsp.DeviceArray(ctx, (chunk, C), np.float64)
+    for a in range(0, T, chunk):
+        n = min(chunk, T - a)
+        hipdsp.unpack(ctx, dx.view(a, (1,)), T, tmp, n, C)
+        host[a:a + n] = tmp.to_host().reshape(-1)[:n*C].reshape(n, C)
+    tmp.free()
+    del dx
+    hipdsp._default_ctx = ctx
+
+    class Shown:
+        def isVisible(self):
+            return True
+
+    g = TraceGraph(T/rate, 0.0)
+    filt, spec = BufferedFilter(), BufferedSpectrogram()          # the defaults: 256, 50 % overlap
+    g.add_trace(filt)
+    g.add_trace(spec)
+    g.setup_traces()
+    g.open(host, rate, view=True)
+    for t in g.traces:
+        t.plot_items = [Shown() for _ in range(t.channels)]
+    g.set_need_update()
+    g.update_times(0.0, T/rate)
+    filt.update()
+    ctx.synchronize()
+    before = dict(hipdsp.launches)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        filt.update()
+    ctx.synchronize()
+    ms = (time.perf_counter() - t0)/5*1e3
+    per = {k: (v - before.get(k, 0))//5 for k, v in hipdsp.launches.items() if v != before.get(k, 0)}
+    nd = len(spec._hostbuf)
+    line(f'default session (no filter + 256/128) through BufferedFilter.update(), launches {per}', ms, 4.0*S + 4.0*C*nd*129)
