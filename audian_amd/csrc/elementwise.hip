@@ -57,37 +57,50 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
 
 // Screen-resolution dB image of one channel: column c = max over the frames
 // [start + c*step, min(start + (c+1)*step, stop)) of the (frames, F) slab (np.maximum.reduceat, NaN
-// propagates), then dB, written transposed as (F, ncols).  32 bins x 32 columns per workgroup; a
-// row of 32 lanes reads 128 contiguous bytes per frame.
+// propagates), then dB, written transposed as (F, ncols).  32 bins x CPB columns per workgroup; a
+// row of 32 lanes reads 128 contiguous bytes per frame, four frames in flight per thread.  CPB = 32 for short
+// columns (each of the eight thread rows walks four columns); long columns (step >= 8) take CPB = 8 -- one column per
+// thread row, four times the workgroups: an image is a few hundred workgroups at most, and a thread that walks
+// 4 x 28 frames one load at a time leaves the chip idle (268 columns of 28 frames ran at 0.93 TB/s).
+__device__ __forceinline__ float db_np_max(float v, float w) { return (w > v || w != w) ? w : v; }   // NaN wins, like np.maximum
+
+template <int CPB>
 __global__ __launch_bounds__(256) void db_image_decimate_kernel(const float *__restrict__ src,
                                                                 float *__restrict__ dst, long long start,
                                                                 long long stop, long long step, long long ncols,
                                                                 long long F, float inv_ref, float min_power)
 {
-    __shared__ float tile[32][33];
+    __shared__ float tile[CPB][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 bins x 8 columns at a time
-    const long long f0 = (long long)blockIdx.x * 32, c0 = (long long)blockIdx.y * 32;
+    const long long f0 = (long long)blockIdx.x * 32, c0 = (long long)blockIdx.y * CPB;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < CPB / 8; k++) {
         const long long c = c0 + ty + 8 * k, f = f0 + tx;
         float v = 0.f;
         if (c < ncols && f < F) {
             const long long a = start + c * step;
             const long long b = a + step < stop ? a + step : stop;
-            v = src[a * F + f];
-            for (long long r = a + 1; r < b; r++) {
-                const float w = src[r * F + f];
-                v = (w > v || w != w) ? w : v;                   // NaN wins, like np.maximum
+            const float *p = src + a * F + f;
+            v = p[0];
+            long long r = a + 1;
+            for (; r + 4 <= b; r += 4) {                         // four independent loads in flight
+                const float w0 = src[r * F + f], w1 = src[(r + 1) * F + f], w2 = src[(r + 2) * F + f],
+                            w3 = src[(r + 3) * F + f];
+                v = db_np_max(db_np_max(db_np_max(db_np_max(v, w0), w1), w2), w3);
             }
+            for (; r < b; r++) v = db_np_max(v, src[r * F + f]);
             v = (v <= min_power) ? -INFINITY : 10.0f * log10f(v * inv_ref);
         }
         tile[ty + 8 * k][tx] = v;
     }
     __syncthreads();
+    // 32 x CPB values out: consecutive lanes write consecutive columns of one bin
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const long long f = f0 + ty + 8 * k, c = c0 + tx;
-        if (f < F && c < ncols) dst[f * ncols + c] = tile[tx][ty + 8 * k];
+    for (int k = 0; k < CPB / 8; k++) {
+        const int idx = threadIdx.x + 256 * k;
+        const int cc = idx % CPB, ff = idx / CPB;
+        const long long fo = f0 + ff, c = c0 + cc;
+        if (fo < F && c < ncols) dst[fo * ncols + c] = tile[cc][ff];
     }
 }
 
@@ -176,6 +189,58 @@ __global__ __launch_bounds__(256) void pcm_unpack_kernel(const unsigned char *__
     }
 }
 
+// The same for the shapes a recording usually has -- 16- or 32-bit samples, a multiple of 8 (4) channels -- with 16-byte
+// accesses on both sides (the kernel above reads single BYTES: 3.2 TB/s of 6 B per int16 sample): a workgroup takes
+// 128 frames x TC channels; a thread loads 16 bytes = 8 (4) channels of one frame, the values cross over through an
+// LDS tile (rows of 129 floats: the transposed stores spread over the banks), and leave as 16-byte stores, 512 bytes
+// per channel row.
+template <int BYTES, int TC>
+__global__ __launch_bounds__(256) void pcm_unpack_tile_kernel(const unsigned char *__restrict__ pcm, float *__restrict__ dst,
+                                                              long long pitch, long long T, long long C, float scale)
+{
+    constexpr int TF = 128, P = TF + 1;
+    constexpr int SPV = 16 / BYTES;                    // samples per 16-byte vector
+    constexpr int VPF = TC / SPV;                      // vectors per frame of the tile
+    constexpr int FPP = 256 / VPF;                     // frames per pass of the 256 threads
+    __shared__ float tile[TC * P];
+    const long long t0 = (long long)blockIdx.x * TF, c0 = (long long)blockIdx.y * TC;
+    const int vi = threadIdx.x % VPF, fi = threadIdx.x / VPF;
+    const double sc = (double)scale;
+#pragma unroll
+    for (int k = 0; k < (TF + FPP - 1) / FPP; k++) {
+        const int f = fi + FPP * k;
+        const long long t = t0 + f;
+        if (f < TF && t < T) {
+            const uint4 raw = *reinterpret_cast<const uint4 *>(pcm + ((t * C + c0) * BYTES + 16 * vi));
+            const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int q = 0; q < SPV; q++) {
+                int iv;
+                if (BYTES == 2) iv = (int)(short)((w[q >> 1] >> (16 * (q & 1))) & 0xffffu);
+                else iv = (int)w[q];
+                tile[(SPV * vi + q) * P + f] = (float)((double)iv * sc);
+            }
+        }
+    }
+    __syncthreads();
+    // TC rows of TF floats out: a thread stores four consecutive frames of one channel
+#pragma unroll
+    for (int k = 0; k < (TC * (TF / 4) + 255) / 256; k++) {
+        const int idx = threadIdx.x + 256 * k;
+        if (idx >= TC * (TF / 4)) break;
+        const int c = idx / (TF / 4), f = 4 * (idx % (TF / 4));
+        const long long t = t0 + f;
+        float *o = dst + (c0 + c) * pitch + t;
+        const float *r = tile + c * P + f;
+        if (t + 4 <= T) {
+            db_f4 v; v.x = r[0]; v.y = r[1]; v.z = r[2]; v.w = r[3];
+            *reinterpret_cast<db_f4 *>(o) = v;
+        } else {
+            for (int q = 0; q < 4 && t + q < T; q++) o[q] = r[q];
+        }
+    }
+}
+
 // Playback chain (DataBrowser.play_region, databrowser.py:1711-1729): mean over a group of
 // channels of frames [start, start + n), optionally times the heterodyne carrier
 // sin(2 pi f k / rate) with k counted from the start of the region.
@@ -240,41 +305,123 @@ __device__ __forceinline__ float np_max(float a, float b) { return (a > b || a !
 // Screen-resolution decimation of traces (TraceItem.update_plot, src/audian/traceitem.py:55-61;
 // compresseddata.py:48-52): out[c][2i] = min, out[c][2i+1] = max of x[c][start + i*step :
 // min(start + (i+1)*step, stop)]  (np.minimum/maximum.reduceat over arange(0, stop-start, step)).
-// A group of GL lanes (a power of two >= min(step, 64)) owns a segment and strides over it, so
-// a wave always reads (nearly) contiguous memory whatever the step; 64/GL segments per wave.
-template <int GL>
-__global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ x, long long pitch,
-                                                     long long start, long long stop, long long step,
-                                                     long long nseg, float *__restrict__ out,
-                                                     long long out_pitch)
+// A pure read stream: whatever the step, the samples leave HBM as 16-byte accesses of consecutive lanes
+// (round 1's kernel let GL lanes stride over a segment with 4-byte loads: 3.6 TB/s at step 28800, 1.4 at step 32).
+// NaN: np.minimum / np.maximum return NaN if either operand is one; v_min / v_max return the other operand, so a
+// flag rides along and the segment's pair becomes NaN at the end.
+typedef float mm_f4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float mm_f2 __attribute__((ext_vector_type(2), aligned(4)));
+struct MinMax {
+    float mn, mx;
+    bool bad;
+    __device__ __forceinline__ void take(float v) { mn = fminf(mn, v); mx = fmaxf(mx, v); bad = bad || v != v; }
+};
+
+// long segments (step >= 512): one wave per segment, four 16-byte loads per lane in flight
+__global__ __launch_bounds__(256) void minmax_long_kernel(const float *__restrict__ x, long long pitch, long long start,
+                                                          long long stop, long long step, long long nseg,
+                                                          float *__restrict__ out, long long out_pitch)
 {
-    constexpr int SPW = 64 / GL;                       // segments per wave
     const long long c = blockIdx.y;
     const float *row = x + c * pitch;
-    float *orow = out + c * out_pitch;
     const int lane = threadIdx.x & 63;
+    const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nseg) return;
+    const long long lo = start + i * step;
+    const long long n = (lo + step < stop ? lo + step : stop) - lo;
+    const float *seg = row + lo;
+    MinMax m = {INFINITY, -INFINITY, false};
+    long long base = 0;
+    for (; base + 1024 <= n; base += 1024) {
+        mm_f4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const mm_f4 *>(seg + base + 256 * k + 4 * lane);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { m.take(v[k].x); m.take(v[k].y); m.take(v[k].z); m.take(v[k].w); }
+    }
+    for (long long j = base + 4 * lane; j < n; j += 256) {
+        if (j + 4 <= n) {
+            const mm_f4 v = *reinterpret_cast<const mm_f4 *>(seg + j);
+            m.take(v.x); m.take(v.y); m.take(v.z); m.take(v.w);
+        } else {
+            for (long long q = j; q < n; q++) m.take(seg[q]);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        m.mn = fminf(m.mn, __shfl_xor(m.mn, d, 64));
+        m.mx = fmaxf(m.mx, __shfl_xor(m.mx, d, 64));
+    }
+    const bool bad = __builtin_amdgcn_ballot_w64(m.bad) != 0;
+    if (lane == 0) {
+        mm_f2 r;
+        r.x = bad ? __builtin_nanf("") : m.mn;
+        r.y = bad ? __builtin_nanf("") : m.mx;
+        *reinterpret_cast<mm_f2 *>(out + c * out_pitch + 2 * i) = r;
+    }
+}
+
+// shorter segments (step < 512): a wave stages the up to 2048 samples of a run of whole segments in LDS (coalesced
+// 16-byte loads; sample j at dword j + j / 32, so that lanes which walk segments side by side -- strides that are
+// powers of two -- land on different banks), then GL lanes take a segment each: GL = 1 up to step 32 (a lane walks its
+// own segment), 16 up to 128, 64 beyond (lanes stride over the segment and combine by shuffles).
+constexpr int MM_TILE = 2048;
+template <int GL>
+__global__ __launch_bounds__(256) void minmax_short_kernel(const float *__restrict__ x, long long pitch, long long start,
+                                                           long long stop, int step, long long nseg, int segs_per_tile,
+                                                           float *__restrict__ out, long long out_pitch)
+{
+    __shared__ float tiles[4][MM_TILE + MM_TILE / 32];
+    const long long c = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    float *tile = tiles[wave];
+    const long long i0 = ((long long)blockIdx.x * 4 + wave) * segs_per_tile;       // first segment of this wave's tile
+    if (i0 >= nseg) return;                                                      // (no workgroup barrier below)
+    const int nst = nseg - i0 < segs_per_tile ? (int)(nseg - i0) : segs_per_tile;
+    const long long p0 = start + i0 * (long long)step;
+    const float *src = x + c * pitch + p0;
+    const int ns = (int)((p0 + (long long)nst * step < stop ? p0 + (long long)nst * step : stop) - p0);   // samples of the tile
+    for (int j = 4 * lane; j < ns; j += 256) {
+        float e[4];
+        if (j + 4 <= ns) {
+            const mm_f4 v = *reinterpret_cast<const mm_f4 *>(src + j);
+            e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) e[q] = j + q < ns ? src[j + q] : 0.f;
+        }
+        const int d = j + (j >> 5);                      // (four consecutive samples share j / 32)
+#pragma unroll
+        for (int q = 0; q < 4; q++) tile[d + q] = e[q];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    constexpr int SPP = 64 / GL;                         // segments per pass
     const int g = lane / GL, l = lane % GL;
-    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long waves = (long long)gridDim.x * 4;
-    for (long long i0 = wave * SPW; i0 < nseg; i0 += waves * SPW) {
-        const long long i = i0 + g;
-        const bool active = i < nseg;
-        const long long lo = start + (active ? i : 0) * step;
-        long long hi = lo + step;
-        if (hi > stop) hi = stop;
-        float mn = row[lo], mx = mn;                   // every segment has at least one sample
+    float *orow = out + c * out_pitch + 2 * i0;
+    for (int s0 = 0; s0 < nst; s0 += SPP) {
+        const int sg = s0 + g;
+        const bool active = sg < nst;
+        const int lo = (active ? sg : 0) * step;
+        int hi = lo + step;
+        if (hi > ns) hi = ns;
+        MinMax m = {INFINITY, -INFINITY, false};
         if (active)
-            for (long long j = lo + l; j < hi; j += GL) {
-                const float v = row[j];
-                mn = np_min(v, mn);
-                mx = np_max(v, mx);
-            }
+            for (int j = lo + l; j < hi; j += GL) m.take(tile[j + (j >> 5)]);
 #pragma unroll
         for (int d = GL / 2; d >= 1; d >>= 1) {
-            mn = np_min(__shfl_xor(mn, d, 64), mn);
-            mx = np_max(__shfl_xor(mx, d, 64), mx);
+            m.mn = fminf(m.mn, __shfl_xor(m.mn, d, 64));
+            m.mx = fmaxf(m.mx, __shfl_xor(m.mx, d, 64));
+            const int ob = __shfl_xor((int)m.bad, d, 64);      // (every lane takes part in the shuffle: not behind the ||)
+            m.bad = m.bad || ob != 0;
         }
-        if (active && l == 0) { orow[2 * i] = mn; orow[2 * i + 1] = mx; }
+        if (active && l == 0) {
+            mm_f2 r;
+            r.x = m.bad ? __builtin_nanf("") : m.mn;
+            r.y = m.bad ? __builtin_nanf("") : m.mx;
+            *reinterpret_cast<mm_f2 *>(orow + 2 * sg) = r;
+        }
     }
 }
 
@@ -564,12 +711,18 @@ int hipdsp_decibel_image_decimate(hipdsp_ctx *ctx, const float *spec_tf, float *
     const long long ncols = (stop - start + step - 1) / step;
     if (ncols == 0 || nfreq == 0) return HIPDSP_OK;
     HD_REQUIRE(spec_tf != nullptr && image_fc != nullptr, "NULL data pointer");
-    HD_REQUIRE((ncols + 31) / 32 <= 65535, "too many columns for one image");
+    const int cpb = step >= 8 ? 8 : 32;
+    HD_REQUIRE((ncols + cpb - 1) / cpb <= 65535, "too many columns for one image");
     HD_CHECK_HIP(hipSetDevice(ctx->device));
-    dim3 grid((unsigned)((nfreq + 31) / 32), (unsigned)((ncols + 31) / 32));
-    hipLaunchKernelGGL(db_image_decimate_kernel, grid, dim3(256), 0, ctx->stream, spec_tf, image_fc,
-                       (long long)start, (long long)stop, (long long)step, ncols, (long long)nfreq,
-                       (float)(1.0 / ref_power), (float)min_power);
+    dim3 grid((unsigned)((nfreq + 31) / 32), (unsigned)((ncols + cpb - 1) / cpb));
+    if (cpb == 8)
+        hipLaunchKernelGGL(db_image_decimate_kernel<8>, grid, dim3(256), 0, ctx->stream, spec_tf, image_fc,
+                           (long long)start, (long long)stop, (long long)step, ncols, (long long)nfreq,
+                           (float)(1.0 / ref_power), (float)min_power);
+    else
+        hipLaunchKernelGGL(db_image_decimate_kernel<32>, grid, dim3(256), 0, ctx->stream, spec_tf, image_fc,
+                           (long long)start, (long long)stop, (long long)step, ncols, (long long)nfreq,
+                           (float)(1.0 / ref_power), (float)min_power);
     return hd_launch_status("db_image_decimate_kernel");
 }
 
@@ -726,8 +879,31 @@ int hipdsp_pcm_unpack(hipdsp_ctx *ctx, const void *pcm_tc, int sample_bytes, int
 {
     int rc = pack_check(ctx, pcm_tc, dst, dst_pitch, frames, channels);
     if (rc != HIPDSP_OK || frames == 0 || channels == 0) return rc;
-    dim3 grid((unsigned)((frames + 31) / 32), (unsigned)((channels + 31) / 32));
     const unsigned char *p = (const unsigned char *)pcm_tc;
+    // 16-byte vectors on both sides when whole vectors of channels line up: 8 (int16) or 4 (int32) channels per vector,
+    // frames that start on a 16-byte boundary
+    if ((sample_bytes == 2 || sample_bytes == 4) && ((uintptr_t)pcm_tc & 15) == 0 && (channels * sample_bytes) % 16 == 0 &&
+        (frames + 127) / 128 <= 0x7fffffffLL) {
+        const int spv = 16 / sample_bytes;
+        int tc = 64;
+        while (tc > spv && channels % tc) tc >>= 1;
+        if (channels % tc == 0 && channels / tc <= 65535) {
+            const dim3 tgrid((unsigned)((frames + 127) / 128), (unsigned)(channels / tc));
+#define HD_PCM_TILE(B, TCV)                                                                                          \
+    hipLaunchKernelGGL((pcm_unpack_tile_kernel<B, TCV>), tgrid, dim3(256), 0, ctx->stream, p, dst, (long long)dst_pitch, \
+                       (long long)frames, (long long)channels, (float)scale)
+            if (sample_bytes == 2) {
+                if (tc == 64) HD_PCM_TILE(2, 64); else if (tc == 32) HD_PCM_TILE(2, 32);
+                else if (tc == 16) HD_PCM_TILE(2, 16); else HD_PCM_TILE(2, 8);
+            } else {
+                if (tc == 64) HD_PCM_TILE(4, 64); else if (tc == 32) HD_PCM_TILE(4, 32);
+                else if (tc == 16) HD_PCM_TILE(4, 16); else if (tc == 8) HD_PCM_TILE(4, 8); else HD_PCM_TILE(4, 4);
+            }
+#undef HD_PCM_TILE
+            return hd_launch_status("pcm_unpack_tile_kernel");
+        }
+    }
+    dim3 grid((unsigned)((frames + 31) / 32), (unsigned)((channels + 31) / 32));
     switch (sample_bytes) {
     case 2: hipLaunchKernelGGL(pcm_unpack_kernel<2>, grid, dim3(256), 0, ctx->stream, p, dst, (long long)dst_pitch,
                                (long long)frames, (long long)channels, (float)scale); break;
@@ -753,26 +929,25 @@ int hipdsp_minmax_decimate(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, int
     HD_REQUIRE(x_pitch >= stop && out_pitch >= 2 * nseg, "pitch too small");
     HD_REQUIRE(channels <= 65535, "too many channels");
     HD_CHECK_HIP(hipSetDevice(ctx->device));
-    int gl = 1;                                      // steps up to 8: one lane per segment
-    if (step > 8)
-        while (gl < 64 && gl < step) gl <<= 1;
-    const long long spw = 64 / gl;
-    unsigned gx = grid1d((nseg + spw - 1) / spw, 4, 16384);
-    dim3 grid(gx, (unsigned)channels), block(256);
-#define HD_MINMAX(GLV)                                                                                   \
-    hipLaunchKernelGGL(minmax_kernel<GLV>, grid, block, 0, ctx->stream, x, (long long)x_pitch, (long long)start, \
-                       (long long)stop, (long long)step, nseg, out, (long long)out_pitch)
-    switch (gl) {
-    case 1: HD_MINMAX(1); break;
-    case 2: HD_MINMAX(2); break;
-    case 4: HD_MINMAX(4); break;
-    case 8: HD_MINMAX(8); break;
-    case 16: HD_MINMAX(16); break;
-    case 32: HD_MINMAX(32); break;
-    default: HD_MINMAX(64); break;
+    if (step >= 512) {
+        HD_REQUIRE((nseg + 3) / 4 <= 0x7fffffffLL, "grid too large");
+        hipLaunchKernelGGL(minmax_long_kernel, dim3((unsigned)((nseg + 3) / 4), (unsigned)channels), dim3(256), 0, ctx->stream,
+                           x, (long long)x_pitch, (long long)start, (long long)stop, (long long)step, nseg, out,
+                           (long long)out_pitch);
+        return hd_launch_status("minmax_long_kernel");
     }
+    const int spt = MM_TILE / (int)step;                  // whole segments per 2048-sample tile (>= 4)
+    const long long tiles = (nseg + spt - 1) / spt;
+    HD_REQUIRE((tiles + 3) / 4 <= 0x7fffffffLL, "grid too large");
+    dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)channels), block(256);
+#define HD_MINMAX(GLV)                                                                                            \
+    hipLaunchKernelGGL(minmax_short_kernel<GLV>, grid, block, 0, ctx->stream, x, (long long)x_pitch, (long long)start, \
+                       (long long)stop, (int)step, nseg, spt, out, (long long)out_pitch)
+    if (step <= 32) HD_MINMAX(1);
+    else if (step <= 128) HD_MINMAX(16);
+    else HD_MINMAX(64);
 #undef HD_MINMAX
-    return hd_launch_status("minmax_kernel");
+    return hd_launch_status("minmax_short_kernel");
 }
 
 int hipdsp_mean_spectrum_db(hipdsp_ctx *ctx, const float *spec_tf, int64_t nfreq, int64_t i0, int64_t i1,

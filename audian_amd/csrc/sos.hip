@@ -1273,16 +1273,20 @@ int hipdsp_envelope_multi(hipdsp_ctx *ctx, const hipdsp_sosplan *const *plans, i
     HD_REQUIRE(x != nullptr && y != nullptr, "NULL data pointer");
     HD_REQUIRE(x_pitch >= frames && y_pitch >= frames - skip, "pitch smaller than row length");
     const long long N = frames + 2LL * edge;                 // (x is fully consumed before y is written: they may overlap)
+    // Two temporaries of the slab's size and one float per channel, from the context's scratch (it grows once and stays;
+    // taken from hipdsp_malloc they were larger than any block its cache keeps by default, and every call paid a
+    // hipMalloc + hipFree of tens of GB -- 1.1-1.2 s at BASELINE configs[2]'s size on some boxes, profiles/r03_entry_points.log).
+    // Nothing below uses the scratch for anything else (sos_scan_kernel parks no tile states).
     float *buf[2] = {nullptr, nullptr}, *ref = nullptr;
-    int rc = hipdsp_malloc(ctx, sizeof(float) * (size_t)N * (size_t)channels, (void **)&buf[0]);
-    if (rc == HIPDSP_OK) rc = hipdsp_malloc(ctx, sizeof(float) * (size_t)N * (size_t)channels, (void **)&buf[1]);
-    if (rc == HIPDSP_OK) rc = hipdsp_malloc(ctx, sizeof(float) * (size_t)channels, (void **)&ref);
-    auto cleanup = [&]() {
-        (void)hipdsp_free(ctx, buf[0]);
-        (void)hipdsp_free(ctx, buf[1]);
-        (void)hipdsp_free(ctx, ref);
-    };
-    if (rc != HIPDSP_OK) { cleanup(); return rc; }
+    const size_t slab = ((sizeof(float) * (size_t)N * (size_t)channels + 255) / 256) * 256;
+    void *work = nullptr;
+    int rc = hipdsp_scratch(ctx, 2 * slab + sizeof(float) * (size_t)channels, &work);
+    if (rc != HIPDSP_OK) return rc;
+    ctx->sweep_frames = -1;                                  // (whatever tile states a forward sweep parked there are gone)
+    buf[0] = (float *)work;
+    buf[1] = (float *)((char *)work + slab);
+    ref = (float *)((char *)work + 2 * slab);
+    auto cleanup = [&]() {};
     HD_REQUIRE((N + 1023) / 1024 <= 0x7fffffffLL, "grid too large");
     const unsigned gx = (unsigned)((N + 1023) / 1024);            // 256 threads x 4 values per block, no loop
     const dim3 grid(gx, (unsigned)channels);

@@ -66,8 +66,7 @@ int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
  *                        "sos_waves_min" >= that: exactly that many (experiments); "chain_pairs" (8): most pairs of
  *                        waves per CU of the fused sweeps
  *   "pool_limit_mb"      bytes (MiB) hipdsp_free may keep cached for hipdsp_malloc (1024); blocks of up to 256 MiB are
- *                        cached, with a larger limit blocks of up to the limit (hipdsp_envelope_multi takes two temporaries
- *                        of the slab's size per call: at tens of GB raise this, or pay a hipMalloc + hipFree each call)
+ *                        cached, with a larger limit blocks of up to the limit
  *   "sos_prefetch"       0: envelope sweeps without the register prefetch of the next tile (1)
  *   "chain_split_frames" non-zero: hipdsp_chain_forward (2048/1024, no db_out) leaves the odd frames to hipdsp_chain_backward
  *   "chain_reserve_cus"  CUs hipdsp_chain_forward plans no workgroup for (0): its 1024-thread workgroups want a
@@ -270,7 +269,7 @@ int hipdsp_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *plan, const float *x,
  * phase: 0 = both sweeps; 1 = forward sweep only (yf complete, states parked in the context
  * scratch); 2 = backward sweep only (env from yf and those states) -- so that other work on yf
  * (the spectrogram) can be enqueued in between; no call that uses the scratch of THIS context
- * (envelope, nfft > 32768, mean_spectrum_db) may come between phase 1 and phase 2.
+ * (envelope, envelope_multi, nfft > 32768, mean_spectrum_db) may come between phase 1 and phase 2.
  * env_first: the envelope is taken of yf[env_first:] -- env rows hold frames - env_first samples, env[i] belongs
  * to sample env_first + i of yf -- which is what BufferedEnvelope's buffer is after a scroll (its second of
  * pre-roll trimmed by BufferedData.align_buffer, buffereddata.py:75-88; sosfiltfilt then pads and starts at that
@@ -291,7 +290,8 @@ int hipdsp_sosfilt_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan,
  * sosfilt_zi scaled by the DC gain of the sections in front of it, exactly as sosfilt_zi of the whole table
  * would give.  The hand-over between plans is float32.  Same arguments and errors as hipdsp_envelope
  * (HIPDSP_ERR_TOO_SHORT when frames <= padlen); 56 instead of 16 bytes per sample, two temporaries of
- * (channels, frames + 2 padlen) floats from the context's block cache. */
+ * (channels, frames + 2 padlen) floats in the context's scratch (which grows to hold them once and keeps its size:
+ * like every call that uses the scratch, not between hipdsp_sosfilt_envelope's phases 1 and 2). */
 int hipdsp_envelope_multi(hipdsp_ctx *ctx, const hipdsp_sosplan *const *plans, int n_plans, const float *x,
                           int64_t x_pitch, float *y, int64_t y_pitch, int64_t channels, int64_t frames,
                           int64_t skip, int rectify, double gain, int clamp);

@@ -422,6 +422,29 @@ def test_pcm_unpack_bit_exact():
         assert np.array_equal(dst.to_host(), want), nbytes
 
 
+@pytest.mark.parametrize('T,C,nbytes', [(3001, 8, 2), (128, 64, 2), (70000, 64, 2), (5000, 24, 2), (777, 16, 2), (4099, 4, 4),
+                                         (1000, 64, 4), (333, 12, 4), (2500, 40, 2)])
+def test_pcm_unpack_whole_vectors_of_channels_bit_exact(T, C, nbytes):
+    """The shapes a recording usually has (16- or 32-bit samples, whole 16-byte vectors of channels per frame) take
+    the tiled kernel (16-byte loads, transposition through LDS, 16-byte stores): bit-exact, frames that are no
+    multiple of the tile, a destination pitch with slack that must stay untouched."""
+    from audian_amd import hipdsp
+    import gpu_helpers as gh
+    rng = np.random.default_rng(T + C)
+    c = gh.ctx()
+    bits = 8*nbytes
+    ints = rng.integers(-(1 << (bits - 1)), 1 << (bits - 1), size=(T, C))
+    raw = np.frombuffer(ints.astype('<i2' if nbytes == 2 else '<i4').tobytes(), dtype=np.uint8)
+    up = hipdsp.DeviceArray.from_host(c, raw)
+    pitch = T + 5
+    dst = hipdsp.DeviceArray.from_host(c, np.full((C, pitch), 7.0, dtype=np.float32))
+    scale = 1.0/float(1 << (bits - 1))
+    hipdsp.pcm_unpack(c, up, nbytes, T, C, scale, dst, pitch)
+    got = dst.to_host()
+    assert np.array_equal(got[:, :T], (ints*scale).astype(np.float32).T)
+    assert np.all(got[:, T:] == 7.0)
+
+
 def test_playback_chain_matches_reference_arithmetic(oracle):
     """DataBrowser.play_region (channel means, heterodyne, zero-phase 20 kHz
     low-pass, down-sampling) from the filtered trace's device mirror."""

@@ -464,6 +464,35 @@ def test_minmax_decimation_bit_exact(oracle, step):
         hipdsp.minmax_decimate(c, dx, T, C, 10, 5, step, dx, 2)
 
 
+@pytest.mark.parametrize('step', [1, 2, 4, 5, 31, 32, 33, 100, 128, 129, 480, 511, 512, 513, 2048, 28800])
+def test_minmax_decimation_streams_any_step(oracle, step):
+    """The same decimation as a read stream (16-byte loads whatever the step: segments of a tile staged in LDS below
+    512 samples per segment, a wave per segment from there on): every regime and its borders, windows that start and
+    stop anywhere, an output pitch with slack, NaN and infinities in the data (np.minimum / np.maximum: a NaN in a
+    segment makes both of its values NaN)."""
+    from audian_amd import hipdsp
+    rng = np.random.default_rng(1000 + step)
+    T, C = 100000 + 7*step, 2
+    x = rng.standard_normal((T, C)).astype(np.float32)
+    x[rng.integers(0, T, size=40), 0] = np.nan
+    x[rng.integers(0, T, size=40), 1] = np.inf
+    x[rng.integers(0, T, size=40), 1] = -np.inf
+    c = gh.ctx()
+    dx = gh.to_planar(c, x)
+    for start, stop in [(0, T), (3, T - 1), (step + 1, min(T, step + 1 + 37*step + step//2)), (T - 1, T), (5, 5)]:
+        nseg = (stop - start + step - 1)//step
+        if nseg == 0:
+            hipdsp.minmax_decimate(c, dx, T, C, start, stop, step, dx, 2)
+            continue
+        pitch = 2*nseg + 3
+        out = hipdsp.DeviceArray.from_host(c, np.full((C, pitch), 5.0, dtype=np.float32))
+        hipdsp.minmax_decimate(c, dx, T, C, start, stop, step, out, pitch)
+        got = out.to_host()
+        want = oracle.minmax_decimate(x.astype(np.float64), start, stop, step).T          # (C, 2n)
+        assert np.array_equal(got[:, :2*nseg].astype(np.float64), want, equal_nan=True), (step, start, stop)
+        assert np.all(got[:, 2*nseg:] == 5.0)
+
+
 def test_mean_spectrum_db(oracle):
     """decibel(mean over frames) with the -200 dB floor."""
     from audian_amd import hipdsp

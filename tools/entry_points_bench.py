@@ -41,10 +41,7 @@ line('hipdsp_sosfilt, no filter (copy)', timed(lambda: hipdsp.sosfilt(ctx, None,
 hipdsp.sosfilt(ctx, bp2, dx, T, df, T, C, T, 0)
 line('hipdsp_envelope, low-pass of 1 section (BufferedEnvelope alone)', timed(lambda: hipdsp.envelope(ctx, lp1, df, T, de, T, C, T, 0)), 12.0*S)
 line('hipdsp_envelope, low-pass of 2 sections', timed(lambda: hipdsp.envelope(ctx, lp2, df, T, de, T, C, T, 0)), 12.0*S)
-line('hipdsp_envelope_multi, low-pass of 6 sections as 3 + 3 (two temporaries hipMalloc\'ed per call)', timed(lambda: hipdsp.envelope_multi(ctx, lp6, df, T, de, T, C, T, 0), n=3), 12.0*S)
-ctx.set_option('pool_limit_mb', 2*(4*S >> 20) + 1024)
-line('hipdsp_envelope_multi, the same with "pool_limit_mb" raised to hold them', timed(lambda: hipdsp.envelope_multi(ctx, lp6, df, T, de, T, C, T, 0), n=3), 12.0*S)
-ctx.set_option('pool_limit_mb', 1024)
+line('hipdsp_envelope_multi, low-pass of 6 sections as 3 + 3 (default options; temporaries in the context scratch)', timed(lambda: hipdsp.envelope_multi(ctx, lp6, df, T, de, T, C, T, 0), n=3), 12.0*S)
 line('hipdsp_sosfilt_envelope, both sweeps (filter + envelope, unfused spectrogram)', timed(lambda: hipdsp.sosfilt_envelope(ctx, bp2, lp1, dx, T, df, T, de, T, C, T)), 16.0*S)
 for nfft, hop in ((2048, 1024), (1024, 256), (256, 128), (8192, 4096), (65536, 32768)):
     F, nd = nfft//2 + 1, (T + hop - 1)//hop
