@@ -1083,6 +1083,7 @@ int run_fast(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long chann
 }
 
 #include "spec_pack.h"
+#include "spec_wgs.h"
 
 template <int NFFT, int LPF, int R1, int R2, int R3, int OCC>
 int run_wg(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long channels, long long n_valid,
@@ -1204,15 +1205,24 @@ extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pit
             return run_fast<2048, 64, 16, 16, 4, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
         case 4096:
             if (want == 2) return run_wg<4096, 128, 16, 16, 8, 3>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+            // (the streamed workgroup: 3.0 TB/s, level with the one-wave-per-frame kernel, "spec_kernel" 3; 4.1 against 2.9
+            // with the dB image next to the PSD)
+            if (want != 3) return run_wgs<4096, 128, 16, 16, 8, 3>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
             return run_fast<4096, 64, 16, 16, 8, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
         }
     }
+    // long windows: a workgroup streams a run of frames through LDS (spec_wgs.h); "spec_kernel" 2: the kernel it replaced
+    const bool old_wg = ctx->spec_kernel == 2;
     if (!ctx->force_generic_fft && nfft == 8192)
-        return run_wg<8192, 256, 16, 16, 16, 3>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+        return old_wg ? run_wg<8192, 256, 16, 16, 16, 3>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out)
+                      : run_wgs<8192, 256, 16, 16, 16, 3>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
     if (!ctx->force_generic_fft && nfft == 16384)
-        return run_wg<16384, 256, 16, 16, 32, 2>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+        return old_wg ? run_wg<16384, 256, 16, 16, 32, 2>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out)
+                      : run_wgs<16384, 256, 16, 16, 32, 2>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
     if (!ctx->force_generic_fft && nfft == 32768)
-        return run_wg<32768, 512, 16, 32, 32, 2>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+        return old_wg
+                   ? run_wg<32768, 512, 16, 32, 32, 2>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out)
+                      : run_wgs<32768, 512, 16, 32, 32, 1>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
     if (nfft > 8192)
         return run_big(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, nfft, hop, scale, out, db_out);
     size_t lds = sizeof(float2) * 2 * (size_t)nfft;

@@ -279,7 +279,7 @@ def test_spectrogram_fast_and_generic_vs_oracle(oracle, nfft, hop):
     results = [gh.gpu_spectrogram(x, rate, nfft, hop, nd)]
     c = gh.ctx()
     try:
-        for kern in (2, 3):               # two-stage and three-stage register/LDS kernels
+        for kern in (2, 3, 4):            # two-stage, three-stage register/LDS kernels, nfft 4096 as a streamed workgroup
             c.set_option('spec_kernel', kern)
             results.append(gh.gpu_spectrogram(x, rate, nfft, hop, nd))
         c.set_option('spec_kernel', 0)
