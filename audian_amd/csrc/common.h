@@ -36,6 +36,7 @@ struct hipdsp_ctx {
                            // rows, hipdsp_chain... sizes unknown to the library: the tool sizes it from the planned grid)
     long long sos_trace_rows;  // capacity of sos_trace in rows of 9 int64 (option "sos_trace_rows"; set it BEFORE "sos_trace")
     int sos_fair;          // rotating issue priorities in the single-wave sweeps (sos.hip: rotate_issue_priority)
+    int sos_split;         // experiments (A/B): the envelope's backward sweep with compute and mover waves (envsplit.hip)
     int sos_no_pin;        // experiments: scalar table loads left to hipcc's just-in-time placement (A/B of CASC_PIN_GROUPS)
     struct hd_pool *pool;  // stream-ordered cache of freed device blocks (ctx.hip)
     // Device-side fault report: four ints in pinned host memory that kernels can write
@@ -59,6 +60,7 @@ int hd_seg_flags(hipdsp_ctx *ctx, size_t units, unsigned char **out);
 
 // fault codes a kernel may leave in hipdsp_ctx::fault_host[0]
 #define HD_FAULT_CHAIN_HANDOVER 1   // chain_fwd_kernel: a wave waited in vain for its partner's LDS flag
+#define HD_FAULT_SPLIT_HANDOVER 2   // env_bwd_split_kernel: the same between a compute wave and its mover
 
 // Reports (and clears) a fault word left by a kernel of this context: HIPDSP_ERR_HIP with a message,
 // HIPDSP_OK when there is none.  Called after every synchronisation of the context's stream and at

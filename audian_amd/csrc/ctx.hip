@@ -219,6 +219,7 @@ int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value)
     if (strcmp(name, "spec_debug") == 0) { ctx->spec_debug = (int)value; return HIPDSP_OK; }
     if (strcmp(name, "chain_debug") == 0) { ctx->chain_debug = (int)value; return HIPDSP_OK; }
     if (strcmp(name, "sos_no_pin") == 0) { ctx->sos_no_pin = value != 0; return HIPDSP_OK; }
+    if (strcmp(name, "sos_split") == 0) { ctx->sos_split = value != 0; return HIPDSP_OK; }
     if (strcmp(name, "sos_fair") == 0) { ctx->sos_fair = value != 0; return HIPDSP_OK; }
     if (strcmp(name, "sos_trace_rows") == 0) { ctx->sos_trace_rows = value; return HIPDSP_OK; }
     if (strcmp(name, "sos_trace") == 0) {

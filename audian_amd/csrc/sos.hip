@@ -1040,6 +1040,7 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
     long long blocks = (b.units + WPB - 1) / WPB;            // four waves per workgroup: one per SIMD of a CU
     HD_REQUIRE(blocks <= 0x7fffffffLL, "grid too large");
     dim3 grid((unsigned)blocks), block(64 * WPB);
+    if (ctx->sos_split && SE <= 2 && frames >= 4 * TILE) return hd_launch_env_bwd_split(ctx, edev, SE, b);   // (A/B: envsplit.hip)
     if (ctx->sos_single_wave_wg) { grid = dim3((unsigned)b.units); block = dim3(64); }
     if (ctx->sos_single_wave_wg && SE == 1 && ctx->sos_prefetch && frames >= 4 * TILE && !ctx->sos_trace && !ctx->sos_no_pin) {
         hipLaunchKernelGGL((env_bwd_kernel<1, true, true, false, 1>), grid, block, 0, ctx->stream, edev, b);   // A/B

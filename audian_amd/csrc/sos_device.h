@@ -42,6 +42,26 @@ struct FloodArgs {
 int hd_launch_env_fix(hipdsp_ctx *ctx, const SosPlanDev *edev, int SE, double *ckpt, long long ckpt_pitch, long long channels,
                       int n_seg, long long seg_len, long long n_tiles, const FloodArgs *flood, int first_seg = 0);
 
+// (not in the anonymous namespace: envsplit.hip's launcher takes it across translation units)
+struct BwdArgs {
+    const float *in;         // the trace the envelope is taken of (before rectification)
+    float *out;
+    const double *ckpt;
+    long long in_pitch, out_pitch, ckpt_pitch;
+    long long T, skip;
+    long long n_tiles;       // ceil((T + edge) / TILE)
+    long long seg_tiles, warm_tiles;
+    int n_seg, edge, rectify, clamp;
+    double gain;             // as in CkptArgs
+    long long units;         // channels * n_seg (the grid is rounded up to whole workgroups)
+    long long lead, env0;    // as in CkptArgs: the grid of the forward sweep that left the tile states (skip >= env0)
+    long long *trace;        // option "sos_trace": 9 words per wave (start, end in 100 MHz ticks, HW_ID, 6 clock sums)
+    long long trace_rows;    // rows of `trace` (option "sos_trace_rows"): waves beyond it do not report
+    int debug;               // measurements only, results wrong (option "sos_debug"): 1 = every interior tile is stored into
+                             // the channel's first tile (writes stay in L2), 2 = every prefetch reads the first tile
+    int fair;                // rotate_issue_priority() per tile (option "sos_fair", default off: no gain measured)
+};
+
 namespace {
 
 
@@ -303,24 +323,6 @@ __device__ __forceinline__ float env_left_fill(float *ldsf, int lane, int q, int
     return e0;
 }
 
-struct BwdArgs {
-    const float *in;         // the trace the envelope is taken of (before rectification)
-    float *out;
-    const double *ckpt;
-    long long in_pitch, out_pitch, ckpt_pitch;
-    long long T, skip;
-    long long n_tiles;       // ceil((T + edge) / TILE)
-    long long seg_tiles, warm_tiles;
-    int n_seg, edge, rectify, clamp;
-    double gain;             // as in CkptArgs
-    long long units;         // channels * n_seg (the grid is rounded up to whole workgroups)
-    long long lead, env0;    // as in CkptArgs: the grid of the forward sweep that left the tile states (skip >= env0)
-    long long *trace;        // option "sos_trace": 9 words per wave (start, end in 100 MHz ticks, HW_ID, 6 clock sums)
-    long long trace_rows;    // rows of `trace` (option "sos_trace_rows"): waves beyond it do not report
-    int debug;               // measurements only, results wrong (option "sos_debug"): 1 = every interior tile is stored into
-                             // the channel's first tile (writes stay in L2), 2 = every prefetch reads the first tile
-    int fair;                // rotate_issue_priority() per tile (option "sos_fair", default off: no gain measured)
-};
 
 // wave-uniform: is any of the D state values NaN or infinite?
 template <int D>
@@ -405,3 +407,6 @@ void plan_segments_chain(const hipdsp_ctx *ctx, long long N, long long channels,
 }
 
 }  // namespace
+
+// defined in envsplit.hip: the backward sweep with compute and mover waves (context option "sos_split")
+int hd_launch_env_bwd_split(hipdsp_ctx *ctx, const SosPlanDev *edev, int SE, const BwdArgs &b);

@@ -1000,6 +1000,44 @@ def test_chain_forward_at_any_scroll_position(oracle, T, max_segments, nfft, hop
         c.set_max_segments(0)
 
 
+@pytest.mark.parametrize('T,C,env_first', [(300000, 3, 0), (1500000, 2, 0), (400000, 2, 48000), (70001, 1, 12345)])
+def test_role_split_backward_sweep_is_the_same_envelope(oracle, T, C, env_first):
+    """The experiment of round 4 ("sos_split": compute waves that issue no vector-memory instruction for interior tiles,
+    mover waves that do nothing else, envsplit.hip; dropped as the default -- profiles/r04j_bwd_role_split_ab.log -- but
+    kept reproducible): the same envelope as env_bwd_kernel up to the float32 hand-over between its two cascades, and
+    the oracle's within the parity bar, for one and many segments and an envelope that starts inside the trace."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rate = 48000.0
+    rng = np.random.default_rng(T + C)
+    x = synth(rng, T, C, rate)
+    c = gh.ctx()
+    sos = butter_sos(2, (300.0, 3000.0), 'bandpass', rate)
+    fplan = hipdsp.SosPlan(c, sos)
+    dx = gh.to_planar(c, x)
+    for esos in (butter_sos(2, 20.0, 'lowpass', rate), butter_sos(4, 300.0, 'lowpass', rate)):
+        eplan = hipdsp.SosPlan(c, esos)
+        yf = hipdsp.DeviceArray(c, (C, T), np.float32)
+        got = []
+        for mode in (0, 1):
+            ye = hipdsp.DeviceArray(c, (C, T - env_first), np.float32)
+            hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(ye), 0x7f, 4*C*(T - env_first))
+            hipdsp.sosfilt_envelope(c, fplan, eplan, dx, T, yf, T, ye, T - env_first, C, T, phase=1, env_first=env_first)
+            c.set_option('sos_split', mode)
+            try:
+                hipdsp.sosfilt_envelope(c, fplan, eplan, dx, T, yf, T, ye, T - env_first, C, T, phase=2, env_first=env_first)
+            finally:
+                c.set_option('sos_split', 0)
+            got.append(ye.to_host())
+        sf = yf.to_host()
+        want = np.zeros((T - env_first, C))
+        oracle.envelope_process(esos, sf.T[env_first:].astype(np.float64), want, 0)
+        for ch in range(C):
+            assert rel_err(got[1][ch], got[0][ch]) < 1e-4, (T, ch)
+            assert rel_err(got[1][ch], want[:, ch]) < TOL, (T, ch)
+            assert rel_err(got[0][ch], want[:, ch]) < TOL, (T, ch)
+
+
 def test_envelope_start_inside_the_trace_too_short_raises():
     """frames - env_first <= padlen: scipy's ValueError, as for a slab of that length."""
     from audian_amd import hipdsp
