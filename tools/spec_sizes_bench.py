@@ -14,8 +14,11 @@ if os.environ.get('SPEC_KERNEL'):
 dx = hipdsp.DeviceArray(ctx, (C, T), np.float32)
 hipdsp.synth(ctx, dx, T, C, T, rate, 7)
 e0, e1 = ctx.event(), ctx.event()
-for nfft in sizes:
-    hop = max(nfft//hopdiv, 1)
+# PAIRS="1024:100,256:37": arbitrary overlaps (the reference's overlap spin box, databrowser.py:522-529) instead of the size list
+pairs = [(n, max(n//hopdiv, 1)) for n in sizes]
+if os.environ.get('PAIRS'):
+    pairs = [tuple(int(v) for v in p.split(':')) for p in os.environ['PAIRS'].split(',')]
+for nfft, hop in pairs:
     t = T if nfft >= 64 else T//8          # the tiny windows write 2x the input: keep the output small
     nd = (t + hop - 1)//hop
     for want_db in (False, True):
