@@ -235,6 +235,8 @@ int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value)
     }
     if (strcmp(name, "n_cus") == 0) {                 // tests: pretend a smaller chip (planning only)
         HD_REQUIRE(value >= 1 && value <= 1024, "n_cus out of range");
+        HD_REQUIRE(value > ctx->chain_reserve_cus, "n_cus %lld would leave no CU beside the %d of \"chain_reserve_cus\"", value,
+                   ctx->chain_reserve_cus);
         ctx->n_cus = (int)value;
         return HIPDSP_OK;
     }

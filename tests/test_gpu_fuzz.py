@@ -319,6 +319,96 @@ def test_random_chain_forward_cases(oracle, seed):
         c.set_option('chain_debug', 0)
 
 
+@pytest.mark.parametrize('seed', range(24))
+def test_random_scroll_positions_of_the_fused_launch(oracle, seed):
+    """hipdsp_chain_forward's spec_first / env_first (the filtered buffer after a scroll: frame 0 of the spectrogram
+    inside its first hop -- or anywhere --, the envelope from a later sample to the end) under random draws: every
+    window shape, random offsets with a bias towards tile, lane-row and hop borders, spec_frames, pitches, channel
+    counts, segmentations, barrier / flag hand-over, band-pass and low-pass envelopes.  Filtered trace against the
+    oracle, PSD against the separate kernel on the sliced filtered trace, envelope against the oracle on the slice."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rng = np.random.default_rng(424200 + seed)
+    rate = float(rng.choice([44100.0, 48000.0, 96000.0]))
+    nfft, hop = [(2048, 1024), (2048, 512), (1024, 512), (1024, 256), (512, 256), (256, 128)][int(rng.integers(0, 6))]
+    F = nfft//2 + 1
+    T = max(4*TILE + 50, int(rng.integers(5, 40))*TILE + int(rng.integers(-TILE + 1, TILE)))
+    C = int(rng.integers(1, 5))
+
+    def near_border(limit):
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            return 0
+        base = int(rng.integers(0, max(1, limit)))
+        if kind == 1:
+            base = (base//TILE)*TILE + int(rng.integers(-20, 21))
+        elif kind == 2:
+            base = (base//32)*32 + int(rng.integers(-1, 2))
+        elif kind == 3:
+            base = (base//hop)*hop + int(rng.integers(-2, 3))
+        return int(min(max(base, 0), max(0, limit - 1)))
+    spec_first = near_border(min(T - nfft - 1, 3*hop)) if rng.integers(0, 4) else near_border(T - nfft - 1)
+    lo = float(rng.uniform(50.0, 0.05*rate))
+    sos = butter_sos(int(rng.integers(1, 3)), (lo, float(rng.uniform(2*lo, 0.4*rate))), 'bandpass', rate)
+    band_env = rng.integers(0, 4) == 0
+    esos = butter_sos(1, (float(rng.uniform(2.0, 20.0)), float(rng.uniform(100.0, 1000.0))), 'bandpass', rate) if band_env \
+        else butter_sos(int(rng.integers(1, 5)), float(rng.uniform(5.0, 2000.0)), 'lowpass', rate)
+    edge = oracle.sosfiltfilt_edge(esos)
+    env_first = near_border(T - edge - 2)
+    nsrc = T - spec_first
+    spec_frames = 0 if rng.integers(0, 2) else int(rng.integers(max(1, nsrc//2), nsrc + 1))
+    xp, fp, ep = T + int(rng.integers(0, 9)), T + int(rng.integers(0, 9)), T - env_first + int(rng.integers(0, 9))
+    nd = (nsrc + hop - 1)//hop + int(rng.integers(-2, 3))
+    nd = max(nd, 1)
+    x = (rng.standard_normal((C, T))*rng.uniform(0.1, 3.0) + 0.1).astype(np.float32)
+    c = gh.ctx()
+    c.set_max_segments(int(rng.choice([0, 0, 1, 3, 11])))
+    c.set_option('chain_debug', int(rng.choice([0, 0, 4])) if (nfft, hop) == (2048, 1024) and len(sos) <= 2 else 0)
+    try:
+        host = np.zeros((C, xp), dtype=np.float32)
+        host[:, :T] = x
+        dx = hipdsp.DeviceArray(c, (C, xp), np.float32)
+        hipdsp.lib.hipdsp_memcpy_h2d(c.handle, hipdsp._p(dx), host.ctypes.data, host.nbytes)
+        yf = hipdsp.DeviceArray(c, (C, fp), np.float32)
+        ye = hipdsp.DeviceArray(c, (C, ep), np.float32)
+        ps = hipdsp.DeviceArray(c, (C, nd, F), np.float32)
+        for arr, n in ((yf, C*fp), (ye, C*ep), (ps, C*nd*F)):
+            hipdsp.lib.hipdsp_memset(c.handle, hipdsp._p(arr), 0x7f, 4*n)
+        fplan, eplan = hipdsp.SosPlan(c, sos), hipdsp.SosPlan(c, esos)
+        hipdsp.chain_forward(c, fplan, eplan, dx, xp, yf, fp, C, T, nfft, hop, rate, ps, nd, spec_frames=spec_frames,
+                             spec_first=spec_first, env_first=env_first)
+        hipdsp.sosfilt_envelope(c, fplan, eplan, dx, xp, yf, fp, ye, ep, C, T, clamp=not band_env, phase=2,
+                                env_first=env_first)
+        gf = yf.to_host()
+        ge = ye.to_host()
+        gs = ps.to_host()
+        guard = np.frombuffer(b'\x7f\x7f\x7f\x7f', dtype=np.float32)[0]
+        assert np.all(gf[:, T:] == guard) and np.all(ge[:, T - env_first:] == guard), seed
+        gf, ge = gf[:, :T], ge[:, :T - env_first]
+        s1 = hipdsp.DeviceArray(c, (C, nd, F), np.float32)
+        hipdsp.spectrogram(c, yf.view(spec_first, (1,)), fp, C, spec_frames or nsrc, nfft, hop, rate, s1, nd)
+        ss = s1.to_host()
+        want_f = oracle.sosfilt(sos, x.T.astype(np.float64))
+        src = gf.T[env_first:].astype(np.float64)
+        want_e = oracle.sosfiltfilt(esos, (np.pi/2)*np.abs(src))
+        if not band_env:
+            want_e[want_e < 0] = 0
+        what = (seed, T, nfft, hop, spec_first, env_first, spec_frames)
+        for ch in range(C):
+            assert rel_err(gf[ch], want_f[:, ch]) < TOL, what
+            assert np.all(np.isfinite(ge[ch])), what
+            assert rel_err(ge[ch], want_e[:, ch]) < TOL, what
+            for j in range(nd):
+                peak = np.max(np.abs(ss[ch, j]))
+                if peak == 0:
+                    assert np.all(gs[ch, j] == 0), what + (j,)
+                else:
+                    assert np.max(np.abs(gs[ch, j] - ss[ch, j]))/peak < 1e-5, what + (j,)
+    finally:
+        c.set_max_segments(0)
+        c.set_option('chain_debug', 0)
+
+
 @pytest.mark.parametrize('seed', range(20))
 def test_random_chain_shapes_sections_and_modes(oracle, seed):
     """The round-2 generalisations of the fused sweep under random draws: every window shape the kernel is built

@@ -82,7 +82,8 @@ int main()
     CHECK(hipdsp_ctx_create(0, nullptr, &ctx));
     EXPECT(hipdsp_ctx_set_option(ctx, "no_such_option", 1) == HIPDSP_ERR_INVALID);
     CHECK(hipdsp_ctx_set_option(ctx, "chain_reserve_cus", 8));
-    CHECK(hipdsp_ctx_set_option(ctx, "n_cus", 4));                 // fewer CUs than reserved: must not divide by zero later
+    EXPECT(hipdsp_ctx_set_option(ctx, "n_cus", 4) == HIPDSP_ERR_INVALID);    // fewer CUs than reserved: refused (ADVICE round 2)
+    CHECK(hipdsp_ctx_set_option(ctx, "n_cus", 9));
     CHECK(hipdsp_ctx_set_option(ctx, "n_cus", 256));
     EXPECT(hipdsp_ctx_set_option(ctx, "sos_trace", 1234) == HIPDSP_ERR_INVALID);     // capacity first
     CHECK(hipdsp_ctx_reserve(ctx, 1 << 20));
