@@ -152,8 +152,10 @@ def cpu_baseline(args, sos, esos):
         from oracle import scipy_path as path
         impl = 'scipy %s call pattern of the reference (oracle/scipy_path.py)' % \
             __import__('scipy').__version__
-        run = lambda: path.chain(x, args.rate, sos, esos, args.nfft, args.hop)
+        stamps = {}
+        run = lambda: path.chain(x, args.rate, sos, esos, args.nfft, args.hop, stamps=stamps)
     except ImportError:
+        stamps = {}
         from oracle import oracle as path
         impl = 'C/NumPy oracle port (oracle/oracle.py); scipy not installed'
 
@@ -175,6 +177,12 @@ def cpu_baseline(args, sos, esos):
            'host_cores': os.cpu_count(), 'usable_cores': usable_cores(),
            'sample': f'{C} ch x {T/args.rate:g} s x {args.rate/1000:g} kHz float64, '
                      f'same chain, {dt:.1f} s wall; {impl}'}
+    if stamps:
+        # per process() body, so that the figure explains itself: SURVEY 6's indicative 2.2 Msamples/s for this very call
+        # pattern came from the survey container (8 virtual cores of a 2.1 GHz Xeon: band-pass 39, spectrogram 12,
+        # envelope 10 Msamples/s when timed alone, 2.1 for the chain -- its transposes and the first touch of 0.5 GB of
+        # float64 temporaries are memory-bound there); the GPU boxes' host cores run the same scipy calls ~9x faster
+        out['stages_Msamples_per_s'] = {k: round(C*T/v/1e6, 1) for k, v in stamps.items() if v > 0}
     # for fairness also an all-cores figure: channels split over worker processes, one per channel up to the
     # cores this process may use (affinity mask and cgroup quota), in a separate process tree that never
     # touches the GPU
