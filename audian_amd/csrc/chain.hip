@@ -69,10 +69,18 @@ __device__ __forceinline__ void psd_frame(const v2f *w, float2 *fb, const float2
     const int l = lane % LPF, g0 = (lane / LPF) * LPF;
     float2 v[PPL];
     v2f acc = {0.f, 0.f};
+    // the frame mean (detrend='constant') relative to a PIVOT -- the wave's first sample, zero if that is not finite --:
+    // on an offset plus something small (a low-pass only in front of raw data with a DC offset, a decaying transient) a
+    // float32 sum of the samples carries 1e-7 of the OFFSET into bins 0 and 1, the sum of the differences 1e-7 of the
+    // small part (spec_pack.h; tools/fuzz_stress.py seed 10268 was a frame of this sweep)
+    float pv = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w[0].x)));
+    pv = (fabsf(pv) <= 3.0e38f) ? pv : 0.f;
+    const v2f pivot2 = {pv, pv};
 #pragma unroll
     for (int t = 0; t < R1; t++) {
-        v[t] = make_float2(w[t].x, w[t].y);
-        acc += w[t];
+        const v2f d = w[t] - pivot2;
+        v[t] = make_float2(d.x, d.y);
+        acc += d;
     }
     float sum = acc.x + acc.y;
     if (LPF == 64) {

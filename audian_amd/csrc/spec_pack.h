@@ -23,11 +23,13 @@ typedef float f4p __attribute__((ext_vector_type(4), aligned(4)));     // float4
 template <int LPF>
 __device__ __forceinline__ float group_sum(float v)
 {
-    static_assert(LPF == 1 || LPF == 2 || LPF == 4 || LPF == 8 || LPF == 16, "a lane group is part of a DPP row");
+    static_assert(LPF == 1 || LPF == 2 || LPF == 4 || LPF == 8 || LPF == 16 || LPF == 32 || LPF == 64, "lanes per frame");
+    if (LPF == 64) return wave_sum(v);
     if (LPF >= 2) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
     if (LPF >= 4) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
     if (LPF >= 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));   // row_half_mirror
     if (LPF >= 16) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));  // row_mirror
+    if (LPF == 32) v += __shfl_xor(v, 16, 64);            // (the other row of the half wave)
     return v;
 }
 
@@ -57,7 +59,8 @@ __global__ __launch_bounds__(256, 3) void spec_pack_kernel(
 
     constexpr int M = NFFT / 2, PPL = M / LPF, G = 64 / LPF, F = M + 1, MP = M + M / 16;
     constexpr bool THREE = R3 > 1;
-    constexpr bool INLANE = NFFT == 256 && LPF == 16 && R1 == 8 && R2 == 4 && R3 == 4;    // see the split step
+    constexpr bool INLANE = R3 == 4 && PPL == 8 && (R1 * R2) % 32 == 0;    // two last-stage butterflies per lane: see the split step
+    constexpr int NS3 = R1 * R2;                           // (= M / 4 there)
     static_assert(R1 * R2 * R3 == M && PPL % R1 == 0 && PPL % R2 == 0 && PPL % R3 == 0, "radices");
     constexpr int TW2 = (R2 - 1) * R1, TW3 = THREE ? R1 * R2 : 0, TWN = M / 2 + 1, NTAB = TW2 + TW3 + TWN + M;
     constexpr int RB = 2048;                               // ring: a batch's span (<= 1024 samples) + one fetch
@@ -157,13 +160,22 @@ __global__ __launch_bounds__(256, 3) void spec_pack_kernel(
         float2 v[PPL];
         {
             const int r0 = (int)(((fb0 + (valid ? g : 0)) * (long long)hop) & (RB - 1)) + 2 * l;
+            // The frame mean (detrend='constant') relative to a PIVOT, the batch's first sample (one LDS word, the same
+            // for every lane): on a trace that is an offset plus something small -- raw data of the reference's default
+            // session, a filter's decaying transient -- a float32 sum of the samples carries an error of 1e-7 of the
+            // OFFSET into bins 0 and 1 of every frame (tools/fuzz_stress.py, seed 10268: 1.0e-4 of the frame's peak);
+            // the sum of the differences carries 1e-7 of the small part.  (A non-finite pivot would poison frames
+            // that do not hold the sample: zero then.)
+            float pivot = ring[(int)((fb0 * (long long)hop) & (RB - 1))];
+            pivot = (fabsf(pivot) <= 3.0e38f) ? pivot : 0.f;
+            const v2f pivot2 = {pivot, pivot};
             v2f acc = {0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < PPL / R1; u++)
 #pragma unroll
                 for (int t = 0; t < R1; t++) {
                     const int ri = (r0 + 2 * (LPF * u + t * (M / R1))) & (RB - 1);
-                    const v2f e = {ring[ri], ring[ri + 1]};
+                    const v2f e = (v2f){ring[ri], ring[ri + 1]} - pivot2;
                     v[u * R1 + t] = as_f2(e);
                     acc += e;
                 }
@@ -194,21 +206,21 @@ __global__ __launch_bounds__(256, 3) void spec_pack_kernel(
             for (int m = 0; m < PPL; m++) { sg[l + LPF * m] = v[m].x; }
             if (l == 0) sg[M] = v[0].y;
         } else if constexpr (INLANE) {
-            // nfft 256 (M = 128 = 8 x 4 x 4, sixteen lanes per frame): the last stage's butterfly j produces the bins
-            // j + 32 t, and the partner of bin k is bin 128 - k: butterfly j pairs with butterfly 32 - j.  Which
-            // butterflies a lane takes is only a matter of the LDS addresses it loads from, so lane l takes j = l AND
-            // j = 32 - l (lane 0: the two self-paired ones, 0 and 16) and finds every partner in its own registers --
-            // no exchange between lanes in the split step at all.
+            // nfft 256 (M = 128 = 8 x 4 x 4, sixteen lanes per frame; 512 = 8 x 8 x 4 with 32 lanes alike): the last stage's
+            // butterfly j (j < NS3 = M / 4) produces the bins j + NS3 t, and the partner of bin k is bin M - k: butterfly j
+            // pairs with butterfly NS3 - j.  Which butterflies a lane takes is only a matter of the LDS addresses it
+            // loads from, so lane l takes j = l AND j = NS3 - l (lane 0: the two self-paired ones, 0 and NS3 / 2) and
+            // finds every partner in its own registers -- no exchange between lanes in the split step at all.
             stockham_stage<R1, 1, M, LPF, false, true>(v, fb, tw2, l);
             stockham_stage<R2, R1, M, LPF, true, true>(v, fb, tw2, l);
-            const int jb = (l == 0) ? 16 : 32 - l;
+            const int jb = (l == 0) ? NS3 / 2 : NS3 - l;
             float2 A[4], B[4];
             {
                 const int pa = pad16(l), pb = pad16(jb);
 #pragma unroll
-                for (int t = 0; t < 4; t++) {                        // pad16(j + 32 t) = pad16(j) + 34 t
-                    A[t] = fb[pa + 34 * t];
-                    B[t] = fb[pb + 34 * t];
+                for (int t = 0; t < 4; t++) {                        // pad16(j + NS3 t) = pad16(j) + NS3 t + NS3 t / 16
+                    A[t] = fb[pa + NS3 * t + NS3 * t / 16];
+                    B[t] = fb[pb + NS3 * t + NS3 * t / 16];
                 }
                 const v2f wa = as_v2f(tw3[l]), wb = as_v2f(tw3[jb]);
                 v2f qa = wa, qb = wb;
@@ -223,13 +235,13 @@ __global__ __launch_bounds__(256, 3) void spec_pack_kernel(
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // pairs (low bin k < 64, its partner 128 - k): lanes 1..15: (A0, B3) k = l; (A1, B2) k = 32 + l; (B1, A2)
-            // k = 64 - l; (B0, A3) k = 32 - l.  Lane 0: A0 = DC and Nyquist; (A1, A3) k = 32; (B1, B2) k = 48;
-            // (B0, B3) k = 16; A2 = bin 64, which pairs with itself.
+            // pairs (low bin k < M / 2, its partner M - k): lanes >= 1: (A0, B3) k = l; (A1, B2) k = NS3 + l; (B1, A2)
+            // k = 2 NS3 - l; (B0, A3) k = NS3 - l.  Lane 0: A0 = DC and Nyquist; (A1, A3) k = NS3; (B1, B2) k = 3 NS3 / 2;
+            // (B0, B3) k = NS3 / 2; A2 = bin M / 2, which pairs with itself.
             const bool l0 = l == 0;
             float pk[4], pm[4];
             int kk[4];
-            kk[0] = l; kk[1] = 32 + l; kk[2] = l0 ? 48 : 64 - l; kk[3] = l0 ? 16 : 32 - l;
+            kk[0] = l; kk[1] = NS3 + l; kk[2] = l0 ? 3 * NS3 / 2 : 2 * NS3 - l; kk[3] = l0 ? NS3 / 2 : NS3 - l;
             pair_psd(A[0], B[3], kk[0], pk[0], pm[0]);
             pair_psd(A[1], l0 ? A[3] : B[2], kk[1], pk[1], pm[1]);
             pair_psd(B[1], l0 ? B[2] : A[2], kk[2], pk[2], pm[2]);

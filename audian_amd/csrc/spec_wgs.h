@@ -80,10 +80,15 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wgs_kernel(
             nx[j] = make_float4(t.x, t.y, t.z, t.w);
         }
     };
-    // raw frame into LDS from (keep | nx); leaves the upper half in `keep`; the thread's share of the frame's sum
+    // The frame mean is taken relative to a PIVOT, the run's first sample (zero if that is not finite): on an offset plus
+    // something small a float32 sum of the samples carries 1e-7 of the OFFSET into bins 0 and 1, the sum of the differences
+    // 1e-7 of the small part (spec_pack.h has the case that showed it).
+    float pivot = (nv > 0) ? xc[fbeg * (long long)hop] : 0.f;
+    pivot = (fabsf(pivot) <= 3.0e38f) ? pivot : 0.f;
+    // raw frame into LDS from (keep | nx); leaves the upper half in `keep`; the thread's share of the sum of (sample - pivot)
     auto put_raw = [&]() -> float {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        auto add = [&](float4 v) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; };
+        auto add = [&](float4 v) { acc.x += v.x - pivot; acc.y += v.y - pivot; acc.z += v.z - pivot; acc.w += v.w - pivot; };
         if (HALF) {
 #pragma unroll
             for (int j = 0; j < NQ / 2; j++) {
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wgs_kernel(
                     const float ct = wgs_cos64(STEP * t), st = wgs_sin64(STEP * t);
                     const float w0 = 0.5f - 0.5f * (c0 * ct - s0 * st);
                     const float w1 = 0.5f - 0.5f * (c1 * ct - s1 * st);
-                    v[u * R1 + t] = make_float2((r.x - mean) * w0, (r.y - mean) * w1);
+                    v[u * R1 + t] = make_float2(((r.x - pivot) - mean) * w0, ((r.y - pivot) - mean) * w1);
                 }
             }
             stockham_stage<R1, 1, M, LPF, false, false>(v, fb, tw2, l);                  // first butterflies

@@ -185,6 +185,17 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? (DB ? 2 : 3) : 1) * WAV
         float *od = DB ? dc + frame * (long long)F : nullptr;
         float2 v[PPL];
         v2f acc = {0.f, 0.f};                             // even and odd samples side by side (v_pk_add_f32)
+        // the frame mean relative to a PIVOT (the first sample of the wave's first lane, wave-uniform; zero if it is not
+        // finite): on an offset plus something small a float32 sum of the samples carries 1e-7 of the OFFSET into bins
+        // 0 and 1, the sum of the differences 1e-7 of the small part (spec_pack.h has the case that showed it)
+        v2f pivot2;
+        {
+            v2f &r0 = qa[0];
+            asm volatile("" : "+v"(r0));                  // not before the counted wait
+            float pv = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r0.x)));
+            pv = (fabsf(pv) <= 3.0e38f) ? pv : 0.f;
+            pivot2 = (v2f){pv, pv};
+        }
 #pragma unroll
         for (int u = 0; u < PPL / R1; u++)
 #pragma unroll
@@ -192,8 +203,9 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? (DB ? 2 : 3) : 1) * WAV
                 v2f *const qs[4] = {qa, qb, qc, qd};
                 v2f &r = qs[t / R1Q][u * R1Q + t % R1Q];
                 asm volatile("" : "+v"(r));               // not before the counted wait
-                v[u * R1 + t] = make_float2(r.x, r.y);
-                acc += r;
+                const v2f d = r - pivot2;
+                v[u * R1 + t] = make_float2(d.x, d.y);
+                acc += d;
             }
         float s = acc.x + acc.y;
         if (LPF == 64) {

@@ -353,6 +353,42 @@ def test_short_windows_stream_runs_of_frames_through_lds(oracle, nfft):
         assert np.max(np.abs(got - o)/scale) < 1e-5, (nfft, hop)
 
 
+@pytest.mark.parametrize('nfft,hop', [(64, 32), (256, 128), (256, 100), (512, 256), (1024, 256), (2048, 1024), (4096, 2048),
+                                      (8192, 4096), (16384, 8192)])
+def test_spectrogram_of_an_offset_plus_something_small(oracle, nfft, hop):
+    """A trace that is a large offset plus a small signal -- raw data of the reference's default session (no filter,
+    bufferedfilter.py:40-42) from a sensor with a DC offset, or a filter's decaying transient: detrend='constant'
+    removes the offset, and a float32 sum of the samples would carry 1e-7 of the OFFSET into bins 0 and 1 of every
+    frame (1e-4 of the frame's peak already at offset / signal = 100).  The stand-alone kernels take the frame mean
+    relative to a pivot sample instead (tools/fuzz_stress.py found the case, seed 10268); a NaN as the pivot must not
+    spread to frames that do not hold it."""
+    from audian_amd import hipdsp
+    rate, C = 96000.0, 2
+    rng = np.random.default_rng(nfft + hop)
+    nframes = 40 if nfft <= 2048 else 12
+    T = (nframes - 1)*hop + nfft + 3
+    for offset, small in ((1000.0, 0.05), (-3.0, 1e-3), (0.5, 1e-5)):
+        x = (offset + small*rng.standard_normal((T, C))).astype(np.float32)
+        nd = (T + hop - 1)//hop
+        want = np.zeros((nd, C, nfft//2 + 1))
+        oracle.spectrogram_process(x.astype(np.float64), want, rate, nfft, hop)
+        got = gh.gpu_spectrogram(x, rate, nfft, hop, nd)
+        for ch in range(C):
+            for j in range(nd):
+                if np.max(np.abs(want[j, ch])) == 0:
+                    assert np.all(got[j, ch] == 0)
+                else:
+                    assert rel_err(got[j, ch], want[j, ch]) < TOL, (nfft, hop, offset, small, j, ch)
+    x = rng.standard_normal((T, C)).astype(np.float32)
+    x[0, 0] = np.nan                                   # the pivot of the first run of frames
+    nd = (T + hop - 1)//hop
+    want = np.zeros((nd, C, nfft//2 + 1))
+    oracle.spectrogram_process(x.astype(np.float64), want, rate, nfft, hop)
+    got = gh.gpu_spectrogram(x, rate, nfft, hop, nd)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), (nfft, hop)
+    assert np.all(np.isnan(got[0, 0])) and np.all(np.isfinite(got[(nfft + hop - 1)//hop:, 0]))
+
+
 def test_spectrogram_short_source_and_db(oracle):
     x = np.ones((100, 2), dtype=np.float32)
     got = gh.gpu_spectrogram(x, 48000.0, 256, 128, 3)
