@@ -1,0 +1,253 @@
+// spec_chip.h -- nfft 65536 of BufferedSpectrogram.process (the reference's selector offers 2^3 ... 2^19,
+// src/audian/databrowser.py:516) with the whole frame ON CHIP.  Included by spectrogram.hip inside its anonymous namespace.
+//
+// A frame of 65536 samples is 32768 complex points of the half-length transform: 256 KB, more than the 160 KB of LDS, which
+// is why round 1 ran it as Bailey's four-step algorithm through a scratch in HBM (52 bytes of traffic per complex point
+// against 8 algorithmic: 0.5 TB/s, profiles/r04k_spec_pmc_traffic.txt).  But the REGISTERS of one 512-thread workgroup hold
+// it: 64 points per thread, M = 32 x 32 x 32, two radix-32 butterflies per thread and stage, and each of the two exchanges
+// between stages goes through LDS in two halves of 16384 points (128 KB + padding) -- conveniently a thread's first
+// butterfly always writes into the lower half of the index space and its second into the upper one (j < 512 or not, at both
+// exchanges), so an exchange is: write half A, barrier, read A, barrier, write half B, barrier, read B, barrier.  No third
+// exchange for the split step: the last stage's butterfly j produces the bins j + 1024 t, the partner of bin k is bin
+// 32768 - k, so butterfly j pairs with butterfly 1024 - j, and which butterflies a thread takes at the last stage is only a
+// matter of the LDS addresses it reads: thread l takes j = l and 1024 - l (thread 0: the two self-paired ones, 0 and 512).
+// Window, stage twiddles and split twiddles are computed on the fly (v_cos_f32 / v_sin_f32 on exact fractions of a turn
+// for one base angle each, the rest by angle addition with compile-time constants or by powers), the frame mean relative to
+// a pivot sample (spec_pack.h).  HBM sees each frame's samples once per frame (the overlapped half a second time, a few
+// microseconds later, mostly from L2) and each bin once.
+#pragma once
+
+template <bool DB>
+__global__ __launch_bounds__(512, 2) void spec_chip65536_kernel(
+    const float *__restrict__ x, long long x_pitch, long long n_valid, long long frames_out, long long out_pitch, int hop,
+    float scale, float *__restrict__ out, float *__restrict__ db_out, int frames_per_block)
+{
+    constexpr int NFFT = 65536, M = NFFT / 2, F = M + 1, LPF = 512, R = 32, Q = M / R, H = M / 2;
+    __shared__ float2 xb[H + H / 32];
+    __shared__ float red[LPF / 64];
+    const int l = threadIdx.x, lane = l & 63, wave = l >> 6;
+    // exchange buffer index of element e: e + e / 32 (the writes of one instruction are 32 elements apart).  The constant
+    // parts are multiples of 32 everywhere, so each access is a per-lane base plus a compile-time offset.
+    auto pidx = [](int e) { return e + (e >> 5); };
+    const unsigned loff = 8u * (unsigned)l;
+    const int wr1 = 33 * l;                                  // pidx(32 l + t) = 33 l + t
+    const int rd1 = pidx(l);                                 // pidx(l + 512 b + 1024 t) = pidx(l) + 528 b + 1056 t
+    typedef float f2q __attribute__((ext_vector_type(2), aligned(4)));
+    const long long ch = blockIdx.y;
+    const float *xc = x + ch * x_pitch;
+    float *oc = out + ch * out_pitch;
+    float *dc = DB ? db_out + ch * out_pitch : nullptr;
+    const long long fbeg = (long long)blockIdx.x * frames_per_block;
+    long long nh = frames_out - fbeg;
+    if (nh > frames_per_block) nh = frames_per_block;
+    long long nvl = n_valid - fbeg;
+    const int nv = nvl <= 0 ? 0 : (nvl < nh ? (int)nvl : (int)nh);
+
+    // frame-invariant twiddle bases of this thread (exact fractions of a turn)
+    const int k2 = l & 31;                                   // stage 2: W_1024^(k2 t), the same k2 for both butterflies
+    const int j3a = l, j3b = (l == 0) ? 512 : 1024 - l;      // stage 3 butterflies: a pair of partners
+    auto cis = [](float turn) { return make_float2(__builtin_amdgcn_cosf(turn), -__builtin_amdgcn_sinf(turn)); };   // exp(-2 pi i turn)
+    float2 w2 = cis((float)k2 * (1.0f / 1024.0f));
+    float2 w3a = cis((float)j3a * (1.0f / 32768.0f)), w3b = cis((float)j3b * (1.0f / 32768.0f));
+    float2 sa = cis((float)j3a * (1.0f / 65536.0f)), sb = cis((float)j3b * (1.0f / 65536.0f));   // split twiddles of the first bins
+
+    for (int it = 0; it < nv; it++) {
+        const long long frame = fbeg + it;
+        const float *seg = xc + frame * (long long)hop;
+        float pivot = seg[0];                                // mean and window relative to a sample of the frame (spec_pack.h)
+        pivot = (fabsf(pivot) <= 3.0e38f) ? pivot : 0.f;
+        int zero = 0;                                        // (keeps the frame-invariant window and twiddle powers out of the
+        asm volatile("" : "+v"(zero));                       // loop's preheader: hoisted, they would fill the register file)
+        asm volatile("" : "+v"(w2.x), "+v"(w2.y), "+v"(w3a.x), "+v"(w3a.y), "+v"(w3b.x), "+v"(w3b.y));
+        asm volatile("" : "+v"(sa.x), "+v"(sa.y), "+v"(sb.x), "+v"(sb.y));
+        // ---- stage 1 inputs: z[n] = (x[2n], x[2n+1]), n = j + 1024 t, butterflies j = l and l + 512
+        float2 v0[R], v1[R];
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+            // (a uniform base per load plus one 32-bit lane offset: 64 lane addresses of 64 bits would be half the registers)
+            const f2q a = *reinterpret_cast<const f2q *>(reinterpret_cast<const char *>(seg + 2 * Q * t) + loff);
+            const f2q b = *reinterpret_cast<const f2q *>(reinterpret_cast<const char *>(seg + 2 * Q * t + 1024) + loff);
+            v0[t] = make_float2(a.x - pivot, a.y - pivot);
+            v1[t] = make_float2(b.x - pivot, b.y - pivot);
+            s += (v0[t].x + v0[t].y) + (v1[t].x + v1[t].y);
+        }
+        s = wave_sum(s);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        float total = 0.f;
+#pragma unroll
+        for (int w = 0; w < LPF / 64; w++) total += red[w];
+        const float mean = total * (1.0f / (float)NFFT);
+        {
+            // periodic Hann 0.5 - 0.5 cos(2 pi i / nfft) at i = 2n, 2n + 1: n = l + 1024 t is t / 32 of a turn further on,
+            // the second butterfly 1 / 64 of a turn
+            const float a0 = (float)(2 * l + zero) * (1.0f / (float)NFFT), a1 = (float)(2 * l + 1 + zero) * (1.0f / (float)NFFT);
+            const float c0 = __builtin_amdgcn_cosf(a0), s0 = __builtin_amdgcn_sinf(a0);
+            const float c1 = __builtin_amdgcn_cosf(a1), s1 = __builtin_amdgcn_sinf(a1);
+#pragma unroll
+            for (int t = 0; t < R; t++) {
+                const float ca = wgs_cos64(2 * t), sn = wgs_sin64(2 * t);
+                const float cb = wgs_cos64(2 * t + 1), sb2 = wgs_sin64(2 * t + 1);
+                v0[t].x = (v0[t].x - mean) * (0.5f - 0.5f * (c0 * ca - s0 * sn));
+                v0[t].y = (v0[t].y - mean) * (0.5f - 0.5f * (c1 * ca - s1 * sn));
+                v1[t].x = (v1[t].x - mean) * (0.5f - 0.5f * (c0 * cb - s0 * sb2));
+                v1[t].y = (v1[t].y - mean) * (0.5f - 0.5f * (c1 * cb - s1 * sb2));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);       // (one butterfly at a time: two interleaved ones do not fit the registers)
+        dft<32>(v0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- exchange 1 -> 2: butterfly j's outputs are elements 32 j + t'; stage 2's butterfly j2 reads j2 + 1024 t.
+        // (The first butterfly's half is on its way into LDS while the VALU transforms the second one.)
+#pragma unroll
+        for (int t = 0; t < R; t++) xb[wr1 + t] = v0[t];
+        __builtin_amdgcn_sched_barrier(0);
+        dft<32>(v1);
+        __builtin_amdgcn_sched_barrier(0);
+        float2 u0[R], u1[R];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < R / 2; t++) {
+            u0[t] = xb[rd1 + 1056 * t];
+            u1[t] = xb[rd1 + 528 + 1056 * t];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < R; t++) xb[wr1 + t] = v1[t];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < R / 2; t++) {
+            u0[R / 2 + t] = xb[rd1 + 1056 * t];
+            u1[R / 2 + t] = xb[rd1 + 528 + 1056 * t];
+        }
+        __syncthreads();
+        // ---- stage 2: W_1024^(k2 t) by powers (the same for both butterflies)
+        {
+            v2f w = as_v2f(w2);
+#pragma unroll
+            for (int t = 1; t < R; t++) {
+                u0[t] = as_f2(pk_cmul(as_v2f(u0[t]), w));
+                u1[t] = as_f2(pk_cmul(as_v2f(u1[t]), w));
+                if (t + 1 < R) w = pk_cmul(w, as_v2f(w2));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);       // (one butterfly at a time: two interleaved ones do not fit the registers)
+        dft<32>(u0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- exchange 2 -> 3: butterfly j2's output t2 is element (j2 / 32) 1024 + j2 % 32 + 32 t2
+        const int wr2 = (l >> 5) * (Q + 32) + (l & 31);      // pidx((l / 32) 1024 + l % 32 + 32 t) = this + 33 t
+#pragma unroll
+        for (int t = 0; t < R; t++) xb[wr2 + 33 * t] = u0[t];
+        __builtin_amdgcn_sched_barrier(0);
+        dft<32>(u1);
+        __builtin_amdgcn_sched_barrier(0);
+        float2 ya[R], yb[R];
+        const int ra = pidx(j3a), rb = pidx(j3b);            // pidx(j3 + 1024 t) = pidx(j3) + 1056 t
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < R / 2; t++) {
+            ya[t] = xb[ra + 1056 * t];
+            yb[t] = xb[rb + 1056 * t];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < R; t++) xb[wr2 + 33 * t] = u1[t];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < R / 2; t++) {
+            ya[R / 2 + t] = xb[ra + 1056 * t];
+            yb[R / 2 + t] = xb[rb + 1056 * t];
+        }
+        __syncthreads();
+        // ---- stage 3: W_32768^(j3 t) by powers
+        {
+            v2f wa = as_v2f(w3a), wb = as_v2f(w3b);
+#pragma unroll
+            for (int t = 1; t < R; t++) {
+                ya[t] = as_f2(pk_cmul(as_v2f(ya[t]), wa));
+                yb[t] = as_f2(pk_cmul(as_v2f(yb[t]), wb));
+                if (t + 1 < R) { wa = pk_cmul(wa, as_v2f(w3a)); wb = pk_cmul(wb, as_v2f(w3b)); }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);       // (one butterfly at a time: two interleaved ones do not fit the registers)
+        dft<32>(ya);
+        __builtin_amdgcn_sched_barrier(0);
+        dft<32>(yb);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- split step and PSD: ya[t] = Z[j3a + 1024 t], yb[t] = Z[j3b + 1024 t].  Pairs (low bin k <= M / 2, partner
+        // M - k), t' < 16: (ya[t'], yb[31 - t']) k = l + 1024 t' and (yb[t'], ya[31 - t']) k = 1024 - l + 1024 t'; thread 0:
+        // ya[0] = DC and Nyquist, (ya[t'], ya[32 - t']) k = 1024 t', (yb[t'], yb[31 - t']) k = 512 + 1024 t', ya[16] = bin
+        // M / 2, which pairs with itself.  exp(-2 pi i k / nfft): the first bin's angle plus t' / 64 of a turn.
+        float *o = oc + frame * (long long)F;
+        float *od = DB ? dc + frame * (long long)F : nullptr;
+        const bool l0 = l == 0;
+        const v2f hscale2 = {0.5f * scale, 0.5f * scale};
+        auto pair_psd = [&](float2 zk, float2 zm, float2 tw, float &pk, float &pm) {
+            const v2f e = pk_add_conj(as_v2f(zk), as_v2f(zm));
+            const v2f t = pk_cmul_negi(pk_sub_conj(as_v2f(zk), as_v2f(zm)), as_v2f(tw));
+            const v2f re = pk_sumdiff_x(e, t), im = pk_sumdiff_y(e, t);
+            const v2f pw = (re * re + im * im) * hscale2;
+            pk = pw.x; pm = pw.y;
+        };
+        // bin j + 1024 t and its partner M - j - 1024 t: a uniform base per store plus a 32-bit lane offset (as for the loads)
+        auto put = [&](int t, unsigned lo, unsigned lm, float pk, float pm) {
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(o + Q * t) + lo) = pk;
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(o + (M - Q) - Q * t) + lm) = pm;
+            if (DB) {
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(od + Q * t) + lo) = to_db(pk);
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(od + (M - Q) - Q * t) + lm) = to_db(pm);
+            }
+        };
+        const unsigned loa = 4u * (unsigned)j3a, lma = 4u * (unsigned)(Q - j3a), lob = 4u * (unsigned)j3b, lmb = 4u * (unsigned)(Q - j3b);
+#pragma unroll
+        for (int t = 0; t < R / 2; t++) {
+            // exp(-2 pi i (k0 + 1024 t) / 65536) = base * exp(-2 pi i t / 64)
+            const float ct = wgs_cos64(t), st = wgs_sin64(t);
+            const float2 twa = make_float2(sa.x * ct + sa.y * st, sa.y * ct - sa.x * st);
+            const float2 twb = make_float2(sb.x * ct + sb.y * st, sb.y * ct - sb.x * st);
+            float pk, pm;
+            // (selects of VALUES: `l0 ? ya[i] : yb[j]` is a select of addresses and keeps the arrays in scratch memory)
+            const float2 pa0 = ya[t == 0 ? 0 : 32 - t], pa1 = yb[31 - t], pb0 = yb[31 - t], pb1 = ya[31 - t];
+            pair_psd(ya[t], make_float2(l0 ? pa0.x : pa1.x, l0 ? pa0.y : pa1.y), twa, pk, pm);
+            if (t == 0) {
+                const float dc0 = ya[0].x + ya[0].y, ny = ya[0].x - ya[0].y;     // DC and Nyquist, not doubled
+                pk = l0 ? dc0 * dc0 * scale : pk;
+                pm = l0 ? ny * ny * scale : pm;
+            }
+            put(t, loa, lma, pk, pm);
+            pair_psd(yb[t], make_float2(l0 ? pb0.x : pb1.x, l0 ? pb0.y : pb1.y), twb, pk, pm);
+            put(t, lob, lmb, pk, pm);
+        }
+        if (l0) {
+            const float ph = 2.f * scale * (ya[16].x * ya[16].x + ya[16].y * ya[16].y);
+            o[M / 2] = ph;
+            if (DB) od[M / 2] = to_db(ph);
+        }
+        __syncthreads();                                     // (red[] and the exchange buffer are reused by the next frame)
+    }
+    // frames behind the last valid one (bufferedspectrogram.py:59)
+    for (long long frame = fbeg + nv; frame < fbeg + nh; frame++) {
+        float *o = oc + frame * (long long)F;
+        for (int f = l; f < F; f += LPF) {
+            o[f] = 0.f;
+            if (DB) dc[frame * (long long)F + f] = -INFINITY;
+        }
+    }
+}
+
+inline int run_chip65536(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long channels, long long n_valid,
+                         long long frames_out, long long out_pitch, int hop, float scale, float *out, float *db_out)
+{
+    long long fpb = ctx->spec_fpw > 0 ? ctx->spec_fpw : frames_out * channels / ((long long)ctx->n_cus * 4);
+    if (fpb < 1) fpb = 1;
+    if (fpb > 16) fpb = 16;
+    const dim3 grid((unsigned)((frames_out + fpb - 1) / fpb), (unsigned)channels);
+    if (db_out)
+        hipLaunchKernelGGL((spec_chip65536_kernel<true>), grid, dim3(512), 0, ctx->stream, x, x_pitch, n_valid, frames_out,
+                           out_pitch, hop, scale, out, db_out, (int)fpb);
+    else
+        hipLaunchKernelGGL((spec_chip65536_kernel<false>), grid, dim3(512), 0, ctx->stream, x, x_pitch, n_valid, frames_out,
+                           out_pitch, hop, scale, out, db_out, (int)fpb);
+    return hd_launch_status("spec_chip65536_kernel");
+}

@@ -1096,6 +1096,7 @@ int run_fast(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long chann
 
 #include "spec_pack.h"
 #include "spec_wgs.h"
+#include "spec_chip.h"
 
 template <int NFFT, int LPF, int R1, int R2, int R3, int OCC>
 int run_wg(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long channels, long long n_valid,
@@ -1235,6 +1236,9 @@ extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pit
         return old_wg
                    ? run_wg<32768, 512, 16, 32, 32, 2>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out)
                       : run_wgs<32768, 512, 16, 32, 32, 1>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+    // 65536: the frame in the registers of one workgroup (spec_chip.h); "spec_kernel" 2: the four-step path through HBM
+    if (!ctx->force_generic_fft && nfft == 65536 && !old_wg)
+        return run_chip65536(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
     if (nfft > 8192)
         return run_big(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, nfft, hop, scale, out, db_out);
     size_t lds = sizeof(float2) * 2 * (size_t)nfft;

@@ -601,6 +601,43 @@ def test_spectrogram_large_nfft_four_step(oracle, nfft, hop, nframes):
         gh.gpu_spectrogram(x, rate, 1 << 20, 1 << 19, 1)
 
 
+@pytest.mark.parametrize('hop,nframes', [(32768, 9), (8192, 21), (1001, 37), (65536, 5)])
+def test_spectrogram_65536_with_the_frame_on_chip(oracle, hop, nframes):
+    """nfft 65536 (spec_chip.h: the frame in the registers of a 512-thread workgroup, two exchanges through LDS) against the
+    oracle and against the four-step path through HBM it replaces ("spec_kernel" 2): runs of frames that end inside a
+    workgroup's run, hops that leave the frames at odd addresses, a tail of frames behind the last whole window, the dB
+    image, and an offset of 300 times the signal's amplitude on one channel (the frame mean relative to a pivot)."""
+    from audian_amd import hipdsp
+    nfft, rate, C = 65536, 192000.0, 3
+    rng = np.random.default_rng(hop)
+    T = (nframes - 1)*hop + nfft + 17
+    x = synth(rng, T, C, rate)
+    x[:, 1] = np.float32(0.01)*x[:, 1] + np.float32(3.0)
+    nd = nframes + 2
+    want = np.zeros((nd, C, nfft//2 + 1))
+    oracle.spectrogram_process(x.astype(np.float64), want, rate, nfft, hop)
+    c = gh.ctx()
+    try:
+        for fpw in (0, 1, 4):
+            c.set_option('spec_fpw', fpw)
+            got, db = gh.gpu_spectrogram(x, rate, nfft, hop, nd, want_db=True)
+            for ch in range(C):
+                for j in range(nd):
+                    if np.max(np.abs(want[j, ch])) == 0:
+                        assert j >= nframes and np.all(got[j, ch] == 0) and np.all(db[j, ch] == -np.inf)
+                    else:
+                        assert rel_err(got[j, ch], want[j, ch]) < TOL, (hop, fpw, j, ch)
+            fin = got > 1e-20
+            assert np.max(np.abs(db[fin] - 10*np.log10(got[fin]))) < 1e-3
+        c.set_option('spec_kernel', 2)
+        old = gh.gpu_spectrogram(x, rate, nfft, hop, nd)
+        for ch in range(C):
+            assert rel_err(got[:, ch], old[:, ch]) < 2e-5
+    finally:
+        c.set_option('spec_kernel', 0)
+        c.set_option('spec_fpw', 0)
+
+
 @pytest.mark.parametrize('nfft,hop', [(100, 30), (6174, 3087), (1000, 1000), (4097, 2000), (9, 4)])
 def test_spectrogram_arbitrary_nfft_direct_dft(oracle, nfft, hop):
     """nfft values the reference's clamp to len(source)//2 can produce (not powers of two)."""

@@ -11,6 +11,8 @@ hopdiv = int(os.environ.get('HOPDIV', '2'))
 ctx = hipdsp.Context(0)
 if os.environ.get('SPEC_KERNEL'):
     ctx.set_option('spec_kernel', int(os.environ['SPEC_KERNEL']))      # 2: the alternative kernel of a size
+if os.environ.get('FPW'):
+    ctx.set_option('spec_fpw', int(os.environ['FPW']))                 # frames per wave / workgroup run instead of the heuristic
 dx = hipdsp.DeviceArray(ctx, (C, T), np.float32)
 hipdsp.synth(ctx, dx, T, C, T, rate, 7)
 e0, e1 = ctx.event(), ctx.event()
