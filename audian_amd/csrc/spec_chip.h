@@ -20,7 +20,8 @@
 template <bool DB>
 __global__ __launch_bounds__(512, 2) void spec_chip65536_kernel(
     const float *__restrict__ x, long long x_pitch, long long n_valid, long long frames_out, long long out_pitch, int hop,
-    float scale, float *__restrict__ out, float *__restrict__ db_out, int frames_per_block)
+    float scale, float *__restrict__ out, float *__restrict__ db_out, int frames_per_block, long long runs_per_channel,
+    long long total_runs)
 {
     constexpr int NFFT = 65536, M = NFFT / 2, F = M + 1, LPF = 512, R = 32, Q = M / R, H = M / 2;
     __shared__ float2 xb[H + H / 32];
@@ -33,11 +34,17 @@ __global__ __launch_bounds__(512, 2) void spec_chip65536_kernel(
     const int wr1 = 33 * l;                                  // pidx(32 l + t) = 33 l + t
     const int rd1 = pidx(l);                                 // pidx(l + 512 b + 1024 t) = pidx(l) + 528 b + 1056 t
     typedef float f2q __attribute__((ext_vector_type(2), aligned(4)));
-    const long long ch = blockIdx.y;
+    // Workgroups are dealt to the eight XCDs round-robin by their linear id; each XCD has its own L2.  The runs of frames
+    // are numbered so that an XCD works on CONSECUTIVE runs at any time: the half a frame shares with its neighbour is
+    // then fetched by two CUs of one XCD within microseconds of each other -- one trip to HBM, not two.
+    const long long per_xcd = (total_runs + 7) / 8;
+    const long long w = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((long long)(blockIdx.x >> 3) >= per_xcd || w >= total_runs) return;
+    const long long ch = w / runs_per_channel;
     const float *xc = x + ch * x_pitch;
     float *oc = out + ch * out_pitch;
     float *dc = DB ? db_out + ch * out_pitch : nullptr;
-    const long long fbeg = (long long)blockIdx.x * frames_per_block;
+    const long long fbeg = (w % runs_per_channel) * frames_per_block;
     long long nh = frames_out - fbeg;
     if (nh > frames_per_block) nh = frames_per_block;
     long long nvl = n_valid - fbeg;
@@ -239,15 +246,18 @@ __global__ __launch_bounds__(512, 2) void spec_chip65536_kernel(
 inline int run_chip65536(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long channels, long long n_valid,
                          long long frames_out, long long out_pitch, int hop, float scale, float *out, float *db_out)
 {
-    long long fpb = ctx->spec_fpw > 0 ? ctx->spec_fpw : frames_out * channels / ((long long)ctx->n_cus * 4);
-    if (fpb < 1) fpb = 1;
+    // (a run of ONE frame: neighbours in time are then neighbours on the XCD, and the half they share is in L2; a longer run
+    // only amortises a thread's five base twiddles and re-reads its own shared halves 30 us later, from HBM)
+    long long fpb = ctx->spec_fpw > 0 ? ctx->spec_fpw : 1;
     if (fpb > 16) fpb = 16;
-    const dim3 grid((unsigned)((frames_out + fpb - 1) / fpb), (unsigned)channels);
+    const long long runs = (frames_out + fpb - 1) / fpb, total = runs * channels;
+    HD_REQUIRE(total <= 0x7ffffff0LL, "too many frames");
+    const dim3 grid((unsigned)(((total + 7) / 8) * 8));
     if (db_out)
         hipLaunchKernelGGL((spec_chip65536_kernel<true>), grid, dim3(512), 0, ctx->stream, x, x_pitch, n_valid, frames_out,
-                           out_pitch, hop, scale, out, db_out, (int)fpb);
+                           out_pitch, hop, scale, out, db_out, (int)fpb, runs, total);
     else
         hipLaunchKernelGGL((spec_chip65536_kernel<false>), grid, dim3(512), 0, ctx->stream, x, x_pitch, n_valid, frames_out,
-                           out_pitch, hop, scale, out, db_out, (int)fpb);
+                           out_pitch, hop, scale, out, db_out, (int)fpb, runs, total);
     return hd_launch_status("spec_chip65536_kernel");
 }
