@@ -48,6 +48,7 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wgs_kernel(
     // points per thread); at 32 points per thread the registers do not go that far (106-150 spilled), so those sizes
     // fetch the next frame once this one's bins are on their way -- the other workgroup of the CU covers the wait
     constexpr bool PIPE = PPL <= 16;
+    constexpr bool KEEPW = PPL <= 16 && LPF >= 256;     // (nfft 8192; at 4096 the 32 registers are not there: spills)
     __shared__ __attribute__((aligned(16))) float2 smem[TW2 + TW3 + MP];
     __shared__ float red[NW];
     const float2 *tw2 = smem, *tw3 = smem + TW2;
@@ -108,6 +109,30 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wgs_kernel(
         if (lane == 0) red[wave] = s;
     };
 
+    // periodic Hann 0.5 - 0.5 cos(2 pi i / nfft) at i = 2n, 2n + 1, n = n0 + t M / R1, n0 = l + LPF u: the angle of input t is
+    // that of input 0 plus t / R1 of a turn (the argument of v_cos_f32 / v_sin_f32 is in turns), so two transcendental
+    // pairs and the angle-addition formulas with compile-time constants give a thread's R1 window pairs
+    static_assert(64 % R1 == 0, "first-stage inputs a multiple of 1/64 turn apart");
+    auto window_of = [&](int u, int zero, float2 *w) {
+        const int n0 = l + LPF * u + zero;
+        const float a0 = (float)(2 * n0) * (1.0f / (float)NFFT), a1 = (float)(2 * n0 + 1) * (1.0f / (float)NFFT);
+        const float c0 = __builtin_amdgcn_cosf(a0), s0 = __builtin_amdgcn_sinf(a0);
+        const float c1 = __builtin_amdgcn_cosf(a1), s1 = __builtin_amdgcn_sinf(a1);
+#pragma unroll
+        for (int t = 0; t < R1; t++) {
+            constexpr int STEP = 64 / R1;
+            const float ct = wgs_cos64(STEP * t), st = wgs_sin64(STEP * t);
+            w[t] = make_float2(0.5f - 0.5f * (c0 * ct - s0 * st), 0.5f - 0.5f * (c1 * ct - s1 * st));
+        }
+    };
+    // KEEPW: where the registers allow (16 points per thread), the thread's window values stay in registers for the whole run
+    // of frames; elsewhere they are recomputed per frame (an opaque zero in their argument keeps hipcc from hoisting them)
+    float2 wkeep[KEEPW ? PPL : 1];
+    if (KEEPW) {
+#pragma unroll
+        for (int u = 0; u < PPL / R1; u++) window_of(u, 0, wkeep + (KEEPW ? u * R1 : 0));
+    }
+
     if (nv > 0) {
         if (HALF) {
             // the first frame whole: its lower half through `keep`
@@ -135,23 +160,15 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wgs_kernel(
             int zero = 0;
             asm volatile("" : "+v"(zero));
             float2 v[PPL];
-            static_assert(64 % R1 == 0, "first-stage inputs a multiple of 1/64 turn apart");
 #pragma unroll
             for (int u = 0; u < PPL / R1; u++) {
-                // periodic Hann 0.5 - 0.5 cos(2 pi i / nfft) at i = 2n, 2n + 1, n = n0 + t M / R1: the angle of input t is
-                // that of input 0 plus t / R1 of a turn (the argument of v_cos_f32 / v_sin_f32 is in turns)
-                const int n0 = l + LPF * u + zero;
-                const float a0 = (float)(2 * n0) * (1.0f / (float)NFFT), a1 = (float)(2 * n0 + 1) * (1.0f / (float)NFFT);
-                const float c0 = __builtin_amdgcn_cosf(a0), s0 = __builtin_amdgcn_sinf(a0);
-                const float c1 = __builtin_amdgcn_cosf(a1), s1 = __builtin_amdgcn_sinf(a1);
+                float2 wl[R1];
+                if (!KEEPW) window_of(u, zero, wl);
 #pragma unroll
                 for (int t = 0; t < R1; t++) {
                     const float2 r = raw2[l + LPF * u + t * (M / R1)];
-                    constexpr int STEP = 64 / R1;
-                    const float ct = wgs_cos64(STEP * t), st = wgs_sin64(STEP * t);
-                    const float w0 = 0.5f - 0.5f * (c0 * ct - s0 * st);
-                    const float w1 = 0.5f - 0.5f * (c1 * ct - s1 * st);
-                    v[u * R1 + t] = make_float2(((r.x - pivot) - mean) * w0, ((r.y - pivot) - mean) * w1);
+                    const float2 w = KEEPW ? wkeep[u * R1 + t] : wl[t];
+                    v[u * R1 + t] = make_float2(((r.x - pivot) - mean) * w.x, ((r.y - pivot) - mean) * w.y);
                 }
             }
             stockham_stage<R1, 1, M, LPF, false, false>(v, fb, tw2, l);                  // first butterflies
@@ -164,42 +181,53 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wgs_kernel(
             __syncthreads();
             stockham_stage<R3, R1 * R2, M, LPF, true, false, true>(v, fb, tw3, l);
             __syncthreads();
-            // v[(m % NB3) * R3 + m / NB3] = Z[k], k = l + LPF m; natural order into LDS for the partner bins Z[M-k]
+            // v[(m % NB3) * R3 + m / NB3] = Z[k], k = l + LPF m; natural order into LDS for the partner bins Z[M-k] -- only
+            // the upper half of the bins (and bin 0) is anybody's partner
 #pragma unroll
-            for (int m = 0; m < PPL; m++) fb[pad16(l) + LPF * m + LPF * m / 16] = v[(m % NB3) * R3 + m / NB3];
+            for (int m = 0; m < PPL; m++)
+                if (m == 0 || m >= PPL / 2) fb[pad16(l) + LPF * m + LPF * m / 16] = v[(m % NB3) * R3 + m / NB3];
             __syncthreads();
             float *o = oc + frame * (long long)F;
             float *od = DB ? dc + frame * (long long)F : nullptr;
             float pk[PPL / 2], pm[PPL / 2], ph = 0.f;
+            // bins k = l + LPF m and M - k: a uniform base per store plus a 32-bit lane offset (a 64-bit address per lane and
+            // store costs two VALU instructions and two registers each)
+            const unsigned lo4 = 4u * (unsigned)l, lm4 = 4u * (unsigned)(LPF - l);
+            auto put = [&](int m, float a, float b) {
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(o + LPF * m) + lo4) = a;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(o + (M - LPF) - LPF * m) + lm4) = b;
+                if (DB) {
+                    *reinterpret_cast<float *>(reinterpret_cast<char *>(od + LPF * m) + lo4) = to_db(a);
+                    *reinterpret_cast<float *>(reinterpret_cast<char *>(od + (M - LPF) - LPF * m) + lm4) = to_db(b);
+                }
+            };
             // exp(-2 pi i k / nfft) at k = l + LPF m: bin 0's angle plus m LPF / nfft of a turn
             static_assert((64 * LPF) % NFFT == 0, "bins a multiple of 1/64 turn apart");
             const float tb = (float)(l + zero) * (1.0f / (float)NFFT);
             const float cb = __builtin_amdgcn_cosf(tb), sb = __builtin_amdgcn_sinf(tb);
+            const v2f hscale2 = {0.5f * scale, 0.5f * scale};
 #pragma unroll
             for (int m = 0; m < PPL / 2; m++) {
                 const int k = l + LPF * m;
                 const float2 zk = v[(m % NB3) * R3 + m / NB3];
                 const float2 zm = fb[pad16((M - k) & (M - 1))];
-                if (m == 0 && l == 0) {
+                constexpr int BSTEP = 64 * LPF / NFFT;
+                const float cm = wgs_cos64(BSTEP * m), sm = wgs_sin64(BSTEP * m);
+                const v2f tw = {cb * cm - sb * sm, -(sb * cm + cb * sm)};                         // exp(-2 pi i k / nfft)
+                // X[k] = E + W O and X[M-k] = conj(E - W O) with 2 E = Z[k] + conj(Z[M-k]), 2 O = -i (Z[k] - conj(Z[M-k])), in
+                // packed arithmetic (spec_pack.h's pair_psd)
+                const v2f e = pk_add_conj(as_v2f(zk), as_v2f(zm));
+                const v2f t = pk_cmul_negi(pk_sub_conj(as_v2f(zk), as_v2f(zm)), tw);
+                const v2f re = pk_sumdiff_x(e, t), im = pk_sumdiff_y(e, t);
+                const v2f pw = (re * re + im * im) * hscale2;
+                pk[m] = pw.x;
+                pm[m] = pw.y;
+                if (m == 0) {
                     const float a = zk.x + zk.y, b = zk.x - zk.y;    // DC and Nyquist, not doubled
-                    pk[m] = a * a * scale;
-                    pm[m] = b * b * scale;
-                } else {
-                    constexpr int BSTEP = 64 * LPF / NFFT;
-                    const float cm = wgs_cos64(BSTEP * m), sm = wgs_sin64(BSTEP * m);
-                    const float2 tw = make_float2(cb * cm - sb * sm, -(sb * cm + cb * sm));      // exp(-2 pi i k / nfft)
-                    const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-                    const float2 o = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
-                    const float2 t = cmul(o, tw);
-                    const float2 a = cadd(e, t), b = csub(e, t);
-                    pk[m] = 2.f * scale * (a.x * a.x + a.y * a.y);
-                    pm[m] = 2.f * scale * (b.x * b.x + b.y * b.y);
+                    pk[m] = (l == 0) ? a * a * scale : pk[m];
+                    pm[m] = (l == 0) ? b * b * scale : pm[m];
                 }
-                if (!PIPE) {                                         // (nothing is held back: the bins leave at once)
-                    o[k] = pk[m];
-                    o[M - k] = pm[m];
-                    if (DB) { od[k] = to_db(pk[m]); od[M - k] = to_db(pm[m]); }
-                }
+                if (!PIPE) put(m, pk[m], pm[m]);                     // (nothing is held back: the bins leave at once)
             }
             if (l == 0) {                                            // k = M / 2 pairs with itself
                 const float2 z = v[((PPL / 2) % NB3) * R3 + (PPL / 2) / NB3];
@@ -219,12 +247,7 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wgs_kernel(
             }
             if (PIPE) {
 #pragma unroll
-                for (int m = 0; m < PPL / 2; m++) {
-                    const int k = l + LPF * m;
-                    o[k] = pk[m];
-                    o[M - k] = pm[m];
-                    if (DB) { od[k] = to_db(pk[m]); od[M - k] = to_db(pm[m]); }
-                }
+                for (int m = 0; m < PPL / 2; m++) put(m, pk[m], pm[m]);
                 if (l == 0) {
                     o[M / 2] = ph;
                     if (DB) od[M / 2] = to_db(ph);
