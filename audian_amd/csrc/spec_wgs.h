@@ -86,21 +86,24 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wgs_kernel(
     // 1e-7 of the small part (spec_pack.h has the case that showed it).
     float pivot = (nv > 0) ? xc[fbeg * (long long)hop] : 0.f;
     pivot = (fabsf(pivot) <= 3.0e38f) ? pivot : 0.f;
-    // raw frame into LDS from (keep | nx); leaves the upper half in `keep`; the thread's share of the sum of (sample - pivot)
+    // the frame, as differences to the pivot, into LDS from (keep | nx); leaves the upper half in `keep` (differences as
+    // well: a sample meets the pivot once); returns the thread's share of the sum of the differences
     auto put_raw = [&]() -> float {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        auto add = [&](float4 v) { acc.x += v.x - pivot; acc.y += v.y - pivot; acc.z += v.z - pivot; acc.w += v.w - pivot; };
+        auto add = [&](float4 v) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; };
+        auto rel = [&](float4 v) { return make_float4(v.x - pivot, v.y - pivot, v.z - pivot, v.w - pivot); };
         if (HALF) {
 #pragma unroll
             for (int j = 0; j < NQ / 2; j++) {
+                const float4 d = rel(nx[j]);
                 raw4[l + LPF * j] = keep[j];
-                raw4[l + LPF * (j + NQ / 2)] = nx[j];
-                add(keep[j]); add(nx[j]);
-                keep[j] = nx[j];
+                raw4[l + LPF * (j + NQ / 2)] = d;
+                add(keep[j]); add(d);
+                keep[j] = d;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < NQ; j++) { raw4[l + LPF * j] = nx[j]; add(nx[j]); }
+            for (int j = 0; j < NQ; j++) { const float4 d = rel(nx[j]); raw4[l + LPF * j] = d; add(d); }
         }
         return (acc.x + acc.y) + (acc.z + acc.w);
     };
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wgs_kernel(
 #pragma unroll
             for (int j = 0; j < NQ / 2; j++) {
                 const f4q t = *reinterpret_cast<const f4q *>(seg + 4 * (l + LPF * j));
-                keep[j] = make_float4(t.x, t.y, t.z, t.w);
+                keep[j] = make_float4(t.x - pivot, t.y - pivot, t.z - pivot, t.w - pivot);
             }
         }
         fetch(fbeg);
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wgs_kernel(
                 for (int t = 0; t < R1; t++) {
                     const float2 r = raw2[l + LPF * u + t * (M / R1)];
                     const float2 w = KEEPW ? wkeep[u * R1 + t] : wl[t];
-                    v[u * R1 + t] = make_float2(((r.x - pivot) - mean) * w.x, ((r.y - pivot) - mean) * w.y);
+                    v[u * R1 + t] = make_float2((r.x - mean) * w.x, (r.y - mean) * w.y);     // (r: sample - pivot)
                 }
             }
             stockham_stage<R1, 1, M, LPF, false, false>(v, fb, tw2, l);                  // first butterflies
