@@ -6,6 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/spec_pmc
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+export WARM_CALLS=0 TIMED_CALLS=4      # the summaries count on 2 + 4 calls per variant and no other kernel
 for n in "$@"; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch_$n --output-format csv -- python3 $R/tools/spec_sizes_bench.py $n > $O/fetch_$n.log 2>&1 || exit 1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write_$n --output-format csv -- python3 $R/tools/spec_sizes_bench.py $n > $O/write_$n.log 2>&1 || exit 1

@@ -16,6 +16,13 @@ if os.environ.get('FPW'):
 dx = hipdsp.DeviceArray(ctx, (C, T), np.float32)
 hipdsp.synth(ctx, dx, T, C, T, rate, 7)
 e0, e1 = ctx.event(), ctx.event()
+ncalls = int(os.environ.get('TIMED_CALLS', '8'))       # (tools/spec_pmc.sh and spec_sq.sh count on 2 + 4 calls per variant)
+# the clocks come up over a few hundred milliseconds of load: without this the first sizes of a short list read 10-15 % low
+_w = hipdsp.DeviceArray(ctx, (C, (T + 1023)//1024, 1025), np.float32)
+for _ in range(int(os.environ.get('WARM_CALLS', '60'))):
+    hipdsp.spectrogram(ctx, dx, T, C, T, 2048, 1024, rate, _w, (T + 1023)//1024)
+ctx.synchronize()
+_w.free()
 # PAIRS="1024:100,256:37": arbitrary overlaps (the reference's overlap spin box, databrowser.py:522-529) instead of the size list
 pairs = [(n, max(n//hopdiv, 1)) for n in sizes]
 if os.environ.get('PAIRS'):
@@ -29,10 +36,10 @@ for nfft, hop in pairs:
         for _ in range(2):
             hipdsp.spectrogram(ctx, dx, T, C, t, nfft, hop, rate, ds, nd, db_out=db)
         ctx.record(e0)
-        for _ in range(4):
+        for _ in range(ncalls):
             hipdsp.spectrogram(ctx, dx, T, C, t, nfft, hop, rate, ds, nd, db_out=db)
         ctx.record(e1)
-        ms = ctx.elapsed_ms(e0, e1)/4
+        ms = ctx.elapsed_ms(e0, e1)/ncalls
         gb = (4.0*C*t + (8.0 if want_db else 4.0)*C*nd*(nfft//2 + 1))/1e9
         print(f'nfft {nfft:6d} hop {hop:6d} {"PSD+dB" if want_db else "PSD   "}: {ms:8.3f} ms  {gb/ms*1e3:6.0f} GB/s', flush=True)
         ds.free()

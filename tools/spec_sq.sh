@@ -5,6 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/spec_sq
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+export WARM_CALLS=0 TIMED_CALLS=4      # the summaries count on 2 + 4 calls per variant and no other kernel
 for n in "$@"; do
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM -d $O/sq_$n --output-format csv -- python3 $R/tools/spec_sizes_bench.py $n > $O/sq_$n.log 2>&1 || exit 1
   rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/sq2_$n --output-format csv -- python3 $R/tools/spec_sizes_bench.py $n > $O/sq2_$n.log 2>&1 || exit 1
