@@ -61,7 +61,8 @@ struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 template <int NFFT, int LPF, int R1, int R2, int R3, bool DB, class Hook = NoHook>
 __device__ __forceinline__ void psd_frame(const v2f *w, float2 *fb, const float2 *tw2, const float2 *tw3,
                                           const float2 *twn, const float2 *win, int lane, float scale, bool keep,
-                                          float *__restrict__ o, float *__restrict__ od, Hook hook = Hook())
+                                          float *__restrict__ o, float *__restrict__ od, float &piv, bool &have_piv,
+                                          Hook hook = Hook())
 {
 #pragma clang fp contract(fast)
     constexpr int M = NFFT / 2, PPL = M / LPF;
@@ -69,27 +70,44 @@ __device__ __forceinline__ void psd_frame(const v2f *w, float2 *fb, const float2
     const int l = lane % LPF, g0 = (lane / LPF) * LPF;
     float2 v[PPL];
     v2f acc = {0.f, 0.f};
-    // the frame mean (detrend='constant') relative to a PIVOT -- the wave's first sample, zero if that is not finite --:
-    // on an offset plus something small (a low-pass only in front of raw data with a DC offset, a decaying transient) a
-    // float32 sum of the samples carries 1e-7 of the OFFSET into bins 0 and 1, the sum of the differences 1e-7 of the
-    // small part (spec_pack.h; tools/fuzz_stress.py seed 10268 was a frame of this sweep)
-    float pv = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w[0].x)));
-    pv = (fabsf(pv) <= 3.0e38f) ? pv : 0.f;
-    const v2f pivot2 = {pv, pv};
+    // The frame mean (detrend='constant') relative to a PIVOT: on an offset plus something small (a low-pass only in front
+    // of raw data with a DC offset, a decaying transient) a float32 sum of the samples carries 1e-7 of the OFFSET into
+    // bins 0 and 1, the sum of the differences to a value near the mean 1e-7 of the small part (tools/fuzz_stress.py seed
+    // 10268 was a frame of this sweep).  The pivot is the mean of the frame BEFORE this one in the wave's sequence (`piv`,
+    // carried by the caller; a lane group's own), whatever single samples do: a frame that starts on a pulse a thousand
+    // times its baseline -- pulse-type fish, clicks -- has that sample under a window weight of zero, and a pivot taken
+    // from it left 6e-8 of the PULSE times nfft / 2 in bins 0 and 1 (test_spectrogram_of_pulses_at_the_frame_borders).
+    // The first frame of a sequence takes two steps: a sample as the pivot of a rough mean, that mean as the pivot.
+    // Non-finite candidates (a NaN or Inf in the frame) leave the pivot as it was.
+    auto gsum = [&](float sum) {
+        if (LPF == 64) return wave_sum(sum);
+#pragma unroll
+        for (int d = LPF / 2; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+        return sum;
+    };
+    if (!have_piv) {                            // (wave-uniform)
+        float p0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w[0].x)));
+        p0 = (fabsf(p0) <= 3.0e38f) ? p0 : 0.f;
+        const v2f p02 = {p0, p0};
+        v2f a0 = {0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < R1; t++) a0 += w[t] - p02;
+        const float c = p0 + gsum(a0.x + a0.y) * (1.0f / (float)NFFT);
+        piv = (fabsf(c) <= 3.0e38f) ? c : p0;
+        have_piv = true;
+    }
+    const v2f pivot2 = {piv, piv};
 #pragma unroll
     for (int t = 0; t < R1; t++) {
         const v2f d = w[t] - pivot2;
         v[t] = make_float2(d.x, d.y);
         acc += d;
     }
-    float sum = acc.x + acc.y;
-    if (LPF == 64) {
-        sum = wave_sum(sum);
-    } else {
-#pragma unroll
-        for (int d = LPF / 2; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    const float mean = gsum(acc.x + acc.y) * (1.0f / (float)NFFT);
+    {
+        const float c = piv + mean;
+        piv = (fabsf(c) <= 3.0e38f) ? c : piv;
     }
-    const float mean = sum * (1.0f / (float)NFFT);
     const v2f mean2 = {mean, mean};
 #pragma unroll
     for (int t = 0; t < R1; t++) v[t] = as_f2((as_v2f(v[t]) - mean2) * as_v2f(win[l + LPF * t]));
@@ -590,6 +608,8 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
 #pragma unroll
         for (int j = 0; j < 4; j++) pv_[j] = (v2f){0.f, 0.f};
         bool have_prev = false;
+        float piv = 0.f;                                       // psd_frame's pivot: the mean of the frame before (per lane group)
+        bool have_piv = false;
         for (int it = 0; it < a.n_iter; it++) {
             const long long tile = base + (long long)it * TILE;
             const bool active = tile >= start && tile < loop_end;
@@ -645,7 +665,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                             for (int i = 0; i < 8; i++) w[i] = bb_[4 * q + i];
                             const long long fc = keep ? f : 0;                      // a masked group still needs a legal address
                             psd_frame<NFFT, LPF, R1, R2, R3, DB>(w, fb + gq * MP, tw2, tw3, twn, win, lane, a.scale, keep,
-                                                                 oc + fc * (long long)F, dc + fc * (long long)F);
+                                                                 oc + fc * (long long)F, dc + fc * (long long)F, piv, have_piv);
                         }
                     }
                    } else {
@@ -663,11 +683,11 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                                     STAMP_AT(10);                  // (between the frames)
                                     auto hook = [&](int n) { STAMP_AT(11 + n); };
                                     psd_frame<NFFT, LPF, R1, R2, R3, DB>(w, fb, tw2, tw3, twn, win, lane, a.scale, true,
-                                                                         oc + f * (long long)F, dc + f * (long long)F, hook);
+                                                                         oc + f * (long long)F, dc + f * (long long)F, piv, have_piv, hook);
                                     STAMP_AT(15);                  // split step, PSD, stores
                                 } else {
                                     psd_frame<NFFT, LPF, R1, R2, R3, DB>(w, fb, tw2, tw3, twn, win, lane, a.scale, true,
-                                                                         oc + f * (long long)F, dc + f * (long long)F);
+                                                                         oc + f * (long long)F, dc + f * (long long)F, piv, have_piv);
                                 }
                             }
                         } else {
@@ -692,7 +712,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                                 }
                                 const long long fc = keep ? f : 0;            // a masked group still needs a legal address
                                 psd_frame<NFFT, LPF, R1, R2, R3, DB>(w, fb + gq * MP, tw2, tw3, twn, win, lane, a.scale, keep,
-                                                                     oc + fc * (long long)F, dc + fc * (long long)F);
+                                                                     oc + fc * (long long)F, dc + fc * (long long)F, piv, have_piv);
                             }
                         }
                     }
@@ -992,6 +1012,8 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_bwd_kernel(const SosPl
 #pragma unroll
         for (int j = 0; j < 8; j++) nxt_[j] = (v2f){0.f, 0.f};
         bool have_next = false;
+        float piv = 0.f;
+        bool have_piv = false;
         int it = 0;
         for (long long rt = rt_start; rt < rt_hi; rt++) {
             it++;
@@ -1010,7 +1032,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_bwd_kernel(const SosPl
 #pragma unroll
                 for (int i = 0; i < 8; i++) { w[i] = cur_[8 + i]; w[8 + i] = nxt_[i]; }
                 psd_frame<NFFT, 64, R1, R2, R3, false>(w, fb, tw2, tw3, twn, win, lane, a.scale, true, oc + f * (long long)F,
-                                                       nullptr);
+                                                       nullptr, piv, have_piv);
             }
 #pragma unroll
             for (int j = 0; j < 8; j++) nxt_[j] = cur_[j];

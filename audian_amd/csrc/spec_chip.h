@@ -13,7 +13,7 @@
 // matter of the LDS addresses it reads: thread l takes j = l and 1024 - l (thread 0: the two self-paired ones, 0 and 512).
 // Window, stage twiddles and split twiddles are computed on the fly (v_cos_f32 / v_sin_f32 on exact fractions of a turn
 // for one base angle each, the rest by angle addition with compile-time constants or by powers), the frame mean relative to
-// a pivot sample (spec_pack.h).  HBM sees each frame's samples once per frame (the overlapped half a second time, a few
+// its first sample and then to that mean (two steps: the sample may be a pulse).  HBM sees each frame's samples once per frame (the overlapped half a second time, a few
 // microseconds later, mostly from L2) and each bin once.
 #pragma once
 
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(512, 2) void spec_chip65536_kernel(
 {
     constexpr int NFFT = 65536, M = NFFT / 2, F = M + 1, LPF = 512, R = 32, Q = M / R, H = M / 2;
     __shared__ float2 xb[H + H / 32];
-    __shared__ float red[LPF / 64];
+    __shared__ float red[2][LPF / 64];
     const int l = threadIdx.x, lane = l & 63, wave = l >> 6;
     // exchange buffer index of element e: e + e / 32 (the writes of one instruction are 32 elements apart).  The constant
     // parts are multiples of 32 everywhere, so each access is a per-lane base plus a compile-time offset.
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(512, 2) void spec_chip65536_kernel(
     for (int it = 0; it < nv; it++) {
         const long long frame = fbeg + it;
         const float *seg = xc + frame * (long long)hop;
-        float pivot = seg[0];                                // mean and window relative to a sample of the frame (spec_pack.h)
+        float pivot = seg[0];                                // (the first of the two steps of the frame mean, below)
         pivot = (fabsf(pivot) <= 3.0e38f) ? pivot : 0.f;
         int zero = 0;                                        // (keeps the frame-invariant window and twiddle powers out of the
         asm volatile("" : "+v"(zero));                       // loop's preheader: hoisted, they would fill the register file)
@@ -80,12 +80,29 @@ __global__ __launch_bounds__(512, 2) void spec_chip65536_kernel(
             s += (v0[t].x + v0[t].y) + (v1[t].x + v1[t].y);
         }
         s = wave_sum(s);
-        if (lane == 0) red[wave] = s;
+        if (lane == 0) red[0][wave] = s;
         __syncthreads();
         float total = 0.f;
 #pragma unroll
-        for (int w = 0; w < LPF / 64; w++) total += red[w];
-        const float mean = total * (1.0f / (float)NFFT);
+        for (int w = 0; w < LPF / 64; w++) total += red[0][w];
+        // The frame mean in TWO steps: the mean of the differences to the frame's first sample is good to 6e-8 of ITS size,
+        // and that sample may be a pulse a thousand times the rest of the frame under a window weight of zero (chain.hip's
+        // psd_frame has the case; every workgroup starts a new frame here, there is no frame before it to take a pivot
+        // from): subtract it, take the mean of what is left -- small whatever the sample was -- and subtract that too.
+        const float mean0 = total * (1.0f / (float)NFFT);
+        float s1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+            v0[t].x -= mean0; v0[t].y -= mean0; v1[t].x -= mean0; v1[t].y -= mean0;
+            s1 += (v0[t].x + v0[t].y) + (v1[t].x + v1[t].y);
+        }
+        s1 = wave_sum(s1);
+        if (lane == 0) red[1][wave] = s1;
+        __syncthreads();
+        float total1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < LPF / 64; w++) total1 += red[1][w];
+        const float mean = total1 * (1.0f / (float)NFFT);
         {
             // periodic Hann 0.5 - 0.5 cos(2 pi i / nfft) at i = 2n, 2n + 1: n = l + 1024 t is t / 32 of a turn further on,
             // the second butterfly 1 / 64 of a turn

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256, 3) void spec_pack_kernel(
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
+    float pvs = 0.f;                                        // pivot of the frame mean, per lane group
     for (int b = 0; b < batches_per_wave; b++) {
         const long long fb0 = f0 + (long long)b * G;       // first frame of the batch (wave-uniform)
         if (fb0 >= frames_out) break;
@@ -160,15 +161,30 @@ __global__ __launch_bounds__(256, 3) void spec_pack_kernel(
         float2 v[PPL];
         {
             const int r0 = (int)(((fb0 + (valid ? g : 0)) * (long long)hop) & (RB - 1)) + 2 * l;
-            // The frame mean (detrend='constant') relative to a PIVOT, the batch's first sample (one LDS word, the same
-            // for every lane): on a trace that is an offset plus something small -- raw data of the reference's default
-            // session, a filter's decaying transient -- a float32 sum of the samples carries an error of 1e-7 of the
-            // OFFSET into bins 0 and 1 of every frame (tools/fuzz_stress.py, seed 10268: 1.0e-4 of the frame's peak);
-            // the sum of the differences carries 1e-7 of the small part.  (A non-finite pivot would poison frames
-            // that do not hold the sample: zero then.)
-            float pivot = ring[(int)((fb0 * (long long)hop) & (RB - 1))];
-            pivot = (fabsf(pivot) <= 3.0e38f) ? pivot : 0.f;
-            const v2f pivot2 = {pivot, pivot};
+            // The frame mean (detrend='constant') relative to a PIVOT: on a trace that is an offset plus something small --
+            // raw data of the reference's default session, a filter's decaying transient -- a float32 sum of the samples
+            // carries an error of 1e-7 of the OFFSET into bins 0 and 1 of every frame (tools/fuzz_stress.py, seed 10268:
+            // 1.0e-4 of the frame's peak); the sum of the differences to a value near the mean carries 1e-7 of the small
+            // part.  The pivot is the mean of the frame this lane group transformed in the batch before (`pvs`), not a
+            // sample: a frame that starts on a pulse has that sample under a window weight of zero (chain.hip's psd_frame
+            // has the case).  The run's first batch takes two steps: the batch's first sample (one LDS word, the same for
+            // every lane; zero if it is not finite) as the pivot of a rough mean, that mean as the pivot.
+            if (b == 0) {
+                float p0 = ring[(int)((fb0 * (long long)hop) & (RB - 1))];
+                p0 = (fabsf(p0) <= 3.0e38f) ? p0 : 0.f;
+                const v2f p02 = {p0, p0};
+                v2f a0 = {0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < PPL / R1; u++)
+#pragma unroll
+                    for (int t = 0; t < R1; t++) {
+                        const int ri = (r0 + 2 * (LPF * u + t * (M / R1))) & (RB - 1);
+                        a0 += (v2f){ring[ri], ring[ri + 1]} - p02;
+                    }
+                const float c = p0 + group_sum<LPF>(a0.x + a0.y) * (1.0f / (float)NFFT);
+                pvs = (fabsf(c) <= 3.0e38f) ? c : p0;
+            }
+            const v2f pivot2 = {pvs, pvs};
             v2f acc = {0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < PPL / R1; u++)
@@ -181,6 +197,10 @@ __global__ __launch_bounds__(256, 3) void spec_pack_kernel(
                 }
             const float mean = group_sum<LPF>(acc.x + acc.y) * (1.0f / (float)NFFT);
             const v2f mean2 = {mean, mean};
+            {
+                const float c = pvs + mean;                          // the next batch's pivot (a NaN or Inf in this frame: unchanged)
+                pvs = (fabsf(c) <= 3.0e38f) ? c : pvs;
+            }
 #pragma unroll
             for (int u = 0; u < PPL / R1; u++)
 #pragma unroll

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wgs_kernel(
     constexpr bool PIPE = PPL <= 16;
     constexpr bool KEEPW = PPL <= 16 && LPF >= 256;     // (nfft 8192; at 4096 the 32 registers are not there: spills)
     __shared__ __attribute__((aligned(16))) float2 smem[TW2 + TW3 + MP];
-    __shared__ float red[NW];
+    __shared__ float red[NW], red2[NW];
     const float2 *tw2 = smem, *tw3 = smem + TW2;
     float2 *fb = smem + TW2 + TW3;                     // (16-byte aligned: TW2 + TW3 is even)
     static_assert((TW2 + TW3) % 2 == 0, "frame buffer alignment");
@@ -81,11 +81,16 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wgs_kernel(
             nx[j] = make_float4(t.x, t.y, t.z, t.w);
         }
     };
-    // The frame mean is taken relative to a PIVOT, the run's first sample (zero if that is not finite): on an offset plus
-    // something small a float32 sum of the samples carries 1e-7 of the OFFSET into bins 0 and 1, the sum of the differences
-    // 1e-7 of the small part (spec_pack.h has the case that showed it).
-    float pivot = (nv > 0) ? xc[fbeg * (long long)hop] : 0.f;
-    pivot = (fabsf(pivot) <= 3.0e38f) ? pivot : 0.f;
+    // The frame mean is taken relative to a PIVOT: on an offset plus something small a float32 sum of the samples carries
+    // 1e-7 of the OFFSET into bins 0 and 1, the sum of the differences to a value near the mean 1e-7 of the small part
+    // (spec_pack.h has the case that showed it).  The pivot of a frame is the MEAN OF THE FRAME BEFORE IT; the run's first
+    // frame finds its own in two steps (the run's first sample -- zero if that is not finite -- as the pivot of a rough
+    // mean): a sample alone can be a pulse a thousand times the baseline under a window weight of zero (chain.hip's
+    // psd_frame has that case).  A half that is kept for the next frame stays a difference to the pivot it was fetched
+    // under; the bookkeeping is two scalars (`pivot`, `delta`) and a per-half mean at the window.
+    float p0 = (nv > 0) ? xc[fbeg * (long long)hop] : 0.f;
+    p0 = (fabsf(p0) <= 3.0e38f) ? p0 : 0.f;
+    float pivot = p0, delta = 0.f;
     // the frame, as differences to the pivot, into LDS from (keep | nx); leaves the upper half in `keep` (differences as
     // well: a sample meets the pivot once); returns the thread's share of the sum of the differences
     auto put_raw = [&]() -> float {
@@ -143,11 +148,33 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wgs_kernel(
 #pragma unroll
             for (int j = 0; j < NQ / 2; j++) {
                 const f4q t = *reinterpret_cast<const f4q *>(seg + 4 * (l + LPF * j));
-                keep[j] = make_float4(t.x - pivot, t.y - pivot, t.z - pivot, t.w - pivot);
+                keep[j] = make_float4(t.x, t.y, t.z, t.w);
             }
         }
         fetch(fbeg);
-        __syncthreads();                               // (the tables)
+        {
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f);
+            auto add0 = [&](float4 v) { a0.x += v.x - p0; a0.y += v.y - p0; a0.z += v.z - p0; a0.w += v.w - p0; };
+            if (HALF) {
+#pragma unroll
+                for (int j = 0; j < NQ / 2; j++) add0(keep[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < NQN; j++) add0(nx[j]);
+            post_sum((a0.x + a0.y) + (a0.z + a0.w));
+            __syncthreads();                           // (and the tables)
+            float total0 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; w++) total0 += red[w];
+            const float c = p0 + total0 * (1.0f / (float)NFFT);
+            pivot = (fabsf(c) <= 3.0e38f) ? c : p0;
+            __syncthreads();                           // (red[] is written again below)
+            if (HALF) {
+#pragma unroll
+                for (int j = 0; j < NQ / 2; j++)
+                    keep[j] = make_float4(keep[j].x - pivot, keep[j].y - pivot, keep[j].z - pivot, keep[j].w - pivot);
+            }
+        }
         post_sum(put_raw());
         if (PIPE && nv > 1) fetch(fbeg + 1);
         __syncthreads();                               // B0
@@ -156,13 +183,22 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wgs_kernel(
             float total = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; w++) total += red[w];
-            const float mean = total * (1.0f / (float)NFFT);
+            // the halves of the frame in LDS are differences to the pivots in force when they were fetched: the upper half's
+            // is `pivot`, the lower half's `pivot - delta`
+            const float mean = total * (1.0f / (float)NFFT) - 0.5f * delta;      // of (sample - pivot)
+            const float mean_lo = mean + delta;
             // (an always-zero offset the compiler cannot see through: the window and the split twiddles do not depend on
             // the frame, and left alone hipcc computes them once, in front of the loop -- 96 registers that then live
             // through every frame)
             int zero = 0;
             asm volatile("" : "+v"(zero));
             float2 v[PPL];
+            // What the subtraction leaves: `mean` is a float32 and the mean of the differences as good as their sum -- after
+            // a step in the trace's level the differences to the frame before are all large, and 6e-8 of THEM times nfft / 2
+            // would sit in bins 0 and 1 of a frame that is flat.  The detrended samples are summed once more (small
+            // whatever came before); their mean m1 times the Hann window is m1 nfft / 2 in bin 0 and -m1 nfft / 4 in bin
+            // 1 and nothing anywhere else, and the split step takes it out of those two bins.
+            v2f rest = {0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < PPL / R1; u++) {
                 float2 wl[R1];
@@ -171,8 +207,15 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wgs_kernel(
                 for (int t = 0; t < R1; t++) {
                     const float2 r = raw2[l + LPF * u + t * (M / R1)];
                     const float2 w = KEEPW ? wkeep[u * R1 + t] : wl[t];
-                    v[u * R1 + t] = make_float2((r.x - mean) * w.x, (r.y - mean) * w.y);     // (r: sample - pivot)
+                    const float mt = (HALF && t < R1 / 2) ? mean_lo : mean;       // (input t < R1 / 2: the frame's lower half)
+                    const v2f q = {r.x - mt, r.y - mt};
+                    rest += q;
+                    v[u * R1 + t] = make_float2(q.x * w.x, q.y * w.y);
                 }
+            }
+            {
+                const float s1 = wave_sum(rest.x + rest.y);
+                if (lane == 0) red2[wave] = s1;            // (read at the split step, four barriers on; written again a frame later)
             }
             stockham_stage<R1, 1, M, LPF, false, false>(v, fb, tw2, l);                  // first butterflies
             __syncthreads();                           // B1: every raw sample has been read
@@ -209,6 +252,10 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wgs_kernel(
             const float tb = (float)(l + zero) * (1.0f / (float)NFFT);
             const float cb = __builtin_amdgcn_cosf(tb), sb = __builtin_amdgcn_sinf(tb);
             const v2f hscale2 = {0.5f * scale, 0.5f * scale};
+            float corr = 0.f;                                        // m1 nfft / 2 = half the sum of what the subtraction left
+#pragma unroll
+            for (int w = 0; w < NW; w++) corr += red2[w];
+            corr *= 0.5f;
 #pragma unroll
             for (int m = 0; m < PPL / 2; m++) {
                 const int k = l + LPF * m;
@@ -221,12 +268,14 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wgs_kernel(
                 // packed arithmetic (spec_pack.h's pair_psd)
                 const v2f e = pk_add_conj(as_v2f(zk), as_v2f(zm));
                 const v2f t = pk_cmul_negi(pk_sub_conj(as_v2f(zk), as_v2f(zm)), tw);
-                const v2f re = pk_sumdiff_x(e, t), im = pk_sumdiff_y(e, t);
+                v2f re = pk_sumdiff_x(e, t);
+                const v2f im = pk_sumdiff_y(e, t);
+                if (m == 0) re.x += (l == 1) ? corr : 0.f;           // bin 1 (re is twice its real part; the window's bin 1 is -nfft / 4)
                 const v2f pw = (re * re + im * im) * hscale2;
                 pk[m] = pw.x;
                 pm[m] = pw.y;
                 if (m == 0) {
-                    const float a = zk.x + zk.y, b = zk.x - zk.y;    // DC and Nyquist, not doubled
+                    const float a = zk.x + zk.y - corr, b = zk.x - zk.y;    // DC (the window's bin 0 is nfft / 2) and Nyquist, not doubled
                     pk[m] = (l == 0) ? a * a * scale : pk[m];
                     pm[m] = (l == 0) ? b * b * scale : pm[m];
                 }
@@ -245,6 +294,12 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wgs_kernel(
             // the next frame goes into LDS now (PIPE: its fetch is older than this frame's stores, which follow, and the
             // one after it is requested)
             if (it + 1 < nv) {
+                // the next frame's pivot: this frame's mean (a NaN or Inf in this frame: unchanged); what is kept of this
+                // frame stays as it is, `delta` remembers by how much the pivot moved
+                const float c = pivot + mean;
+                const float pn = (fabsf(c) <= 3.0e38f) ? c : pivot;
+                delta = HALF ? pn - pivot : 0.f;
+                pivot = pn;
                 post_sum(put_raw());
                 if (PIPE && it + 2 < nv) fetch(frame + 2);
             }

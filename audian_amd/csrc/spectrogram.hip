@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void spec_generic_kernel(
     float *__restrict__ db_out)
 {
     extern __shared__ float2 fftbuf[];        // 2 * nfft
-    __shared__ float red[4];
+    __shared__ double red[4];
     const int tid = threadIdx.x;
     const long long frame = blockIdx.x;
     const long long ch = blockIdx.y;
@@ -34,18 +34,19 @@ __global__ __launch_bounds__(256) void spec_generic_kernel(
         return;
     }
     const float *seg = x + ch * x_pitch + frame * (long long)hop;
-    // detrend='constant': subtract the frame mean
-    float s = 0.f;
-    for (int i = tid; i < nfft; i += 256) s += seg[i];
+    // detrend='constant': subtract the frame mean -- sum and subtraction in float64 (the streamed kernels get the same
+    // effect from a pivot near the mean, spec_pack.h; this kernel is a cross-check path and can afford the plain way)
+    double s = 0.0;
+    for (int i = tid; i < nfft; i += 256) s += (double)seg[i];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
-    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)nfft;
+    const double mean = (red[0] + red[1] + red[2] + red[3]) / (double)nfft;
     float2 *in = fftbuf, *ou = fftbuf + nfft;
     for (int i = tid; i < nfft; i += 256) {
         float w = 0.5f - 0.5f * cospif(2.0f * (float)i / (float)nfft);   // periodic Hann
-        in[i] = make_float2((seg[i] - mean) * w, 0.f);
+        in[i] = make_float2((float)((double)seg[i] - mean) * w, 0.f);
     }
     __syncthreads();
     const int half = nfft >> 1;
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? (DB ? 2 : 3) : 1) * WAV
     for (int i = 0; i < QP; i++) {
         rq0[i] = (v2f){0.f, 0.f}; rq1[i] = (v2f){0.f, 0.f}; rq2[i] = (v2f){0.f, 0.f}; rq3[i] = (v2f){0.f, 0.f};
     }
+    float pvs = 0.f;                                       // pivot of the frame mean, per lane group (body())
     auto fetch_quarter = [&](long long frame, auto which, v2f *dst) {
         constexpr int K = decltype(which)::value;
         const float *seg = xc + frame * (long long)hop + 2 * l;
@@ -185,17 +187,9 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? (DB ? 2 : 3) : 1) * WAV
         float *od = DB ? dc + frame * (long long)F : nullptr;
         float2 v[PPL];
         v2f acc = {0.f, 0.f};                             // even and odd samples side by side (v_pk_add_f32)
-        // the frame mean relative to a PIVOT (the first sample of the wave's first lane, wave-uniform; zero if it is not
-        // finite): on an offset plus something small a float32 sum of the samples carries 1e-7 of the OFFSET into bins
-        // 0 and 1, the sum of the differences 1e-7 of the small part (spec_pack.h has the case that showed it)
-        v2f pivot2;
-        {
-            v2f &r0 = qa[0];
-            asm volatile("" : "+v"(r0));                  // not before the counted wait
-            float pv = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r0.x)));
-            pv = (fabsf(pv) <= 3.0e38f) ? pv : 0.f;
-            pivot2 = (v2f){pv, pv};
-        }
+        // the frame mean relative to a PIVOT, the mean of the frame this lane group transformed before (`pvs`; the run's
+        // first frame: the two steps in front of the first call) -- chain.hip's psd_frame has the two cases that ask for it
+        const v2f pivot2 = {pvs, pvs};
 #pragma unroll
         for (int u = 0; u < PPL / R1; u++)
 #pragma unroll
@@ -216,14 +210,40 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? (DB ? 2 : 3) : 1) * WAV
         }
         const float mean = s * (1.0f / (float)NFFT);
         const v2f mean2 = {mean, mean};
+        {
+            const float c = pvs + mean;                   // the next frame's pivot (a NaN or Inf in this frame: unchanged)
+            pvs = (fabsf(c) <= 3.0e38f) ? c : pvs;
+        }
+        // CORR (the variants without register reuse, i.e. every hop but nfft / 2 and nfft / 4 -- hop = nfft among them): what
+        // the subtraction leaves.  After a step in the trace's level the differences to the mean of a frame that does not
+        // overlap this one are all large, `mean` is good to 6e-8 of THEM, and the Hann window puts that error times
+        // nfft / 2 into bins 0 and 1 (3e-4 of a flat frame's peak for a step of 1000 sigma at nfft 1024; with half of the
+        // frame before inside this one it stays under 1e-4).  The detrended samples are summed once more; their mean m1
+        // under the window is m1 nfft / 2 in bin 0, -m1 nfft / 4 in bin 1 and nothing elsewhere: the split step removes it.
+        // (spec_wgs.h does the same for every hop: its frames are longer and the error grows with sqrt(nfft).)
+        constexpr bool CORR = REUSE == 1;
+        v2f rest = {0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < PPL / R1; u++)
 #pragma unroll
             for (int t = 0; t < R1; t++) {
                 const v2f w = as_v2f(win[l + LPF * u + t * (M / R1)]);
                 float2 &e = v[u * R1 + t];
-                e = as_f2((as_v2f(e) - mean2) * w);
+                const v2f q = as_v2f(e) - mean2;
+                if (CORR) rest += q;
+                e = as_f2(q * w);
             }
+        float corr = 0.f;
+        if (CORR) {
+            float s1 = rest.x + rest.y;
+            if (LPF == 64) {
+                s1 = wave_sum(s1);
+            } else {
+#pragma unroll
+                for (int d = LPF / 2; d >= 1; d >>= 1) s1 += __shfl_xor(s1, d, 64);
+            }
+            corr = 0.5f * s1;                             // m1 nfft / 2
+        }
         // the raw registers are dead from here on: request the next frame now, so that the whole
         // FFT of this one hides the latency
         if (PF && EARLY_PF) {
@@ -280,12 +300,14 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? (DB ? 2 : 3) : 1) * WAV
             // X[k] = E + W^k O, X[M-k] = conj(E - W^k O): real parts in `re`, imaginary in `im`
             const v2f e = pk_add_conj(as_v2f(zk), as_v2f(zm));
             const v2f t = pk_cmul_negi(pk_sub_conj(as_v2f(zk), as_v2f(zm)), as_v2f(twn[k]));
-            const v2f re = pk_sumdiff_x(e, t), im = pk_sumdiff_y(e, t);
+            v2f re = pk_sumdiff_x(e, t);
+            const v2f im = pk_sumdiff_y(e, t);
+            if (CORR && m == 0) re.x += (l == 1) ? corr : 0.f;       // bin 1 (re: twice its real part)
             const v2f pw = (re * re + im * im) * hscale2;
             float pk = pw.x, pm = pw.y;
             if (m == 0) {
                 // bin 0 pairs with itself: DC = re + im, Nyquist = re - im, not doubled
-                const float dc0 = zk.x + zk.y, ny = zk.x - zk.y;
+                const float dc0 = zk.x + zk.y - corr, ny = zk.x - zk.y;
                 pk = (l == 0) ? dc0 * dc0 * scale : pk;
                 pm = (l == 0) ? ny * ny * scale : pm;
             }
@@ -324,6 +346,30 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? (DB ? 2 : 3) : 1) * WAV
         const long long c0 = f0 < last_valid ? f0 : last_valid;
         fetch_quarter(c0, Q0(), rq0); fetch_quarter(c0, Q1(), rq1);
         fetch_quarter(c0, Q2(), rq2); fetch_quarter(c0, Q3(), rq3);
+    }
+    {
+        // the pivot of the run's first frame in two steps: a sample as the pivot of a rough mean, that mean as the pivot
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < QP; i++) {
+            asm volatile("" : "+v"(rq0[i])); asm volatile("" : "+v"(rq1[i]));
+            asm volatile("" : "+v"(rq2[i])); asm volatile("" : "+v"(rq3[i]));
+        }
+        float p0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(rq0[0].x)));
+        p0 = (fabsf(p0) <= 3.0e38f) ? p0 : 0.f;
+        const v2f p02 = {p0, p0};
+        v2f a0 = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < QP; i++) a0 += ((rq0[i] - p02) + (rq1[i] - p02)) + ((rq2[i] - p02) + (rq3[i] - p02));
+        float s0 = a0.x + a0.y;
+        if (LPF == 64) {
+            s0 = wave_sum(s0);
+        } else {
+#pragma unroll
+            for (int d = LPF / 2; d >= 1; d >>= 1) s0 += __shfl_xor(s0, d, 64);
+        }
+        const float c = p0 + s0 * (1.0f / (float)NFFT);
+        pvs = (fabsf(c) <= 3.0e38f) ? c : p0;
     }
     int it = 0;
     // (the steady-state loop sits inside this branch so that no path of the generated code can
@@ -658,7 +704,7 @@ __global__ __launch_bounds__(256) void spec_direct_kernel(
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
-    const float mean = (float)((red[0] + red[1] + red[2] + red[3]) / (double)nfft);
+    const double mean = (red[0] + red[1] + red[2] + red[3]) / (double)nfft;   // (subtracted in float64: an offset of any size)
     float re = 0.f, im = 0.f;
     long long idx = 0;                       // (k * n) mod nfft, advanced incrementally
     for (int base = 0; base < nfft; base += CHUNK) {
@@ -667,7 +713,7 @@ __global__ __launch_bounds__(256) void spec_direct_kernel(
         for (int i = tid; i < len; i += 256) {
             const int n = base + i;
             const float w = 0.5f - 0.5f * cospif(2.0f * (float)n / (float)nfft);
-            xs[i] = (seg[n] - mean) * w;
+            xs[i] = (float)((double)seg[n] - mean) * w;
         }
         __syncthreads();
         if (k < F) {
@@ -706,7 +752,7 @@ constexpr int BIG_W = 16;                 // sub-transforms per workgroup
 
 __global__ __launch_bounds__(256) void big_mean_kernel(const float *__restrict__ x, long long x_pitch,
                                                        long long frames_valid, long long item0, int nfft,
-                                                       int hop, float *__restrict__ mean)
+                                                       int hop, double *__restrict__ mean)
 {
     __shared__ double red[4];
     const long long item = item0 + blockIdx.x;
@@ -726,7 +772,7 @@ __global__ __launch_bounds__(256) void big_mean_kernel(const float *__restrict__
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) mean[blockIdx.x] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)nfft);
+    if (threadIdx.x == 0) mean[blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) / (double)nfft;
 }
 
 // BIG_W Stockham transforms of length n (power of two) side by side in LDS, radix-4 stages and
@@ -780,7 +826,7 @@ __device__ float2 *big_fft_lds(float2 *a, float2 *b, float2 *tw, int n)
 
 __global__ __launch_bounds__(256) void big_pass1_kernel(const float *__restrict__ x, long long x_pitch,
                                                         long long frames_valid, long long item0, int nfft,
-                                                        int hop, int N1, int N2, const float *__restrict__ mean,
+                                                        int hop, int N1, int N2, const double *__restrict__ mean,
                                                         float2 *__restrict__ B)
 {
     extern __shared__ float2 big_lds[];                    // 2 * BIG_W * N1 + N1
@@ -789,7 +835,7 @@ __global__ __launch_bounds__(256) void big_pass1_kernel(const float *__restrict_
     const float *seg = x + ch * x_pitch + frame * (long long)hop;
     const int n2_0 = blockIdx.x * BIG_W;
     const int M = nfft >> 1;
-    const float mu = mean[blockIdx.y];
+    const double mu = mean[blockIdx.y];                    // (float64 mean, subtracted in float64: an offset of any size)
     float2 *a = big_lds, *b = big_lds + BIG_W * N1;
     for (int i = threadIdx.x; i < BIG_W * N1; i += 256) {
         const int n1 = i / BIG_W, j = i - n1 * BIG_W;
@@ -797,7 +843,7 @@ __global__ __launch_bounds__(256) void big_pass1_kernel(const float *__restrict_
         const float x0 = seg[2 * n], x1 = seg[2 * n + 1];
         const float w0 = 0.5f - 0.5f * cospif((float)(2 * n) / (float)M);        // 2 pi (2n) / nfft
         const float w1 = 0.5f - 0.5f * cospif((float)(2 * n + 1) / (float)M);
-        a[j * N1 + n1] = make_float2((x0 - mu) * w0, (x1 - mu) * w1);
+        a[j * N1 + n1] = make_float2((float)((double)x0 - mu) * w0, (float)((double)x1 - mu) * w1);
     }
     __syncthreads();
     float2 *r = big_fft_lds(a, b, big_lds + 2 * BIG_W * N1, N1);
@@ -901,16 +947,16 @@ int run_big(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long channe
     const long long items = channels * n_valid;
     if (items == 0) return HIPDSP_OK;
     // scratch: mean | B | Z for one batch of (channel, frame) items, at most ~512 MiB
-    long long batch = (512LL << 20) / (16LL * M + 4);
+    long long batch = (512LL << 20) / (16LL * M + 8);
     if (batch < 1) batch = 1;
     if (batch > items) batch = items;
     if (batch > 65535) batch = 65535;
-    const size_t off_b = (size_t)((batch * 4 + 255) / 256 * 256);
+    const size_t off_b = (size_t)((batch * 8 + 255) / 256 * 256);
     const size_t bytes = off_b + 2 * (size_t)batch * (size_t)M * sizeof(float2);
     void *work = nullptr;
     int rc = hipdsp_scratch(ctx, bytes, &work);
     if (rc != HIPDSP_OK) return rc;
-    float *mean = (float *)work;
+    double *mean = (double *)work;
     float2 *B = (float2 *)((char *)work + off_b);
     float2 *Z = B + (size_t)batch * M;
     const size_t lds1 = (2 * (size_t)BIG_W * N1 + N1) * sizeof(float2), lds2 = (2 * (size_t)BIG_W * N2 + N2) * sizeof(float2);

@@ -133,6 +133,16 @@ def test_random_spectrogram_cases(oracle, seed):
     C = int(rng.integers(1, 4))
     nd = max(1, (T + hop - 1)//hop + int(rng.integers(-2, 3)))
     x = (rng.standard_normal((T, C)) + 0.3).astype(np.float32)
+    shape = int(rng.integers(0, 5))
+    if shape == 1 and T > 0:                              # a large offset under a small signal (raw data of a DC-coupled sensor)
+        x = (np.float32(10.0**rng.uniform(0, 4)*rng.choice([-1, 1])) + np.float32(10.0**rng.uniform(-3, 0))*x).astype(np.float32)
+    elif shape == 2 and T > 0:                            # a pulse train on or next to the frame borders (pulse-type fish, clicks)
+        x = (np.float32(1e-3)*x).astype(np.float32)
+        x[int(rng.integers(0, min(hop, T)))::hop*int(rng.integers(1, 4))] += np.float32(10.0**rng.uniform(-2, 0.5)*rng.choice([-1, 1]))
+    elif shape == 3 and T > 0:                            # steps in the level at a few frame borders, up to 300 times the noise
+        x = (np.float32(1e-3)*x).astype(np.float32)
+        for _ in range(int(rng.integers(1, 4))):
+            x[int(rng.integers(0, max(T//hop, 1)))*hop:] += np.float32(rng.uniform(-0.3, 0.3))
     want_db = bool(rng.integers(0, 2))
     got = gh.gpu_spectrogram(x, rate, nfft, hop, nd, want_db=want_db)
     if want_db:

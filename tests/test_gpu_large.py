@@ -72,8 +72,14 @@ def test_one_channel_of_more_than_two_to_the_31_frames(oracle):
         a, b = ps.view(k0*F, (4, F)).to_host(), ps.view(kb*F, (4, F)).to_host()
         assert np.abs(a - b).max()/np.abs(b).max() < 1e-5, ('PSD', n0)
         a, b = db.view(k0*F, (4, F)).to_host(), db.view(kb*F, (4, F)).to_host()
-        fin = np.isfinite(b)
-        assert np.array_equal(np.isfinite(a), fin) and np.abs(a[fin] - b[fin]).max() < 1e-2, ('dB', n0)
+        # (bins more than six decades under their frame's peak are rounding noise of the float32 transform, down to the
+        # floor of -200 dB = 1e-20, and the two windows' frames do not share their rounding: the pivot of a frame's mean is
+        # the mean of the frame before it.  The PSD comparison above is the one with teeth; here: the dB image agrees
+        # wherever it means something and stays down where it does not.)
+        for ra, rb in zip(a, b):
+            clear = np.isfinite(rb) & (rb > rb[np.isfinite(rb)].max() - 60.0)
+            assert np.isfinite(ra[clear]).all() and np.abs(ra[clear] - rb[clear]).max() < 1e-2, ('dB', n0)
+            assert np.all(ra[~clear] < rb[np.isfinite(rb)].max() - 55.0), ('dB under the noise', n0)
     # the last frames: valid ones finite and non-zero, the zero tail zero
     tail = ps.view((nd - 4)*F, (4, F)).to_host()
     n_valid = (min((nd - 1)*hop + nfft, T) - (nfft - hop))//hop

@@ -389,6 +389,102 @@ def test_spectrogram_of_an_offset_plus_something_small(oracle, nfft, hop):
     assert np.all(np.isnan(got[0, 0])) and np.all(np.isfinite(got[(nfft + hop - 1)//hop:, 0]))
 
 
+@pytest.mark.parametrize('nfft,hop', [(64, 64), (256, 256), (256, 128), (512, 512), (1024, 1024), (2048, 2048), (2048, 1024),
+                                      (4096, 4096), (8192, 8192), (16384, 16384), (65536, 65536)])
+def test_spectrogram_of_pulses_at_the_frame_borders(oracle, nfft, hop):
+    """A pulse train -- a pulse-type electric fish, clicks -- over a quiet baseline, with the pulses on the frame borders:
+    the first sample of a frame is a thousand times the rest of it, and the Hann window gives that sample weight zero, so
+    the frame's spectrum is the baseline's.  A frame mean taken relative to THAT sample (the pivot of round 4's first
+    version) is the mean of differences of size A, wrong by 6e-8 A, and the Hann window puts 6e-8 A nfft / 2 of it into
+    bins 0 and 1: 1e-3 of the frame's peak.  The pivot is the previous frame's mean (the first frame of a run takes two
+    steps), which is as good as the signal is stationary over two frames and never worse than the plain sum."""
+    rate, C = 96000.0, 2
+    rng = np.random.default_rng(nfft)
+    nframes = 24 if nfft <= 4096 else 6
+    T = (nframes - 1)*hop + nfft + 5
+    for amp, sigma, offset in ((1.0, 1e-3, 0.0), (-3.0, 1e-3, 0.2), (50.0, 2e-2, -1.0)):
+        x = (offset + sigma*rng.standard_normal((T, C))).astype(np.float32)
+        x[::hop, 0] += np.float32(amp)                 # channel 0: on every frame's first sample
+        x[hop - 1::hop, 1] += np.float32(amp)          # channel 1: on every frame's last sample (weight 6e-10 at nfft 65536 ...)
+        nd = (T + hop - 1)//hop
+        want = np.zeros((nd, C, nfft//2 + 1))
+        oracle.spectrogram_process(x.astype(np.float64), want, rate, nfft, hop)
+        got = gh.gpu_spectrogram(x, rate, nfft, hop, nd)
+        worst = 0.0
+        for ch in range(C):
+            for j in range(nd):
+                if np.max(np.abs(want[j, ch])) == 0:
+                    assert np.all(got[j, ch] == 0)
+                else:
+                    worst = max(worst, rel_err(got[j, ch], want[j, ch]))
+        assert worst < TOL, (nfft, hop, amp, sigma, offset, worst)
+
+
+@pytest.mark.parametrize('nfft', [64, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536])
+def test_spectrogram_after_a_step_in_the_level(oracle, nfft):
+    """A trace whose level jumps by a thousand times its noise between two frames (stimulus artefacts, a DC-coupled
+    amplifier): the frame after the jump is flat again, the differences to the mean of the frame before it are all the
+    size of the jump, and their float32 mean is good to 6e-8 of THAT.  Frames without overlap (the reference's overlap
+    spin box goes down to 0 %, databrowser.py:522-529) and with half of it; the kernels sum what the subtraction left and
+    take it out of bins 0 and 1 (spec_wgs.h, spec_fast's variants without register reuse), or take the frame mean in two
+    steps (spec_chip.h); with half of the frame before inside the frame the plain scheme stays under the tolerance."""
+    rate, sigma = 96000.0, 1e-3
+    for hop in (nfft, nfft//2):
+        rng = np.random.default_rng(nfft + hop)
+        nframes = 24 if nfft <= 4096 else 8
+        T = (nframes - 1)*hop + nfft + 5
+        x = (sigma*rng.standard_normal((T, 2))).astype(np.float32)
+        level = np.zeros(T, dtype=np.float32)
+        for j in range(3, nframes, 4):
+            level[j*hop:] += np.float32(1000.0*sigma*(1 if (j//4) % 2 == 0 else -0.7))
+        x[:, 0] += level
+        x[:, 1] += np.float32(0.3)*level + np.float32(5.0)
+        nd = (T + hop - 1)//hop
+        want = np.zeros((nd, 2, nfft//2 + 1))
+        oracle.spectrogram_process(x.astype(np.float64), want, rate, nfft, hop)
+        got = gh.gpu_spectrogram(x, rate, nfft, hop, nd)
+        worst = max(rel_err(got[j, ch], want[j, ch]) for j in range(nd) for ch in range(2) if np.max(np.abs(want[j, ch])) > 0)
+        assert worst < TOL, (nfft, hop, worst)
+
+
+@pytest.mark.parametrize('nfft,hop', [(2048, 1024), (1024, 256), (512, 256), (256, 128)])
+def test_fused_sweep_of_pulses_at_the_frame_borders(oracle, nfft, hop):
+    """The same pulse train through hipdsp_chain_forward: behind a wide first-order low-pass a pulse stays a few samples
+    long, and every nfft-th sample carries one -- the frames that START there see it under window weights of 1e-5 and less,
+    the frames that have it in their middle are all pulse.  The fused sweep's FFT waves take the pivot of a frame's mean
+    from the frame before it (psd_frame, chain.hip), never from a sample."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rate, C = 96000.0, 2
+    rng = np.random.default_rng(nfft + hop)
+    T = 30*2048 + 777
+    x = (1e-3*rng.standard_normal((T, C))).astype(np.float32)
+    x[::nfft, 0] += np.float32(2.0)
+    x[5::nfft, 1] -= np.float32(40.0)
+    c = gh.ctx()
+    dx = gh.to_planar(c, x)
+    nd = (T + hop - 1)//hop
+    F = nfft//2 + 1
+    sos = butter_sos(1, 0.4*rate, 'lowpass', rate)
+    esos = butter_sos(1, 500.0, 'lowpass', rate)
+    fplan, eplan = hipdsp.SosPlan(c, sos), hipdsp.SosPlan(c, esos)
+    for with_env in (True, False):
+        yf = hipdsp.DeviceArray(c, (C, T), np.float32)
+        ps = hipdsp.DeviceArray(c, (C, nd, F), np.float32)
+        hipdsp.chain_forward(c, fplan, eplan if with_env else None, dx, T, yf, T, C, T, nfft, hop, rate, ps, nd)
+        gf, gs = yf.to_host(), ps.to_host()
+        want_s = np.zeros((nd, C, F))
+        oracle.spectrogram_process(gf.T.astype(np.float64), want_s, rate, nfft, hop)
+        worst = 0.0
+        for ch in range(C):
+            for j in range(nd):
+                if np.max(np.abs(want_s[j, ch])) == 0:
+                    assert np.all(gs[ch, j] == 0)
+                else:
+                    worst = max(worst, rel_err(gs[ch, j], want_s[j, ch]))
+        assert worst < TOL, (nfft, hop, with_env, worst)
+
+
 def test_spectrogram_short_source_and_db(oracle):
     x = np.ones((100, 2), dtype=np.float32)
     got = gh.gpu_spectrogram(x, 48000.0, 256, 128, 3)

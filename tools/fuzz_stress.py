@@ -3,6 +3,7 @@ that module that takes (oracle, seed), seeds 1000 .. 1000 + N, time-boxed; needs
     python tools/fuzz_stress.py [N=400] [minutes=8] [first seed=1000]
     FUZZ_MODULE=test_gpu_facade python tools/fuzz_stress.py 60 9        (random walks through the facade)
     FUZZ_OPTIONS=1 python tools/fuzz_stress.py ...                      (random tuning options per case as well)
+    FUZZ_ONLY=spectrogram python tools/fuzz_stress.py ...               (the families whose name contains the word)
 """
 import sys, os, time, inspect
 ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
@@ -19,7 +20,8 @@ os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 progress = open(os.path.join(ROOT, 'gpurun_out', 'fuzz_progress.log'), 'w')
 failures = open(os.path.join(ROOT, 'gpurun_out', 'fuzz_failures.log'), 'w')
 tests = [(n, f) for n, f in inspect.getmembers(t, inspect.isfunction)
-         if n.startswith('test_random') and list(inspect.signature(f).parameters) == ['oracle', 'seed']]
+         if n.startswith('test_random') and list(inspect.signature(f).parameters) == ['oracle', 'seed']
+         and os.environ.get('FUZZ_ONLY', '') in n]                      # FUZZ_ONLY=spectrogram: one family only
 t0 = time.time()
 bad, done = 0, {n: 0 for n, _ in tests}
 for seed in range(first, first + N):
