@@ -17,13 +17,24 @@
 // microseconds later, mostly from L2) and each bin once.
 #pragma once
 
-template <bool DB>
-__global__ __launch_bounds__(512, 2) void spec_chip65536_kernel(
+// X2: nfft 131072 as TWO such workgroups per frame.  One radix-2 step of decimation in frequency in front of the transform:
+// with z1, z2 the windowed halves of the frame (as complex points), the even bins of the half-length spectrum are the
+// 32768-point transform of z1 + z2 and the odd ones that of (z1 - z2) W_65536^n -- workgroup `res` = 0 / 1 forms its input
+// from both halves on the way in (the two of a frame are neighbours on an XCD and share the frame in L2) and owns the bins
+// k = 2 k' + res.  The split step's partner of bin k is 65536 - k: even with even (sub-index k' with 32768 - k', as at
+// 65536), odd with odd (k' with 32767 - k': butterfly j with 1023 - j), so both workgroups finish on their own.  The window
+// of the second half is one minus the window of the first (Hann, half a period on), its even sample's angle is the angle
+// of W^n.  The frame mean never touches the samples here: its pivot is the mean of 2048 samples spread over the frame, and
+// what the sum of the differences says is left comes out of bins 0 and 1 at the split step (m nfft / 2 and -m nfft / 4
+// under the Hann window, nothing elsewhere).
+template <bool DB, bool X2>
+__global__ __launch_bounds__(512, 2) void spec_chip_kernel(
     const float *__restrict__ x, long long x_pitch, long long n_valid, long long frames_out, long long out_pitch, int hop,
     float scale, float *__restrict__ out, float *__restrict__ db_out, int frames_per_block, long long runs_per_channel,
     long long total_runs)
 {
-    constexpr int NFFT = 65536, M = NFFT / 2, F = M + 1, LPF = 512, R = 32, Q = M / R, H = M / 2;
+    constexpr int NFFT = X2 ? 131072 : 65536, M = 32768, MF = NFFT / 2, F = MF + 1, SB = X2 ? 2 : 1;   // M: the transform; MF + 1 bins
+    constexpr int LPF = 512, R = 32, Q = M / R, H = M / 2;
     __shared__ float2 xb[H + H / 32];
     __shared__ float red[2][LPF / 64];
     const int l = threadIdx.x, lane = l & 63, wave = l >> 6;
@@ -38,8 +49,10 @@ __global__ __launch_bounds__(512, 2) void spec_chip65536_kernel(
     // are numbered so that an XCD works on CONSECUTIVE runs at any time: the half a frame shares with its neighbour is
     // then fetched by two CUs of one XCD within microseconds of each other -- one trip to HBM, not two.
     const long long per_xcd = (total_runs + 7) / 8;
-    const long long w = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if ((long long)(blockIdx.x >> 3) >= per_xcd || w >= total_runs) return;
+    const long long wx = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((long long)(blockIdx.x >> 3) >= per_xcd || wx >= total_runs) return;
+    const int res = X2 ? (int)(wx & 1) : 0;                  // which bins of the frame: k = SB k' + res
+    const long long w = X2 ? wx >> 1 : wx;
     const long long ch = w / runs_per_channel;
     const float *xc = x + ch * x_pitch;
     float *oc = out + ch * out_pitch;
@@ -52,13 +65,16 @@ __global__ __launch_bounds__(512, 2) void spec_chip65536_kernel(
 
     // frame-invariant twiddle bases of this thread (exact fractions of a turn)
     const int k2 = l & 31;                                   // stage 2: W_1024^(k2 t), the same k2 for both butterflies
-    const int j3a = l, j3b = (l == 0) ? 512 : 1024 - l;      // stage 3 butterflies: a pair of partners
+    const int j3a = l, j3b = res ? 1023 - l : ((l == 0) ? 512 : 1024 - l);      // stage 3 butterflies: a pair of partners
     auto cis = [](float turn) { return make_float2(__builtin_amdgcn_cosf(turn), -__builtin_amdgcn_sinf(turn)); };   // exp(-2 pi i turn)
     float2 w2 = cis((float)k2 * (1.0f / 1024.0f));
     float2 w3a = cis((float)j3a * (1.0f / 32768.0f)), w3b = cis((float)j3b * (1.0f / 32768.0f));
-    float2 sa = cis((float)j3a * (1.0f / 65536.0f)), sb = cis((float)j3b * (1.0f / 65536.0f));   // split twiddles of the first bins
+    float2 sa = cis((float)(SB * j3a + res) * (1.0f / (float)NFFT)), sb = cis((float)(SB * j3b + res) * (1.0f / (float)NFFT));   // split twiddles of the first bins
 
-    for (int it = 0; it < nv; it++) {
+    // (one frame; RES, which bins of it, as a compile-time constant: a run-time `res` inside the unrolled loops left a branch
+    // per iteration and per-lane 64-bit addresses behind)
+    auto frame_body = [&](int it, auto res_c) {
+        constexpr int RES = decltype(res_c)::value;
         const long long frame = fbeg + it;
         const float *seg = xc + frame * (long long)hop;
         float pivot = seg[0];                                // (the first of the two steps of the frame mean, below)
@@ -69,54 +85,121 @@ __global__ __launch_bounds__(512, 2) void spec_chip65536_kernel(
         asm volatile("" : "+v"(sa.x), "+v"(sa.y), "+v"(sb.x), "+v"(sb.y));
         // ---- stage 1 inputs: z[n] = (x[2n], x[2n+1]), n = j + 1024 t, butterflies j = l and l + 512
         float2 v0[R], v1[R];
-        float s = 0.f;
+        if constexpr (X2) {
+            {
+                // the pivot: the mean of 2048 samples spread over the frame, none of them on its borders (a pulse among them
+                // moves it by 1/2048 of itself; what the pivot misses of the mean is corrected below, to the accuracy of a
+                // float32 sum of 131072 differences -- the closer, the better)
+                float p = (seg[64 * l + 32] + seg[64 * (l + 512) + 32]) + (seg[64 * (l + 1024) + 32] + seg[64 * (l + 1536) + 32]);
+                p = wave_sum(p);
+                if (lane == 0) red[0][wave] = p;
+                __syncthreads();
+                float tot = 0.f;
 #pragma unroll
-        for (int t = 0; t < R; t++) {
-            // (a uniform base per load plus one 32-bit lane offset: 64 lane addresses of 64 bits would be half the registers)
-            const f2q a = *reinterpret_cast<const f2q *>(reinterpret_cast<const char *>(seg + 2 * Q * t) + loff);
-            const f2q b = *reinterpret_cast<const f2q *>(reinterpret_cast<const char *>(seg + 2 * Q * t + 1024) + loff);
-            v0[t] = make_float2(a.x - pivot, a.y - pivot);
-            v1[t] = make_float2(b.x - pivot, b.y - pivot);
-            s += (v0[t].x + v0[t].y) + (v1[t].x + v1[t].y);
-        }
-        s = wave_sum(s);
-        if (lane == 0) red[0][wave] = s;
-        __syncthreads();
-        float total = 0.f;
+                for (int w8 = 0; w8 < LPF / 64; w8++) tot += red[0][w8];
+                tot *= 1.0f / (float)(4 * LPF);
+                pivot = (fabsf(tot) <= 3.0e38f) ? tot : pivot;
+            }
+            float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};    // (eight partial sums: smaller partial sums, smaller roundings)
+            auto stage_in = [&](auto bc, float2 *v) {
+                constexpr int b = decltype(bc)::value, TB = 16;
+                // n = l + 512 b + 1024 t: the even sample's window angle 2 n / nfft IS the angle of W_65536^n; the odd
+                // sample's is 1 / nfft of a turn further on; + t / 64 of a turn per t
+                const float a0 = (float)(l + 512 * b + zero) * (1.0f / 65536.0f);
+                const float a1 = (float)(2 * (l + 512 * b) + 1 + zero) * (1.0f / 131072.0f);
+                const float c0 = __builtin_amdgcn_cosf(a0), s0 = __builtin_amdgcn_sinf(a0);
+                const float c1 = __builtin_amdgcn_cosf(a1), s1 = __builtin_amdgcn_sinf(a1);
+                // (loads as SGPR base + 32-bit lane offset in inline asm: from C++ hipcc adds the lane offset to the frame's
+                // address FIRST -- the subexpression all 128 loads share -- and then pays a 64-bit VALU addition and a register
+                // pair per load.  The wait for them is by hand, the empty asm statements keep their uses behind it.)
 #pragma unroll
-        for (int w = 0; w < LPF / 64; w++) total += red[0][w];
-        // The frame mean in TWO steps: the mean of the differences to the frame's first sample is good to 6e-8 of ITS size,
-        // and that sample may be a pulse a thousand times the rest of the frame under a window weight of zero (chain.hip's
-        // psd_frame has the case; every workgroup starts a new frame here, there is no frame before it to take a pivot
-        // from): subtract it, take the mean of what is left -- small whatever the sample was -- and subtract that too.
-        const float mean0 = total * (1.0f / (float)NFFT);
-        float s1 = 0.f;
+              for (int th = 0; th < R; th += TB) {             // (sixteen inputs at a time: 64 registers of loads in flight)
+                v2f pr[TB], qr[TB];
 #pragma unroll
-        for (int t = 0; t < R; t++) {
-            v0[t].x -= mean0; v0[t].y -= mean0; v1[t].x -= mean0; v1[t].y -= mean0;
-            s1 += (v0[t].x + v0[t].y) + (v1[t].x + v1[t].y);
-        }
-        s1 = wave_sum(s1);
-        if (lane == 0) red[1][wave] = s1;
-        __syncthreads();
-        float total1 = 0.f;
+                for (int t = th; t < th + TB; t++) {
+                    const float *b1 = seg + 2 * Q * t + 1024 * b, *b2 = seg + NFFT / 2 + 2 * Q * t + 1024 * b;
+                    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(pr[t - th]) : "v"(loff), "s"(b1) : "memory");
+                    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(qr[t - th]) : "v"(loff), "s"(b2) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int w = 0; w < LPF / 64; w++) total1 += red[1][w];
-        const float mean = total1 * (1.0f / (float)NFFT);
-        {
-            // periodic Hann 0.5 - 0.5 cos(2 pi i / nfft) at i = 2n, 2n + 1: n = l + 1024 t is t / 32 of a turn further on,
-            // the second butterfly 1 / 64 of a turn
-            const float a0 = (float)(2 * l + zero) * (1.0f / (float)NFFT), a1 = (float)(2 * l + 1 + zero) * (1.0f / (float)NFFT);
-            const float c0 = __builtin_amdgcn_cosf(a0), s0 = __builtin_amdgcn_sinf(a0);
-            const float c1 = __builtin_amdgcn_cosf(a1), s1 = __builtin_amdgcn_sinf(a1);
-#pragma unroll
+                for (int t = th; t < th + TB; t++) {
+                    asm volatile("" : "+v"(pr[t - th]), "+v"(qr[t - th]));
+                    const v2f p = pr[t - th], q = qr[t - th];
+                    const float d1x = p.x - pivot, d1y = p.y - pivot, d2x = q.x - pivot, d2y = q.y - pivot;
+                    acc8[t % 8] += (d1x + d1y) + (d2x + d2y);
+                    const float ct = wgs_cos64(t), st = wgs_sin64(t);
+                    const float cx = c0 * ct - s0 * st, sx = s0 * ct + c0 * st, cy = c1 * ct - s1 * st;
+                    const float wx1 = 0.5f - 0.5f * cx, wy1 = 0.5f - 0.5f * cy;       // the first half's window; the second half's is 1 - it
+                    const float e1x = wx1 * d1x, e1y = wy1 * d1y, e2x = (1.0f - wx1) * d2x, e2y = (1.0f - wy1) * d2y;
+                    if constexpr (RES == 0) {
+                        v[t] = make_float2(e1x + e2x, e1y + e2y);
+                    } else {
+                        const float dx = e1x - e2x, dy = e1y - e2y;                  // times exp(-2 pi i n / 65536) = cx - i sx
+                        v[t] = make_float2(dx * cx + dy * sx, dy * cx - dx * sx);
+                    }
+                    asm volatile("" : "+v"(v[t].x), "+v"(v[t].y));       // (here and now: left alone hipcc parks the differences in scratch
+                                                                         // memory and forms the inputs when the first butterfly asks for them)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            };
+            stage_in(std::integral_constant<int, 0>(), v0);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_in(std::integral_constant<int, 1>(), v1);
+            float acc = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
+            acc = wave_sum(acc);
+            if (lane == 0) red[1][wave] = acc;               // (read at the split step, eight barriers on)
+        } else {
+            float s = 0.f;
+    #pragma unroll
             for (int t = 0; t < R; t++) {
-                const float ca = wgs_cos64(2 * t), sn = wgs_sin64(2 * t);
-                const float cb = wgs_cos64(2 * t + 1), sb2 = wgs_sin64(2 * t + 1);
-                v0[t].x = (v0[t].x - mean) * (0.5f - 0.5f * (c0 * ca - s0 * sn));
-                v0[t].y = (v0[t].y - mean) * (0.5f - 0.5f * (c1 * ca - s1 * sn));
-                v1[t].x = (v1[t].x - mean) * (0.5f - 0.5f * (c0 * cb - s0 * sb2));
-                v1[t].y = (v1[t].y - mean) * (0.5f - 0.5f * (c1 * cb - s1 * sb2));
+                // (a uniform base per load plus one 32-bit lane offset: 64 lane addresses of 64 bits would be half the registers)
+                const f2q a = *reinterpret_cast<const f2q *>(reinterpret_cast<const char *>(seg + 2 * Q * t) + loff);
+                const f2q b = *reinterpret_cast<const f2q *>(reinterpret_cast<const char *>(seg + 2 * Q * t + 1024) + loff);
+                v0[t] = make_float2(a.x - pivot, a.y - pivot);
+                v1[t] = make_float2(b.x - pivot, b.y - pivot);
+                s += (v0[t].x + v0[t].y) + (v1[t].x + v1[t].y);
+            }
+            s = wave_sum(s);
+            if (lane == 0) red[0][wave] = s;
+            __syncthreads();
+            float total = 0.f;
+    #pragma unroll
+            for (int w = 0; w < LPF / 64; w++) total += red[0][w];
+            // The frame mean in TWO steps: the mean of the differences to the frame's first sample is good to 6e-8 of ITS size,
+            // and that sample may be a pulse a thousand times the rest of the frame under a window weight of zero (chain.hip's
+            // psd_frame has the case; every workgroup starts a new frame here, there is no frame before it to take a pivot
+            // from): subtract it, take the mean of what is left -- small whatever the sample was -- and subtract that too.
+            const float mean0 = total * (1.0f / (float)NFFT);
+            float s1 = 0.f;
+    #pragma unroll
+            for (int t = 0; t < R; t++) {
+                v0[t].x -= mean0; v0[t].y -= mean0; v1[t].x -= mean0; v1[t].y -= mean0;
+                s1 += (v0[t].x + v0[t].y) + (v1[t].x + v1[t].y);
+            }
+            s1 = wave_sum(s1);
+            if (lane == 0) red[1][wave] = s1;
+            __syncthreads();
+            float total1 = 0.f;
+    #pragma unroll
+            for (int w = 0; w < LPF / 64; w++) total1 += red[1][w];
+            const float mean = total1 * (1.0f / (float)NFFT);
+            {
+                // periodic Hann 0.5 - 0.5 cos(2 pi i / nfft) at i = 2n, 2n + 1: n = l + 1024 t is t / 32 of a turn further on,
+                // the second butterfly 1 / 64 of a turn
+                const float a0 = (float)(2 * l + zero) * (1.0f / (float)NFFT), a1 = (float)(2 * l + 1 + zero) * (1.0f / (float)NFFT);
+                const float c0 = __builtin_amdgcn_cosf(a0), s0 = __builtin_amdgcn_sinf(a0);
+                const float c1 = __builtin_amdgcn_cosf(a1), s1 = __builtin_amdgcn_sinf(a1);
+    #pragma unroll
+                for (int t = 0; t < R; t++) {
+                    const float ca = wgs_cos64(2 * t), sn = wgs_sin64(2 * t);
+                    const float cb = wgs_cos64(2 * t + 1), sb2 = wgs_sin64(2 * t + 1);
+                    v0[t].x = (v0[t].x - mean) * (0.5f - 0.5f * (c0 * ca - s0 * sn));
+                    v0[t].y = (v0[t].y - mean) * (0.5f - 0.5f * (c1 * ca - s1 * sn));
+                    v1[t].x = (v1[t].x - mean) * (0.5f - 0.5f * (c0 * cb - s0 * sb2));
+                    v1[t].y = (v1[t].y - mean) * (0.5f - 0.5f * (c1 * cb - s1 * sb2));
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);       // (one butterfly at a time: two interleaved ones do not fit the registers)
@@ -214,44 +297,86 @@ __global__ __launch_bounds__(512, 2) void spec_chip65536_kernel(
             const v2f pw = (re * re + im * im) * hscale2;
             pk = pw.x; pm = pw.y;
         };
-        // bin j + 1024 t and its partner M - j - 1024 t: a uniform base per store plus a 32-bit lane offset (as for the loads)
+        // bin SB (j + 1024 t) + res and its partner MF minus that: a uniform base per store plus a 32-bit lane offset (as for
+        // the loads); SB = 2 at nfft 131072, where this workgroup owns every second bin
         auto put = [&](int t, unsigned lo, unsigned lm, float pk, float pm) {
-            *reinterpret_cast<float *>(reinterpret_cast<char *>(o + Q * t) + lo) = pk;
-            *reinterpret_cast<float *>(reinterpret_cast<char *>(o + (M - Q) - Q * t) + lm) = pm;
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(o + SB * Q * t + RES) + lo) = pk;
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(o + (MF - SB * Q) - SB * Q * t + RES) + lm) = pm;
             if (DB) {
-                *reinterpret_cast<float *>(reinterpret_cast<char *>(od + Q * t) + lo) = to_db(pk);
-                *reinterpret_cast<float *>(reinterpret_cast<char *>(od + (M - Q) - Q * t) + lm) = to_db(pm);
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(od + SB * Q * t + RES) + lo) = to_db(pk);
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(od + (MF - SB * Q) - SB * Q * t + RES) + lm) = to_db(pm);
             }
         };
-        const unsigned loa = 4u * (unsigned)j3a, lma = 4u * (unsigned)(Q - j3a), lob = 4u * (unsigned)j3b, lmb = 4u * (unsigned)(Q - j3b);
+        // X2: half the sum of the differences to the pivot = m nfft / 2, what the frame mean left in bin 0 (and, halved and
+        // negated, in bin 1: `re` below is twice that bin's real part)
+        float corr = 0.f;
+        if constexpr (X2) {
 #pragma unroll
-        for (int t = 0; t < R / 2; t++) {
-            // exp(-2 pi i (k0 + 1024 t) / 65536) = base * exp(-2 pi i t / 64)
-            const float ct = wgs_cos64(t), st = wgs_sin64(t);
-            const float2 twa = make_float2(sa.x * ct + sa.y * st, sa.y * ct - sa.x * st);
-            const float2 twb = make_float2(sb.x * ct + sb.y * st, sb.y * ct - sb.x * st);
-            float pk, pm;
-            // (selects of VALUES: `l0 ? ya[i] : yb[j]` is a select of addresses and keeps the arrays in scratch memory)
-            const float2 pa0 = ya[t == 0 ? 0 : 32 - t], pa1 = yb[31 - t], pb0 = yb[31 - t], pb1 = ya[31 - t];
-            pair_psd(ya[t], make_float2(l0 ? pa0.x : pa1.x, l0 ? pa0.y : pa1.y), twa, pk, pm);
-            if (t == 0) {
-                const float dc0 = ya[0].x + ya[0].y, ny = ya[0].x - ya[0].y;     // DC and Nyquist, not doubled
-                pk = l0 ? dc0 * dc0 * scale : pk;
-                pm = l0 ? ny * ny * scale : pm;
-            }
-            put(t, loa, lma, pk, pm);
-            pair_psd(yb[t], make_float2(l0 ? pb0.x : pb1.x, l0 ? pb0.y : pb1.y), twb, pk, pm);
-            put(t, lob, lmb, pk, pm);
+            for (int w8 = 0; w8 < LPF / 64; w8++) corr += red[1][w8];
+            corr *= 0.5f;
         }
-        if (l0) {
-            const float ph = 2.f * scale * (ya[16].x * ya[16].x + ya[16].y * ya[16].y);
-            o[M / 2] = ph;
-            if (DB) od[M / 2] = to_db(ph);
+        if constexpr (X2 && RES == 1) {
+            // odd bins: k = 2 (l + 1024 t) + 1 from (ya[t], yb[31 - t]), its partner 65536 - k from the same pair; no bin
+            // pairs with itself
+            const unsigned lo1 = 8u * (unsigned)l, lm1 = 8u * (unsigned)(1023 - l);
+#pragma unroll
+            for (int t = 0; t < R; t++) {
+                const float ct = wgs_cos64(t), st = wgs_sin64(t);
+                const float2 twa = make_float2(sa.x * ct + sa.y * st, sa.y * ct - sa.x * st);
+                const v2f e = pk_add_conj(as_v2f(ya[t]), as_v2f(yb[31 - t]));
+                const v2f tt = pk_cmul_negi(pk_sub_conj(as_v2f(ya[t]), as_v2f(yb[31 - t])), as_v2f(twa));
+                v2f re = pk_sumdiff_x(e, tt);
+                const v2f im = pk_sumdiff_y(e, tt);
+                if (t == 0) re.x += l0 ? corr : 0.f;                 // bin 1
+                const v2f pw = (re * re + im * im) * hscale2;
+                // (the partner of k = 2 (l + 1024 t) + 1 is (65536 - 2048 - 2048 t) + 2 (1023 - l) + 1)
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(o + SB * Q * t + 1) + lo1) = pw.x;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(o + (MF - SB * Q) - SB * Q * t + 1) + lm1) = pw.y;
+                if (DB) {
+                    *reinterpret_cast<float *>(reinterpret_cast<char *>(od + SB * Q * t + 1) + lo1) = to_db(pw.x);
+                    *reinterpret_cast<float *>(reinterpret_cast<char *>(od + (MF - SB * Q) - SB * Q * t + 1) + lm1) = to_db(pw.y);
+                }
+            }
+        } else {
+            const unsigned loa = 4u * SB * (unsigned)j3a, lma = 4u * SB * (unsigned)(Q - j3a), lob = 4u * SB * (unsigned)j3b,
+                           lmb = 4u * SB * (unsigned)(Q - j3b);
+#pragma unroll
+            for (int t = 0; t < R / 2; t++) {
+                // exp(-2 pi i (k0 + SB 1024 t) / nfft) = base * exp(-2 pi i t / 64)
+                const float ct = wgs_cos64(t), st = wgs_sin64(t);
+                const float2 twa = make_float2(sa.x * ct + sa.y * st, sa.y * ct - sa.x * st);
+                const float2 twb = make_float2(sb.x * ct + sb.y * st, sb.y * ct - sb.x * st);
+                float pk, pm;
+                // (selects of VALUES: `l0 ? ya[i] : yb[j]` is a select of addresses and keeps the arrays in scratch memory)
+                const float2 pa0 = ya[t == 0 ? 0 : 32 - t], pa1 = yb[31 - t], pb0 = yb[31 - t], pb1 = ya[31 - t];
+                pair_psd(ya[t], make_float2(l0 ? pa0.x : pa1.x, l0 ? pa0.y : pa1.y), twa, pk, pm);
+                if (t == 0) {
+                    const float dc0 = ya[0].x + ya[0].y - corr, ny = ya[0].x - ya[0].y;     // DC and Nyquist, not doubled
+                    pk = l0 ? dc0 * dc0 * scale : pk;
+                    pm = l0 ? ny * ny * scale : pm;
+                }
+                put(t, loa, lma, pk, pm);
+                pair_psd(yb[t], make_float2(l0 ? pb0.x : pb1.x, l0 ? pb0.y : pb1.y), twb, pk, pm);
+                put(t, lob, lmb, pk, pm);
+            }
+            if (l0) {
+                const float ph = 2.f * scale * (ya[16].x * ya[16].x + ya[16].y * ya[16].y);
+                o[MF / 2] = ph;
+                if (DB) od[MF / 2] = to_db(ph);
+            }
         }
         __syncthreads();                                     // (red[] and the exchange buffer are reused by the next frame)
+    };
+    if constexpr (X2) {                                      // (one frame per workgroup: no loop for the compiler to hoist out of)
+        if (nv > 0) {
+            if (res) frame_body(0, std::integral_constant<int, 1>());
+            else frame_body(0, std::integral_constant<int, 0>());
+        }
+    } else {
+        for (int it = 0; it < nv; it++) frame_body(it, std::integral_constant<int, 0>());
     }
     // frames behind the last valid one (bufferedspectrogram.py:59)
-    for (long long frame = fbeg + nv; frame < fbeg + nh; frame++) {
+    for (long long frame = fbeg + nv; res == 0 && frame < fbeg + nh; frame++) {
         float *o = oc + frame * (long long)F;
         for (int f = l; f < F; f += LPF) {
             o[f] = 0.f;
@@ -260,21 +385,22 @@ __global__ __launch_bounds__(512, 2) void spec_chip65536_kernel(
     }
 }
 
-inline int run_chip65536(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long channels, long long n_valid,
-                         long long frames_out, long long out_pitch, int hop, float scale, float *out, float *db_out)
+template <bool X2>
+inline int run_chip(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long channels, long long n_valid,
+                    long long frames_out, long long out_pitch, int hop, float scale, float *out, float *db_out)
 {
     // (a run of ONE frame: neighbours in time are then neighbours on the XCD, and the half they share is in L2; a longer run
     // only amortises a thread's five base twiddles and re-reads its own shared halves 30 us later, from HBM)
-    long long fpb = ctx->spec_fpw > 0 ? ctx->spec_fpw : 1;
+    long long fpb = (!X2 && ctx->spec_fpw > 0) ? ctx->spec_fpw : 1;
     if (fpb > 16) fpb = 16;
-    const long long runs = (frames_out + fpb - 1) / fpb, total = runs * channels;
+    const long long runs = (frames_out + fpb - 1) / fpb, total = runs * channels * (X2 ? 2 : 1);
     HD_REQUIRE(total <= 0x7ffffff0LL, "too many frames");
     const dim3 grid((unsigned)(((total + 7) / 8) * 8));
     if (db_out)
-        hipLaunchKernelGGL((spec_chip65536_kernel<true>), grid, dim3(512), 0, ctx->stream, x, x_pitch, n_valid, frames_out,
+        hipLaunchKernelGGL((spec_chip_kernel<true, X2>), grid, dim3(512), 0, ctx->stream, x, x_pitch, n_valid, frames_out,
                            out_pitch, hop, scale, out, db_out, (int)fpb, runs, total);
     else
-        hipLaunchKernelGGL((spec_chip65536_kernel<false>), grid, dim3(512), 0, ctx->stream, x, x_pitch, n_valid, frames_out,
+        hipLaunchKernelGGL((spec_chip_kernel<false, X2>), grid, dim3(512), 0, ctx->stream, x, x_pitch, n_valid, frames_out,
                            out_pitch, hop, scale, out, db_out, (int)fpb, runs, total);
-    return hd_launch_status("spec_chip65536_kernel");
+    return hd_launch_status("spec_chip_kernel");
 }

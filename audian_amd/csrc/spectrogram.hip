@@ -1284,7 +1284,10 @@ extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pit
                       : run_wgs<32768, 512, 16, 32, 32, 1>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
     // 65536: the frame in the registers of one workgroup (spec_chip.h); "spec_kernel" 2: the four-step path through HBM
     if (!ctx->force_generic_fft && nfft == 65536 && !old_wg)
-        return run_chip65536(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+        return run_chip<false>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+    // 131072: two such workgroups per frame, one for the even and one for the odd bins
+    if (!ctx->force_generic_fft && nfft == 131072 && !old_wg)
+        return run_chip<true>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
     if (nfft > 8192)
         return run_big(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, nfft, hop, scale, out, db_out);
     size_t lds = sizeof(float2) * 2 * (size_t)nfft;

@@ -118,7 +118,7 @@ def test_random_spectrogram_cases(oracle, seed):
     elif family == 1:
         nfft = int(2**rng.integers(8, 13))                # register/LDS kernels
     elif family == 2:
-        nfft = int(rng.choice([8192, 16384, 32768, 65536]))   # workgroup FFT, four-step FFT
+        nfft = int(rng.choice([8192, 16384, 32768, 65536, 131072]))   # workgroup FFT, frame-on-chip FFT
     else:
         nfft = int(rng.integers(9, 600))                  # whatever the clamp can produce
     hop = int(rng.choice([nfft//2, max(nfft//4, 1), nfft, int(rng.integers(1, nfft + 1))]))
