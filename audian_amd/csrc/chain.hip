@@ -109,8 +109,18 @@ __device__ __forceinline__ void psd_frame(const v2f *w, float2 *fb, const float2
         piv = (fabsf(c) <= 3.0e38f) ? c : piv;
     }
     const v2f mean2 = {mean, mean};
+    // What the subtraction leaves: after a step in the level the differences to the mean of the frame before are all large,
+    // `mean` is good to 6e-8 of THEM, and the Hann window puts that error times nfft / 2 into bins 0 and 1.  The detrended
+    // samples are summed once more; their mean m1 under the periodic Hann window is m1 nfft / 2 in bin 0, -m1 nfft / 4 in bin
+    // 1 and nothing elsewhere, and the split step takes it out (spec_wgs.h, spec_pack.h and spec_fast_kernel do the same).
+    v2f rest = {0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < R1; t++) v[t] = as_f2((as_v2f(v[t]) - mean2) * as_v2f(win[l + LPF * t]));
+    for (int t = 0; t < R1; t++) {
+        const v2f q = as_v2f(v[t]) - mean2;
+        rest += q;
+        v[t] = as_f2(q * as_v2f(win[l + LPF * t]));
+    }
+    const float corr = 0.5f * gsum(rest.x + rest.y);
     hook(0);                                   // mean and window
     stockham_stage<R1, 1, M, LPF, false, true>(v, fb, tw2, l);
     hook(1);                                   // first butterflies, values on their way through LDS
@@ -139,11 +149,13 @@ __device__ __forceinline__ void psd_frame(const v2f *w, float2 *fb, const float2
         }
         const v2f e = pk_add_conj(as_v2f(zk), as_v2f(zm));
         const v2f t = pk_cmul_negi(pk_sub_conj(as_v2f(zk), as_v2f(zm)), as_v2f(twn[k]));
-        const v2f re = pk_sumdiff_x(e, t), im = pk_sumdiff_y(e, t);
+        v2f re = pk_sumdiff_x(e, t);
+        const v2f im = pk_sumdiff_y(e, t);
+        if (m == 0) re.x += (l == 1) ? corr : 0.f;                    // bin 1 (`re` is twice its real part)
         const v2f pw = (re * re + im * im) * hscale2;
         float pk = pw.x, pm = pw.y;
         if (m == 0) {
-            const float dc0 = zk.x + zk.y, ny = zk.x - zk.y;
+            const float dc0 = zk.x + zk.y - corr, ny = zk.x - zk.y;
             pk = (l == 0) ? dc0 * dc0 * scale : pk;
             pm = (l == 0) ? ny * ny * scale : pm;
         }

@@ -159,6 +159,8 @@ __global__ __launch_bounds__(256, 3) void spec_pack_kernel(
         const bool valid = g < nval;
         // ---- the batch's frames, one per lane group, out of the ring
         float2 v[PPL];
+        constexpr bool CORRP = NFFT >= 128;
+        float corr = 0.f;
         {
             const int r0 = (int)(((fb0 + (valid ? g : 0)) * (long long)hop) & (RB - 1)) + 2 * l;
             // The frame mean (detrend='constant') relative to a PIVOT: on a trace that is an offset plus something small --
@@ -169,7 +171,9 @@ __global__ __launch_bounds__(256, 3) void spec_pack_kernel(
             // sample: a frame that starts on a pulse has that sample under a window weight of zero (chain.hip's psd_frame
             // has the case).  The run's first batch takes two steps: the batch's first sample (one LDS word, the same for
             // every lane; zero if it is not finite) as the pivot of a rough mean, that mean as the pivot.
-            if (b == 0) {
+            // (Windows of up to 64 samples take the two steps in every batch: the mean of so few samples follows a single pulse
+            // among them -- 1/8 of it at nfft 8 -- and would be a poor pivot for the frame that comes G frames later.)
+            if (b == 0 || NFFT <= 64) {
                 float p0 = ring[(int)((fb0 * (long long)hop) & (RB - 1))];
                 p0 = (fabsf(p0) <= 3.0e38f) ? p0 : 0.f;
                 const v2f p02 = {p0, p0};
@@ -201,23 +205,34 @@ __global__ __launch_bounds__(256, 3) void spec_pack_kernel(
                 const float c = pvs + mean;                          // the next batch's pivot (a NaN or Inf in this frame: unchanged)
                 pvs = (fabsf(c) <= 3.0e38f) ? c : pvs;
             }
+            // CORRP (nfft 128, 256): what the subtraction leaves.  The pivot here is G frames old; after a step in the level
+            // the differences of up to G flat frames are all the size of the step, their mean is good to 6e-8 of THAT, and
+            // the Hann window puts the error times nfft / 2 into bins 0 and 1 (2e-4 of the frame's peak behind 275 sigma at
+            // nfft 256).  The detrended samples are summed once more and their mean taken out of those two bins at the
+            // split step (m1 nfft / 2 and -m1 nfft / 4 under the periodic Hann window), as in spec_wgs.h.
+            v2f rest = {0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < PPL / R1; u++)
 #pragma unroll
                 for (int t = 0; t < R1; t++) {
                     float2 &e = v[u * R1 + t];
-                    e = as_f2((as_v2f(e) - mean2) * as_v2f(win[l + LPF * u + t * (M / R1)]));
+                    const v2f q = as_v2f(e) - mean2;
+                    if (CORRP) rest += q;
+                    e = as_f2(q * as_v2f(win[l + LPF * u + t * (M / R1)]));
                 }
+            if (CORRP) corr = 0.5f * group_sum<LPF>(rest.x + rest.y);
         }
         constexpr int RL = THREE ? R3 : R2, NBL = PPL / RL;          // the last stage's radix
         float *sg = stage + g * F;
         const bool full = nval == G;                                 // (wave-uniform: the masks only in a run's last batch)
         const v2f hscale2 = {0.5f * scale, 0.5f * scale};
         // one pair of bins: X[k] = E + W^k O, X[M-k] = conj(E - W^k O) from Z[k] and Z[M-k]; the halves go into the scale
-        auto pair_psd = [&](float2 zk, float2 zm, int k, float &pk, float &pm) {
+        auto pair_psd = [&](float2 zk, float2 zm, int k, float &pk, float &pm, float re_add = 0.f) {
             const v2f e = pk_add_conj(as_v2f(zk), as_v2f(zm));
             const v2f t = pk_cmul_negi(pk_sub_conj(as_v2f(zk), as_v2f(zm)), as_v2f(twn[k]));
-            const v2f re = pk_sumdiff_x(e, t), im = pk_sumdiff_y(e, t);
+            v2f re = pk_sumdiff_x(e, t);
+            const v2f im = pk_sumdiff_y(e, t);
+            re.x += re_add;                                          // (bin 1 of lane 1: `re` is twice its real part)
             const v2f pw = (re * re + im * im) * hscale2;
             pk = pw.x; pm = pw.y;
         };
@@ -262,12 +277,12 @@ __global__ __launch_bounds__(256, 3) void spec_pack_kernel(
             float pk[4], pm[4];
             int kk[4];
             kk[0] = l; kk[1] = NS3 + l; kk[2] = l0 ? 3 * NS3 / 2 : 2 * NS3 - l; kk[3] = l0 ? NS3 / 2 : NS3 - l;
-            pair_psd(A[0], B[3], kk[0], pk[0], pm[0]);
+            pair_psd(A[0], B[3], kk[0], pk[0], pm[0], (CORRP && l == 1) ? corr : 0.f);
             pair_psd(A[1], l0 ? A[3] : B[2], kk[1], pk[1], pm[1]);
             pair_psd(B[1], l0 ? B[2] : A[2], kk[2], pk[2], pm[2]);
             pair_psd(B[0], l0 ? B[3] : A[3], kk[3], pk[3], pm[3]);
             {
-                const float dc0 = A[0].x + A[0].y, ny = A[0].x - A[0].y;     // DC and Nyquist, not doubled
+                const float dc0 = A[0].x + A[0].y - corr, ny = A[0].x - A[0].y;     // DC and Nyquist, not doubled
                 pk[0] = l0 ? dc0 * dc0 * scale : pk[0];
                 pm[0] = l0 ? ny * ny * scale : pm[0];
             }
@@ -312,9 +327,9 @@ __global__ __launch_bounds__(256, 3) void spec_pack_kernel(
                 zm = (l == 0) ? z0 : zm;
             }
             float pk, pm;
-            pair_psd(zk, zm, k, pk, pm);
+            pair_psd(zk, zm, k, pk, pm, (CORRP && m == 0 && l == 1) ? corr : 0.f);
             if (m == 0) {
-                const float dc0 = zk.x + zk.y, ny = zk.x - zk.y;     // DC and Nyquist, not doubled
+                const float dc0 = zk.x + zk.y - corr, ny = zk.x - zk.y;     // DC and Nyquist, not doubled
                 pk = (l == 0) ? dc0 * dc0 * scale : pk;
                 pm = (l == 0) ? ny * ny * scale : pm;
             }

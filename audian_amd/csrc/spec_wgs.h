@@ -186,7 +186,6 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wgs_kernel(
             // the halves of the frame in LDS are differences to the pivots in force when they were fetched: the upper half's
             // is `pivot`, the lower half's `pivot - delta`
             const float mean = total * (1.0f / (float)NFFT) - 0.5f * delta;      // of (sample - pivot)
-            const float mean_lo = mean + delta;
             // (an always-zero offset the compiler cannot see through: the window and the split twiddles do not depend on
             // the frame, and left alone hipcc computes them once, in front of the loop -- 96 registers that then live
             // through every frame)
@@ -207,8 +206,12 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wgs_kernel(
                 for (int t = 0; t < R1; t++) {
                     const float2 r = raw2[l + LPF * u + t * (M / R1)];
                     const float2 w = KEEPW ? wkeep[u * R1 + t] : wl[t];
-                    const float mt = (HALF && t < R1 / 2) ? mean_lo : mean;       // (input t < R1 / 2: the frame's lower half)
-                    const v2f q = {r.x - mt, r.y - mt};
+                    // (input t < R1 / 2: the frame's lower half, whose pivot is `delta` behind -- taken off in a subtraction of
+                    // its own: exact where it matters, i.e. where delta is large against what is left; one rounded
+                    // `mean + delta` for the whole half would be a step of half an ulp of delta in the middle of the frame)
+                    v2f q = {r.x, r.y};
+                    if (HALF && t < R1 / 2) q = q - (v2f){delta, delta};
+                    q = q - (v2f){mean, mean};
                     rest += q;
                     v[u * R1 + t] = make_float2(q.x * w.x, q.y * w.y);
                 }
@@ -298,7 +301,22 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wgs_kernel(
                 // frame stays as it is, `delta` remembers by how much the pivot moved
                 const float c = pivot + mean;
                 const float pn = (fabsf(c) <= 3.0e38f) ? c : pivot;
-                delta = HALF ? pn - pivot : 0.f;
+                float dl = pn - pivot;
+                if (HALF && !((pivot + dl == pn) && (pn - dl == pivot))) {
+                    // The kept half is x - pivot, the window wants x - pn = (x - pivot) - dl, and dl is not EXACTLY pn - pivot
+                    // (a pivot that moves far -- a step in the level -- drops the low bits of the smaller of the two): the
+                    // halves would disagree by half an ulp of dl, a step in the middle of the next frame that shows in bins 1,
+                    // 3, 5 ... (tools/fuzz_stress.py with runs of 16 frames, nfft 32768: 1.6e-4 of a flat frame's peak behind a
+                    // step of 275 sigma).  Rare: fetch the half again (it was read a frame ago) as differences to pn.
+                    const float *segk = xc + (frame + 1) * (long long)hop;
+#pragma unroll
+                    for (int j = 0; j < (HALF ? NQ / 2 : 0); j++) {
+                        const f4q t = *reinterpret_cast<const f4q *>(segk + 4 * (l + LPF * j));
+                        keep[j] = make_float4(t.x - pn, t.y - pn, t.z - pn, t.w - pn);
+                    }
+                    dl = 0.f;
+                }
+                delta = HALF ? dl : 0.f;
                 pivot = pn;
                 post_sum(put_raw());
                 if (PIPE && it + 2 < nv) fetch(frame + 2);

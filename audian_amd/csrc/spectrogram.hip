@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? (DB ? 2 : 3) : 1) * WAV
         // frame before inside this one it stays under 1e-4).  The detrended samples are summed once more; their mean m1
         // under the window is m1 nfft / 2 in bin 0, -m1 nfft / 4 in bin 1 and nothing elsewhere: the split step removes it.
         // (spec_wgs.h does the same for every hop: its frames are longer and the error grows with sqrt(nfft).)
-        constexpr bool CORR = REUSE == 1;
+        constexpr bool CORR = true;
         v2f rest = {0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < PPL / R1; u++)
@@ -496,7 +496,18 @@ __global__ __launch_bounds__(64 * WAVES) void spec2_kernel(
             }
 #pragma unroll
         for (int d = LPF / 2; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-        const float mean = s * (1.0f / (float)NFFT);
+        // the frame mean in two steps (this cross-check kernel can afford the plain way: the rough mean is subtracted, what
+        // is left is summed again and its mean subtracted too; spec_pack.h has the cases a single float32 sum does not survive)
+        const float mean0 = s * (1.0f / (float)NFFT);
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < PPL; i++) {
+            v[i].x -= mean0; v[i].y -= mean0;
+            s1 += v[i].x + v[i].y;
+        }
+#pragma unroll
+        for (int d = LPF / 2; d >= 1; d >>= 1) s1 += __shfl_xor(s1, d, 64);
+        const float mean = s1 * (1.0f / (float)NFFT);
 #pragma unroll
         for (int u = 0; u < NB1; u++)
 #pragma unroll
@@ -620,7 +631,22 @@ __global__ __launch_bounds__(LPF, OCC) void spec_wg_kernel(
         float total = 0.f;
 #pragma unroll
         for (int w = 0; w < LPF / 64; w++) total += red[w];
-        const float mean = total * (1.0f / (float)NFFT);
+        // (the frame mean in two steps, as in spec2_kernel)
+        const float mean0 = total * (1.0f / (float)NFFT);
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < PPL; i++) {
+            v[i].x -= mean0; v[i].y -= mean0;
+            s1 += v[i].x + v[i].y;
+        }
+        s1 = wave_sum(s1);
+        __syncthreads();          // (red[] has been read)
+        if ((l & 63) == 0) red[wave] = s1;
+        __syncthreads();
+        float total1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < LPF / 64; w++) total1 += red[w];
+        const float mean = total1 * (1.0f / (float)NFFT);
 #pragma unroll
         for (int u = 0; u < PPL / R1; u++)
 #pragma unroll

@@ -667,12 +667,15 @@ def test_random_screen_reductions(oracle, seed):
     assert np.array_equal(dst.to_host()[:, :Tp], (ints.T.astype(np.float64)*scale).astype(np.float32)), (seed, nbytes)
 
 
-def _same_non_finite(got, want, what):
+def _same_non_finite(got, want, what, scale=None):
+    """`scale`: the largest finite value of the whole trace where `want` is only a window of it (the parity metric is per
+    channel, SURVEY 7-3: a window of ONE sample next to the end of a sosfiltfilt, five decades under the envelope's size,
+    is not a channel -- tools/fuzz_stress.py seed 90035 drew nbefore = T - 1)."""
     got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
     bad = ~np.isfinite(want)
     assert np.array_equal(~np.isfinite(got), bad), (what, int((~np.isfinite(got)).sum()), int(bad.sum()))
     if (~bad).any() and np.abs(want[~bad]).max() > 0:
-        assert np.abs(got[~bad] - want[~bad]).max()/np.abs(want[~bad]).max() < TOL, what
+        assert np.abs(got[~bad] - want[~bad]).max()/max(np.abs(want[~bad]).max(), scale or 0.0) < TOL, what
 
 
 @pytest.mark.parametrize('seed', range(12))
@@ -711,9 +714,12 @@ def test_random_non_finite_cases(oracle, seed):
             eskip = int(rng.integers(0, T)) if rng.integers(0, 2) else 0
             de = hipdsp.DeviceArray(c, (C, max(T - eskip, 1)), np.float32)
             hipdsp.envelope(c, eplan, dx, T, de, max(T - eskip, 1), C, T, eskip)
-            want_e = np.zeros((T - eskip, C))
-            oracle.envelope_process(esos, x64, want_e, eskip)
-            _same_non_finite(de.to_host()[:, :T - eskip].T, want_e, (seed, 'envelope', eskip, opts))
+            want_full = np.zeros((T, C))
+            oracle.envelope_process(esos, x64, want_full, 0)
+            want_e = want_full[eskip:]
+            fin = np.isfinite(want_full)
+            _same_non_finite(de.to_host()[:, :T - eskip].T, want_e, (seed, 'envelope', eskip, opts),
+                             scale=np.abs(want_full[fin]).max() if fin.any() else None)
         if long_trace and len(sos) <= 4 and len(esos) <= 2:
             nfft, hop = [(2048, 1024), (2048, 512), (1024, 512), (1024, 256), (512, 256), (256, 128)][int(rng.integers(0, 6))]
             F, nd = nfft//2 + 1, (T + hop - 1)//hop

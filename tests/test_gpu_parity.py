@@ -447,6 +447,38 @@ def test_spectrogram_after_a_step_in_the_level(oracle, nfft):
         assert worst < TOL, (nfft, hop, worst)
 
 
+@pytest.mark.parametrize('nfft', [16, 256, 4096, 8192, 32768])
+def test_spectrogram_steps_inside_long_runs_of_frames(oracle, nfft):
+    """Steps in the level while a wave or workgroup is in the middle of a RUN of frames ("spec_fpw" 16; large batches
+    get there by themselves): the pivot of a frame's mean is carried from frame to frame there.  Two finds of
+    tools/fuzz_stress.py with random options: the workgroup kernels keep the overlapped half as differences to the pivot
+    it was fetched under, and a pivot that moves far is not an exact float32 step -- half an ulp of it between the two
+    halves is a step in the middle of the frame (bins 1, 3, 5 ...: 1.6e-4 at nfft 32768 behind 275 sigma; the half is
+    fetched again then); and at eight or sixteen samples per frame the mean of the frame before follows a single pulse
+    (those windows take the two steps of the first frame in every batch)."""
+    from audian_amd import hipdsp
+    rate, hop = 96000.0, nfft//2
+    rng = np.random.default_rng(nfft)
+    nframes = 56 if nfft >= 4096 else 3000
+    T = (nframes - 1)*hop + nfft + 11
+    x = (1e-3*(rng.standard_normal((T, 2)) + 0.3)).astype(np.float32)
+    for j, d in ((30, 0.275), (33, 0.242), (50, 0.173)):
+        x[(j if nfft >= 4096 else 40*j)*hop:, 0] += np.float32(d)
+    x[1::24, 1] += np.float32(1.69)                      # a pulse in every third frame or so (of 8 or 16 samples)
+    nd = (T + hop - 1)//hop
+    want = np.zeros((nd, 2, nfft//2 + 1))
+    oracle.spectrogram_process(x.astype(np.float64), want, rate, nfft, hop)
+    c = gh.ctx()
+    try:
+        for fpw in (16, 3, 0):
+            c.set_option('spec_fpw', fpw)
+            got = gh.gpu_spectrogram(x, rate, nfft, hop, nd)
+            worst = max(rel_err(got[j, ch], want[j, ch]) for j in range(nd) for ch in range(2) if np.max(np.abs(want[j, ch])) > 0)
+            assert worst < TOL, (nfft, fpw, worst)
+    finally:
+        c.set_option('spec_fpw', 0)
+
+
 @pytest.mark.parametrize('nfft,hop', [(2048, 1024), (1024, 256), (512, 256), (256, 128)])
 def test_fused_sweep_of_pulses_at_the_frame_borders(oracle, nfft, hop):
     """The same pulse train through hipdsp_chain_forward: behind a wide first-order low-pass a pulse stays a few samples
