@@ -189,6 +189,33 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? (DB ? 2 : 3) : 1) * WAV
         v2f acc = {0.f, 0.f};                             // even and odd samples side by side (v_pk_add_f32)
         // the frame mean relative to a PIVOT, the mean of the frame this lane group transformed before (`pvs`; the run's
         // first frame: the two steps in front of the first call) -- chain.hip's psd_frame has the two cases that ask for it
+        auto gsum = [&](float sum) {
+            if (LPF == 64) return wave_sum(sum);
+#pragma unroll
+            for (int d = LPF / 2; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+            return sum;
+        };
+        // TWOSTEP (the variants without register reuse, i.e. every hop but nfft / 2 and nfft / 4 -- hop = nfft among them: the
+        // frame before need not overlap this one at all): the frame's own rough mean as its pivot, in every frame.  Behind a
+        // step in the level the differences to the frame before are the size of the step, and at 3e-8 of the step their
+        // per-sample rounding alone is 3e-4 of a flat frame's peak for 5000 sigma; the differences to the frame's own mean
+        // are the size of what the frame holds.
+        constexpr bool TWOSTEP = REUSE == 1;
+        if (TWOSTEP) {
+            const v2f p02 = {pvs, pvs};
+            v2f a0 = {0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < PPL / R1; u++)
+#pragma unroll
+                for (int t = 0; t < R1; t++) {
+                    v2f *const qs[4] = {qa, qb, qc, qd};
+                    v2f &r = qs[t / R1Q][u * R1Q + t % R1Q];
+                    asm volatile("" : "+v"(r));           // not before the counted wait
+                    a0 += r - p02;
+                }
+            const float c = pvs + gsum(a0.x + a0.y) * (1.0f / (float)NFFT);
+            pvs = (fabsf(c) <= 3.0e38f) ? c : pvs;
+        }
         const v2f pivot2 = {pvs, pvs};
 #pragma unroll
         for (int u = 0; u < PPL / R1; u++)
@@ -201,27 +228,19 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? (DB ? 2 : 3) : 1) * WAV
                 v[u * R1 + t] = make_float2(d.x, d.y);
                 acc += d;
             }
-        float s = acc.x + acc.y;
-        if (LPF == 64) {
-            s = wave_sum(s);
-        } else {
-#pragma unroll
-            for (int d = LPF / 2; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-        }
+        const float s = gsum(acc.x + acc.y);
         const float mean = s * (1.0f / (float)NFFT);
         const v2f mean2 = {mean, mean};
         {
             const float c = pvs + mean;                   // the next frame's pivot (a NaN or Inf in this frame: unchanged)
             pvs = (fabsf(c) <= 3.0e38f) ? c : pvs;
         }
-        // CORR (the variants without register reuse, i.e. every hop but nfft / 2 and nfft / 4 -- hop = nfft among them): what
-        // the subtraction leaves.  After a step in the trace's level the differences to the mean of a frame that does not
-        // overlap this one are all large, `mean` is good to 6e-8 of THEM, and the Hann window puts that error times
-        // nfft / 2 into bins 0 and 1 (3e-4 of a flat frame's peak for a step of 1000 sigma at nfft 1024; with half of the
-        // frame before inside this one it stays under 1e-4).  The detrended samples are summed once more; their mean m1
-        // under the window is m1 nfft / 2 in bin 0, -m1 nfft / 4 in bin 1 and nothing elsewhere: the split step removes it.
-        // (spec_wgs.h does the same for every hop: its frames are longer and the error grows with sqrt(nfft).)
-        constexpr bool CORR = true;
+        // CORR (the variants WITH register reuse; the others have taken two steps): what the subtraction leaves.  After a
+        // step in the trace's level the differences to the mean of the frame before are all large, `mean` is good to 6e-8
+        // of THEM, and the Hann window puts that error times nfft / 2 into bins 0 and 1 (9e-5 of a flat frame's peak for a
+        // step of 1000 sigma at 2048 / 1024).  The detrended samples are summed once more; their mean m1 under the window
+        // is m1 nfft / 2 in bin 0, -m1 nfft / 4 in bin 1 and nothing elsewhere: the split step removes it.
+        constexpr bool CORR = !TWOSTEP;
         v2f rest = {0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < PPL / R1; u++)
@@ -233,17 +252,7 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? (DB ? 2 : 3) : 1) * WAV
                 if (CORR) rest += q;
                 e = as_f2(q * w);
             }
-        float corr = 0.f;
-        if (CORR) {
-            float s1 = rest.x + rest.y;
-            if (LPF == 64) {
-                s1 = wave_sum(s1);
-            } else {
-#pragma unroll
-                for (int d = LPF / 2; d >= 1; d >>= 1) s1 += __shfl_xor(s1, d, 64);
-            }
-            corr = 0.5f * s1;                             // m1 nfft / 2
-        }
+        const float corr = CORR ? 0.5f * gsum(rest.x + rest.y) : 0.f;      // m1 nfft / 2
         // the raw registers are dead from here on: request the next frame now, so that the whole
         // FFT of this one hides the latency
         if (PF && EARLY_PF) {
