@@ -1,4 +1,4 @@
-// spec_chip.h -- nfft 65536 of BufferedSpectrogram.process (the reference's selector offers 2^3 ... 2^19,
+// spec_chip.h -- nfft 65536 and 131072 of BufferedSpectrogram.process (the reference's selector offers 2^3 ... 2^19,
 // src/audian/databrowser.py:516) with the whole frame ON CHIP.  Included by spectrogram.hip inside its anonymous namespace.
 //
 // A frame of 65536 samples is 32768 complex points of the half-length transform: 256 KB, more than the 160 KB of LDS, which
@@ -13,8 +13,9 @@
 // matter of the LDS addresses it reads: thread l takes j = l and 1024 - l (thread 0: the two self-paired ones, 0 and 512).
 // Window, stage twiddles and split twiddles are computed on the fly (v_cos_f32 / v_sin_f32 on exact fractions of a turn
 // for one base angle each, the rest by angle addition with compile-time constants or by powers), the frame mean relative to
-// its first sample and then to that mean (two steps: the sample may be a pulse).  HBM sees each frame's samples once per frame (the overlapped half a second time, a few
-// microseconds later, mostly from L2) and each bin once.
+// its first sample and then to that mean (two steps: the sample may be a pulse).  One frame per workgroup, the workgroups
+// numbered so that an XCD works on consecutive frames: HBM sees each sample once (the half a frame shares with its
+// neighbour comes out of the XCD's L2) and each bin once.
 #pragma once
 
 // X2: nfft 131072 as TWO such workgroups per frame.  One radix-2 step of decimation in frequency in front of the transform:
