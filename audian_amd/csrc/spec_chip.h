@@ -119,8 +119,10 @@ __global__ __launch_bounds__(512, 2) void spec_chip_kernel(
 #pragma unroll
                 for (int t = th; t < th + TB; t++) {
                     const float *b1 = seg + 2 * Q * t + 1024 * b, *b2 = seg + NFFT / 2 + 2 * Q * t + 1024 * b;
-                    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(pr[t - th]) : "v"(loff), "s"(b1) : "memory");
-                    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(qr[t - th]) : "v"(loff), "s"(b2) : "memory");
+                    // (s_nop 4: a base that came out of an SGPR spill slot by v_readlane_b32 just before needs five wait states
+                    // in front of a VMEM instruction that reads it, and hipcc cannot see into the asm -- spec_chipx.h ran into it)
+                    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=v"(pr[t - th]) : "v"(loff), "s"(b1) : "memory");
+                    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=v"(qr[t - th]) : "v"(loff), "s"(b2) : "memory");
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll

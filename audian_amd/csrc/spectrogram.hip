@@ -1178,6 +1178,7 @@ int run_fast(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long chann
 #include "spec_pack.h"
 #include "spec_wgs.h"
 #include "spec_chip.h"
+#include "spec_chipx.h"
 
 template <int NFFT, int LPF, int R1, int R2, int R3, int OCC>
 int run_wg(hipdsp_ctx *ctx, const float *x, long long x_pitch, long long channels, long long n_valid,
@@ -1323,6 +1324,11 @@ extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pit
     // 131072: two such workgroups per frame, one for the even and one for the odd bins
     if (!ctx->force_generic_fft && nfft == 131072 && !old_wg)
         return run_chip<true>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+    // 262144, 524288: a radix-4 / radix-8 step in front of the same transform, the residues that pair with each other in one task
+    if (!ctx->force_generic_fft && nfft == 262144 && !old_wg)
+        return run_chipx<4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+    if (!ctx->force_generic_fft && nfft == 524288 && !old_wg)
+        return run_chipx<8>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
     if (nfft > 8192)
         return run_big(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, nfft, hop, scale, out, db_out);
     size_t lds = sizeof(float2) * 2 * (size_t)nfft;

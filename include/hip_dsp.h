@@ -372,7 +372,7 @@ int hipdsp_chain_backward_plan(hipdsp_ctx *ctx, const hipdsp_sosplan *eplan, int
  * elements between consecutive channels (0 = compact, frames_out*(nfft/2 + 1)).
  * If db_out != NULL it additionally receives decibel(out) (fused epilogue,
  * specitem.py:36) in the same layout.  nfft: any power of two in [8, 524288] (the reference's
- * nfft selector, databrowser.py:516; 65536 in the registers of one workgroup, 131072 of two, above that a four-step FFT over the context scratch)
+ * nfft selector, databrowser.py:516; 65536 in the registers of one workgroup, 131072 of two, 262144 and 524288 as tasks of one or two passes of such a workgroup)
  * and, for the values the reference's clamp to len(source)//2 can produce, any other size up
  * to 131072 (direct DFT, O(nfft^2), meant for the rare short recording). */
 int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, int64_t channels,

@@ -354,7 +354,7 @@ def test_short_windows_stream_runs_of_frames_through_lds(oracle, nfft):
 
 
 @pytest.mark.parametrize('nfft,hop', [(64, 32), (256, 128), (256, 100), (512, 256), (1024, 256), (2048, 1024), (4096, 2048),
-                                      (8192, 4096), (16384, 8192), (65536, 32768), (131072, 65536)])
+                                      (8192, 4096), (16384, 8192), (65536, 32768), (131072, 65536), (262144, 131072), (524288, 262144)])
 def test_spectrogram_of_an_offset_plus_something_small(oracle, nfft, hop):
     """A trace that is a large offset plus a small signal -- raw data of the reference's default session (no filter,
     bufferedfilter.py:40-42) from a sensor with a DC offset, or a filter's decaying transient: detrend='constant'
@@ -390,7 +390,8 @@ def test_spectrogram_of_an_offset_plus_something_small(oracle, nfft, hop):
 
 
 @pytest.mark.parametrize('nfft,hop', [(64, 64), (256, 256), (256, 128), (512, 512), (1024, 1024), (2048, 2048), (2048, 1024),
-                                      (4096, 4096), (8192, 8192), (16384, 16384), (65536, 65536), (131072, 131072), (131072, 65536)])
+                                      (4096, 4096), (8192, 8192), (16384, 16384), (65536, 65536), (131072, 131072), (131072, 65536),
+                                      (262144, 262144), (524288, 262144)])
 def test_spectrogram_of_pulses_at_the_frame_borders(oracle, nfft, hop):
     """A pulse train -- a pulse-type electric fish, clicks -- over a quiet baseline, with the pulses on the frame borders:
     the first sample of a frame is a thousand times the rest of it, and the Hann window gives that sample weight zero, so
@@ -420,7 +421,7 @@ def test_spectrogram_of_pulses_at_the_frame_borders(oracle, nfft, hop):
         assert worst < TOL, (nfft, hop, amp, sigma, offset, worst)
 
 
-@pytest.mark.parametrize('nfft', [64, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072])
+@pytest.mark.parametrize('nfft', [64, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 524288])
 def test_spectrogram_after_a_step_in_the_level(oracle, nfft):
     """A trace whose level jumps by a thousand times its noise between two frames (stimulus artefacts, a DC-coupled
     amplifier): the frame after the jump is flat again, the differences to the mean of the frame before it are all the
@@ -730,7 +731,9 @@ def test_spectrogram_large_nfft_four_step(oracle, nfft, hop, nframes):
 
 
 @pytest.mark.parametrize('nfft,hop,nframes', [(65536, 32768, 9), (65536, 8192, 21), (65536, 1001, 37), (65536, 65536, 5),
-                                              (131072, 65536, 7), (131072, 16384, 11), (131072, 3001, 9), (131072, 131072, 3)])
+                                              (131072, 65536, 7), (131072, 16384, 11), (131072, 3001, 9), (131072, 131072, 3),
+                                              (262144, 131072, 5), (262144, 50001, 4), (524288, 262144, 4), (524288, 524288, 2),
+                                              (524288, 77777, 3)])
 def test_spectrogram_65536_with_the_frame_on_chip(oracle, nfft, hop, nframes):
     """nfft 65536 (spec_chip.h: the frame in the registers of a 512-thread workgroup, two exchanges through LDS) and 131072
     (two such workgroups per frame, even and odd bins, behind a radix-2 step of decimation in frequency) against the

@@ -13,6 +13,8 @@ reads stale data.  This script re-checks the generated ISA with a model of the h
     (all paths, loops included); an instruction that touches a register with a load in flight
     in ANY reachable state is reported.
 
+A second, straight-line rule covers the SGPR bases of inline-asm VMEM instructions (sgpr_hazards below).
+
 usage: python tools/check_prefetch_isa.py file.s [kernel-substring ...]
 """
 import re
@@ -204,11 +206,54 @@ def check(name, body):
     return n_loads, [(name, k, inst, regs) for (k, inst), regs in sorted(problems.items())]
 
 
+VALU_SGPR_WRITE = re.compile(r'^v_(readlane_b32|readfirstlane_b32)\s+s(\d+)\b')
+
+
+def sgpr_hazards(name, body):
+    """Second rule, straight-line: a VMEM instruction that reads an SGPR (its `saddr` pair) a VALU instruction has written
+    (v_readlane_b32 / v_readfirstlane_b32: an SGPR coming back from its spill slot) needs five wait states in between.
+    hipcc inserts them for its own instructions and cannot see into an inline-asm block: the asm has to carry its own
+    `s_nop 4` (spec_chipx.h took stale bases without it and faulted)."""
+    out = []
+    recent = []                                     # (wait states since, sgpr) of the latest VALU writes of SGPRs
+    in_asm = False
+    for l in body:
+        st = l.strip()
+        if st.startswith(';;#ASMSTART'):
+            in_asm = True
+            continue
+        if st.startswith(';;#ASMEND'):
+            in_asm = False
+            continue
+        t = l.split(';')[0].strip()
+        if not t or t.startswith('.') or t.endswith(':'):
+            if t.endswith(':'):
+                recent = []                         # (a label: what came before is another path's business)
+            continue
+        m = re.match(r'^s_nop\s+(\d+)', t)
+        states = int(m.group(1)) + 1 if m else 1
+        if in_asm and VMEM.match(t):
+            sm = re.search(r'\bs\[(\d+):(\d+)\]\s*$', t.split('offset')[0].strip())
+            if sm:
+                used = set(range(int(sm.group(1)), int(sm.group(2)) + 1))
+                for ws, reg in recent:
+                    if reg in used and ws < 5:
+                        out.append((name, 'sgpr', t, [reg, ws]))
+        recent = [(ws + states, reg) for ws, reg in recent if ws + states < 5]
+        w = VALU_SGPR_WRITE.match(t)
+        if w:
+            recent.append((0, int(w.group(2))))
+    return out
+
+
 def main():
     path = sys.argv[1]
     want = sys.argv[2:]
     lines = open(path).read().split('\n')
     total, bad, nk = 0, [], 0
+    for name, body in kernels(lines):
+        if not want or any(w in name for w in want):
+            bad += sgpr_hazards(name, body)
     todo = [(name, body) for name, body in kernels(lines) if not want or any(w in name for w in want)]
     # the kernels are independent: one worker process per core (155 kernels of the fused sweeps take minutes in one)
     import multiprocessing as mp

@@ -4,7 +4,7 @@ on gfx950 -- MI355X_MICROARCH.md -- + WRITE_SIZE, both in units of 1024 bytes) a
 import collections, csv, glob, os, sys
 root, sizes = sys.argv[1], [int(a) for a in sys.argv[2:]]
 C, T = 64, 120*96000
-DB_ARG = {'spec_chip_kernel': 0, 'spec_pack_kernel': -1, 'spec_wgs_kernel': -2, 'spec_fast_kernel': -2, 'spec_wg_kernel': -1}
+DB_ARG = {'spec_chipx_kernel': 0, 'spec_chip_kernel': 0, 'spec_pack_kernel': -1, 'spec_wgs_kernel': -2, 'spec_fast_kernel': -2, 'spec_wg_kernel': -1}
 
 
 def db_of(name):
