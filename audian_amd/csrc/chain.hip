@@ -4,758 +4,9 @@
 // of bendalab/audian (src/audian/bufferedfilter.py:31-36, bufferedspectrogram.py:45-59, bufferedenvelope.py:34-41)
 // recomputed depth-first by BufferedData.recompute_all (buffereddata.py:149-153).  The IIR role is sos.hip's
 // sos_ckpt_kernel walk (shared cascade body: sos_cascade.inc), the FFT role spectrogram.hip's arithmetic (fft_device.h).
-#include "sos_device.h"
-#include "fft_device.h"
-#include <cmath>
+#include "chain_fwd.h"
 
 namespace {
-
-// ---- forward sweep of the batch chain with the spectrogram fused in -------------------------
-// The filtered trace is the one array of the chain that is read twice (by the spectrogram and by
-// the envelope's backward sweep).  Here the forward sweep hands every finished tile to an FFT wave
-// of its own workgroup through LDS, so the spectrogram never reads it from HBM: 12 instead of
-// 16 B/sample for band-pass + envelope states + PSD.  nfft == TILE (2048), hop == TILE/2: tile t
-// IS frame 2t, and frame 2t-1 is the second half of tile t-1 followed by the first half of tile t.
-//
-// A workgroup is P IIR waves (exactly sos_ckpt_kernel<SF, SE, true>'s walk over one
-// (channel, segment) each) and P FFT waves, FFT wave p serving IIR wave p.  Two hand-overs per tile:
-//   H1  the tile holds the band-pass output      -> the FFT wave copies it into registers
-//   H2  the copy is done                         -> the IIR wave may rectify the tile in place
-// and between H2 and the next H1 the FFT wave computes its (at most) two frames while the IIR
-// wave finishes the tile (envelope state sweep) and brings in the next one.  FLAGS: the hand-overs
-// are two monotonic counters per pair in LDS (ready / taken, one writer each, bounded polling with
-// s_sleep), so a pair never waits for another pair; otherwise they are workgroup barriers, for which
-// all waves of the grid walk the same number of iterations (tile = lo - warm + k*TILE; a segment
-// without warm-up, or without the extra extension tile, idles through the others) -- the flag
-// variant keeps that iteration space.  Within a wave the single-wave kernels' __syncthreads()
-// become wave-local fences.
-struct ChainArgs {
-    CkptArgs c;
-    float *psd;               // (channels, frames_out, TILE/2 + 1)
-    float *db;                // optional: decibel(psd), same layout
-    long long psd_pitch;
-    long long n_valid;        // frames that lie inside the trace
-    long long tail_end;       // > n_valid: the FFT wave of a channel's last unit also writes the zero tail, frames
-                              // [n_valid, tail_end) (bufferedspectrogram.py:59) -- a few frames, not worth a launch of their own
-    const float *tables;      // tw2 | tw3 | twn | window of the 2048-point PSD kernel (fft_tables)
-    float scale;              // 1 / (fs * sum w^2)
-    int n_iter;
-    long long warm_total;     // band-pass + envelope warm-up samples
-    long long units;          // channels * n_seg
-    int debug;                // experiments: 1 = FFT waves only copy, 2 = IIR waves skip the cascades
-                              // (bit 4, host side: workgroup barriers instead of the pairwise flags;
-                              // bit 8: FFT wave 0 of workgroup 0 withholds one hand-over -- fault-path test)
-    int *fault;               // hipdsp_ctx::fault_dev: where a wave that gave up waiting says so
-    int split;                // frame split: only the even frames are written here, chain_bwd_kernel writes the odd ones
-    long long unit_stride;    // 0: unit = block * NP + pair; else unit = pair * unit_stride + block -- fewer units than the
-                              // chip has pairs are spread over all CUs, the pairs of a workgroup that get none idle
-    int frame_off;            // frame k of psd / db is frame k + frame_off of the sweep's grid (sos_device.h: GridShift)
-};
-
-// One frame of NFFT samples per group of LPF lanes (2048: LPF 64, radix 16 x 16 x 4; 1024: 64, 8 x 8 x 8; 512: two
-// frames side by side in a wave, LPF 32, 8 x 8 x 4) from its PPL = NFFT / (2 LPF) values per lane (value t: samples
-// 2l + 2 LPF t, + 1 of the frame) -> detrend, Hann, half-length complex FFT, split step, PSD.  `keep` masks the
-// stores of a lane group whose frame does not exist.  Same arithmetic as spec_fast_kernel<NFFT, LPF, R1, R2, R3, ...>.
-struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
-
-template <int NFFT, int LPF, int R1, int R2, int R3, bool DB, class Hook = NoHook>
-__device__ __forceinline__ void psd_frame(const v2f *w, float2 *fb, const float2 *tw2, const float2 *tw3,
-                                          const float2 *twn, const float2 *win, int lane, float scale, bool keep,
-                                          float *__restrict__ o, float *__restrict__ od, float &piv, bool &have_piv,
-                                          Hook hook = Hook())
-{
-#pragma clang fp contract(fast)
-    constexpr int M = NFFT / 2, PPL = M / LPF;
-    static_assert(PPL == R1 && R1 * R2 * R3 == M, "one first-stage butterfly per lane");
-    const int l = lane % LPF, g0 = (lane / LPF) * LPF;
-    float2 v[PPL];
-    v2f acc = {0.f, 0.f};
-    // The frame mean (detrend='constant') relative to a PIVOT: on an offset plus something small (a low-pass only in front
-    // of raw data with a DC offset, a decaying transient) a float32 sum of the samples carries 1e-7 of the OFFSET into
-    // bins 0 and 1, the sum of the differences to a value near the mean 1e-7 of the small part (tools/fuzz_stress.py seed
-    // 10268 was a frame of this sweep).  The pivot is the mean of the frame BEFORE this one in the wave's sequence (`piv`,
-    // carried by the caller; a lane group's own), whatever single samples do: a frame that starts on a pulse a thousand
-    // times its baseline -- pulse-type fish, clicks -- has that sample under a window weight of zero, and a pivot taken
-    // from it left 6e-8 of the PULSE times nfft / 2 in bins 0 and 1 (test_spectrogram_of_pulses_at_the_frame_borders).
-    // The first frame of a sequence takes two steps: a sample as the pivot of a rough mean, that mean as the pivot.
-    // Non-finite candidates (a NaN or Inf in the frame) leave the pivot as it was.
-    auto gsum = [&](float sum) {
-        if (LPF == 64) return wave_sum(sum);
-#pragma unroll
-        for (int d = LPF / 2; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
-        return sum;
-    };
-    if (!have_piv) {                            // (wave-uniform)
-        float p0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w[0].x)));
-        p0 = (fabsf(p0) <= 3.0e38f) ? p0 : 0.f;
-        const v2f p02 = {p0, p0};
-        v2f a0 = {0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < R1; t++) a0 += w[t] - p02;
-        const float c = p0 + gsum(a0.x + a0.y) * (1.0f / (float)NFFT);
-        piv = (fabsf(c) <= 3.0e38f) ? c : p0;
-        have_piv = true;
-    }
-    const v2f pivot2 = {piv, piv};
-#pragma unroll
-    for (int t = 0; t < R1; t++) {
-        const v2f d = w[t] - pivot2;
-        v[t] = make_float2(d.x, d.y);
-        acc += d;
-    }
-    const float mean = gsum(acc.x + acc.y) * (1.0f / (float)NFFT);
-    {
-        const float c = piv + mean;
-        piv = (fabsf(c) <= 3.0e38f) ? c : piv;
-    }
-    const v2f mean2 = {mean, mean};
-    // What the subtraction leaves: after a step in the level the differences to the mean of the frame before are all large,
-    // `mean` is good to 6e-8 of THEM, and the Hann window puts that error times nfft / 2 into bins 0 and 1.  The detrended
-    // samples are summed once more; their mean m1 under the periodic Hann window is m1 nfft / 2 in bin 0, -m1 nfft / 4 in bin
-    // 1 and nothing elsewhere, and the split step takes it out (spec_wgs.h, spec_pack.h and spec_fast_kernel do the same).
-    v2f rest = {0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < R1; t++) {
-        const v2f q = as_v2f(v[t]) - mean2;
-        rest += q;
-        v[t] = as_f2(q * as_v2f(win[l + LPF * t]));
-    }
-    const float corr = 0.5f * gsum(rest.x + rest.y);
-    hook(0);                                   // mean and window
-    stockham_stage<R1, 1, M, LPF, false, true>(v, fb, tw2, l);
-    hook(1);                                   // first butterflies, values on their way through LDS
-    stockham_stage<R2, R1, M, LPF, true, true>(v, fb, tw2, l);
-    hook(2);
-    stockham_stage<R3, R1 * R2, M, LPF, true, false, true>(v, fb, tw3, l);
-    hook(3);
-    // v[u*R3 + t] = Z[k], k = l + LPF*m, m = u + NB3*t; partner bin Z[M-k] from lane LPF-l of the same group
-    constexpr int NB3 = PPL / R3;
-    const int partner = g0 + ((LPF - l) & (LPF - 1));
-    float pk_last = 0.f;
-    const v2f hscale2 = {0.5f * scale, 0.5f * scale};
-#pragma unroll
-    for (int m = 0; m < PPL / 2; m++) {
-        const int k = l + LPF * m;
-        const float2 zk = v[(m % NB3) * R3 + m / NB3];
-        const int mp = PPL - 1 - m;
-        const float2 zsrc = v[(mp % NB3) * R3 + mp / NB3];
-        float2 zm;
-        zm.x = __shfl(zsrc.x, partner, 64);
-        zm.y = __shfl(zsrc.y, partner, 64);
-        if (m > 0) {
-            const int m0 = PPL - m;
-            const float2 z0 = v[(m0 % NB3) * R3 + m0 / NB3];
-            zm = (l == 0) ? z0 : zm;
-        }
-        const v2f e = pk_add_conj(as_v2f(zk), as_v2f(zm));
-        const v2f t = pk_cmul_negi(pk_sub_conj(as_v2f(zk), as_v2f(zm)), as_v2f(twn[k]));
-        v2f re = pk_sumdiff_x(e, t);
-        const v2f im = pk_sumdiff_y(e, t);
-        if (m == 0) re.x += (l == 1) ? corr : 0.f;                    // bin 1 (`re` is twice its real part)
-        const v2f pw = (re * re + im * im) * hscale2;
-        float pk = pw.x, pm = pw.y;
-        if (m == 0) {
-            const float dc0 = zk.x + zk.y - corr, ny = zk.x - zk.y;
-            pk = (l == 0) ? dc0 * dc0 * scale : pk;
-            pm = (l == 0) ? ny * ny * scale : pm;
-        }
-        if (LPF == 64 || keep) {
-            o[k] = pk;
-            o[M - k] = pm;
-            if (DB) { od[k] = to_db(pk); od[M - k] = to_db(pm); }
-        }
-        pk_last = pk;
-    }
-    {
-        constexpr int mh = PPL / 2;
-        const float2 z = v[(mh % NB3) * R3 + mh / NB3];
-        const float ph = 2.f * scale * (z.x * z.x + z.y * z.y);
-        const int kk = (l == 0) ? M / 2 : l + LPF * (PPL / 2 - 1);
-        const float pv = (l == 0) ? ph : pk_last;
-        if (LPF == 64 || keep) {
-            o[kk] = pv;
-            if (DB) od[kk] = to_db(pv);
-        }
-    }
-}
-
-// STAMP (diagnostic build, "chain_debug" bit 32; results stay valid): every wave adds up the shader clocks
-// it spends in each part of its loop body and leaves the 16 sums in a.db (which then is NOT a dB output).
-#define FPT_OK(hop, g) ((2048 / (hop)) % (g) == 0)
-// NFFT / HOP: the window lengths whose frames are register windows of a tile -- 2048 or 1024 samples, hops
-// that divide the tile and are multiples of 128 samples (one register of the FFT wave's tile copy).
-template <int SF, int SE, int NP, bool FLAGS, bool DB, int NFFT = 2048, int HOP = 1024, bool STAMP = false>
-__global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPlanDev *__restrict__ PF0,
-                                                                   const SosPlanDev *__restrict__ PE0, ChainArgs a)
-{
-    // SE == 0: no envelope behind the filter (the reference's default trace set, plugins.py:11-13: filter + spectrogram)
-    static_assert(SF > 0 && SE >= 0 && NP % 2 == 0, "band-pass in front; whole waves per SIMD");
-    constexpr int DF = 2 * SF, DE = SE > 0 ? 2 * SE : 1;
-    static_assert((NFFT == 2048 || NFFT == 1024 || NFFT == 512 || NFFT == 256) && TILE % HOP == 0 && HOP % 128 == 0 &&
-                  HOP <= NFFT && NFFT <= TILE, "frames must be register windows of a tile");
-    static_assert(NFFT != 256 || HOP == 128, "256-sample frames: the reference's default, 50 % overlap");
-    constexpr int M = NFFT / 2, F = M + 1, MP = M + M / 16;
-    constexpr int LPF = NFFT >= 1024 ? 64 : (NFFT == 512 ? 32 : 16);  // lanes per frame; G frames side by side in an FFT wave
-    constexpr int G = 64 / LPF;
-    constexpr int R1 = NFFT == 2048 ? 16 : 8, R2 = NFFT == 256 ? 4 : R1, R3 = NFFT == 1024 ? 8 : 4;
-    constexpr int TW2 = (R2 - 1) * R1, TW3 = R1 * R2, TWN = M / 2 + 1, NTAB = TW2 + TW3 + TWN + M;
-    constexpr int PPL = NFFT / 128;             // registers (128 samples each) of one frame
-    static_assert(FPT_OK(HOP, G), "whole groups of frames per tile");
-    constexpr int FPT = TILE / HOP;             // frames that END inside a tile (a multiple of G)
-    constexpr int PREV = (NFFT - HOP) / 128;    // registers of the previous tile a frame can reach back into
-    __shared__ float4 tiles[NP][64 * 8];
-    __shared__ float rprevs[NP][64];
-    __shared__ float2 fbs[NP][G * MP];
-    __shared__ float2 tab[NTAB];
-    // FLAGS: pairwise hand-over instead of the two workgroup barriers -- ready[p] counts the tiles IIR
-    // wave p has finished, taken[p] the tiles FFT wave p has copied (monotonic, one writer each)
-    __shared__ int ready[NP], taken[NP];
-    // Fair shares of a SIMD: the issue arbiter prefers the waves of the lower slots, so that without help
-    // pairs 0 .. NP/2-1 finish their units after 78 % of the launch and the other half then runs alone,
-    // latency-bound, on a half-empty CU (tools/chain_stamps.py: wave lifetimes 14.8 M against 19.0 M clocks).
-    // Every wave publishes the iteration it is in and compares it with the wave of the same role of pair
-    // p ^ NP/2 -- the one it shares its SIMD with: whoever is ahead steps down one priority level until the
-    // other has caught up ("chain_debug" bit 128 = off).
-    __shared__ int prog[2 * NP];
-    if (threadIdx.x < NP) { ready[threadIdx.x] = 0; taken[threadIdx.x] = 0; }
-    if (threadIdx.x < 2 * NP) prog[threadIdx.x] = 0;
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int pair = wave < NP ? wave : wave - NP;
-#define CHAIN_FAIR(iter, behind_prio, ahead_prio)                                                        \
-    do {                                                                                                 \
-        if (FLAGS && !(a.debug & 128)) {                                                                 \
-            if (lane == 0) __hip_atomic_store(&prog[wave], (iter), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-            const int other_ = __builtin_amdgcn_readfirstlane(                                           \
-                __hip_atomic_load(&prog[wave ^ (NP / 2)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); \
-            set_issue_priority(other_ < (iter) ? (ahead_prio) : (behind_prio));                          \
-        }                                                                                                \
-    } while (0)
-    // Bounded polling: a logic error must not hang the GPU.  After 2^23 naps (a third of a second, far
-    // beyond anything a partner wave of the same workgroup can be late by) the wave GIVES UP: it
-    // reports the fault through the context's fault word (the host turns it into HIPDSP_ERR_HIP at the
-    // next synchronisation), raises the workgroup's abort word so that its partner stops waiting too,
-    // and walks the rest of its iterations without waiting for anything -- the launch ends quickly
-    // and its outputs are declared invalid, instead of being silently wrong.
-    // Macros, not lambdas: through a pointer parameter the flags would be accessed with flat
-    // instructions, whose wait also drains the prefetch of the IIR role.
-    __shared__ int abort_wg;
-    if (threadIdx.x == 0) abort_wg = 0;
-    bool gave_up = false;
-#define CHAIN_WAIT_FOR(arr, want, iter)                                             \
-    do {                                                                            \
-        if (!gave_up) {                                                             \
-            for (int spin_ = 0;; spin_++) {                                         \
-                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&arr[pair], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= (want)) break; \
-                if ((spin_ & 1023) == 1023) {                                       \
-                    const bool told = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&abort_wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0; \
-                    if (told || spin_ >= (1 << 23) - 1) {                           \
-                        gave_up = true;                                             \
-                        if (!told && lane == 0) {                                   \
-                            __hip_atomic_store(&abort_wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-                            a.fault[1] = (int)blockIdx.x; a.fault[2] = pair; a.fault[3] = (iter); \
-                            __hip_atomic_store(&a.fault[0], HD_FAULT_CHAIN_HANDOVER, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); \
-                        }                                                           \
-                        break;                                                      \
-                    }                                                               \
-                }                                                                   \
-                __builtin_amdgcn_s_sleep(1);                                        \
-            }                                                                       \
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");        \
-        }                                                                           \
-    } while (0)
-#define CHAIN_POST(arr, value)                                                      \
-    do {                                                                            \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");            \
-        if (lane == 0) __hip_atomic_store(&arr[pair], (value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-    } while (0)
-    {
-        const float2 *src = reinterpret_cast<const float2 *>(a.tables);
-        for (int i = tid; i < NTAB; i += 128 * NP) tab[i] = src[i];
-    }
-    __syncthreads();
-
-    const long long unit = a.unit_stride ? (long long)pair * a.unit_stride + blockIdx.x : (long long)blockIdx.x * NP + pair;
-    const bool unit_ok = unit < a.units;
-    const int seg = unit_ok ? (int)(unit % a.c.n_seg) : 0;
-    const long long ch = unit_ok ? unit / a.c.n_seg : 0;
-    const long long T = a.c.T;
-    const int edge = a.c.edge;
-    const long long lo = (long long)seg * a.c.seg_len;
-    long long hi = lo + a.c.seg_len;
-    const bool last_seg = hi >= T;
-    if (hi > T) hi = T;
-    // no envelope warm-up: zero-state tile states + env_fix_kernel, exactly as in sos_ckpt_kernel.  The envelope
-    // starts at p' = env0 (sos_device.h: GridShift): the unit whose range holds that tile starts it from the true
-    // state there, units in front of it have no envelope work, units behind it start from zero state at `lo`.
-    const long long lead = a.c.lead;
-    const long long env_tile0 = a.c.env0 - a.c.env0 % TILE;
-    const bool env_true = lo <= env_tile0 && env_tile0 < hi;
-    const long long env_start = env_true ? env_tile0 : (lo > env_tile0 ? lo : (1LL << 62));
-    long long start = lo - PF0->warm;
-    if (start < 0) start = 0;
-    long long loop_end = last_seg ? T + edge : hi;
-    if (!unit_ok) loop_end = start;                     // a pair without a unit only takes the barriers
-    const long long base = lo - a.warm_total;           // tile of iteration 0 (negative: idle iterations)
-
-    // "chain_debug" bit 16: IIR wave 0 of workgroup 0 reports shader clocks and 100 MHz ticks spent in
-    // the kernel into the first 16 bytes of the PSD (measurement of the engine clock under this load)
-    const long long dbg_c0 = (a.debug & 16) ? clock64() : 0, dbg_w0 = (a.debug & 16) ? wall_clock64() : 0;
-    long long st_acc[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) st_acc[i] = 0;
-    long long st_last = STAMP ? clock64() : 0;
-#define STAMP_AT(i)                                              \
-    do {                                                         \
-        if (STAMP) {                                             \
-            const long long t_ = clock64();                      \
-            st_acc[(i)] += t_ - st_last;                         \
-            st_last = t_;                                        \
-        }                                                        \
-    } while (0)
-    if (wave < NP) {
-        // ================= IIR role: sos_ckpt_kernel<SF, SE, true> with the barriers added ==========
-        float4 *lds = tiles[pair];
-        float *ldsf = reinterpret_cast<float *>(lds);
-        float *rprev = rprevs[pair];
-        const float *in = a.c.in + ch * a.c.in_pitch;
-        float *yf = a.c.yf + ch * a.c.yf_pitch;
-        double *ckpt = SE > 0 ? a.c.ckpt + ch * a.c.ckpt_pitch : nullptr;
-        double cf_[DF], ce_[DE];
-#pragma unroll
-        for (int r = 0; r < DF; r++) cf_[r] = 0.0;
-#pragma unroll
-        for (int r = 0; r < DE; r++) ce_[r] = 0.0;
-        rprev[lane] = 0.f;
-        v4f nx[8];
-        bool pre = false;
-        int pending = 0;
-        const long long top_full = (T / TILE - 1) * TILE;            // host guarantees >= 0
-        auto fetch = [&](long long t0) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) nx[k] = asm_load16(in + t0 + 256 * k + 4 * lane);
-        };
-        // what iteration k + 1 will read: its tile if that is a full tile of this unit, else a dummy
-        auto prefetchable = [&](long long t0) { return t0 >= start && t0 < loop_end && t0 + TILE <= T && t0 >= lead; };
-        pre = prefetchable(base);
-        fetch(pre ? base : top_full);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-        for (int it = 0; it < a.n_iter; it++) {
-            const long long tile = base + (long long)it * TILE;
-            const bool active = tile >= start && tile < loop_end;
-            if (!(a.debug & 64)) CHAIN_FAIR(it, 1, 0);
-            if (FLAGS && pending) {                            // H2 of the previous (quiet) tile
-                CHAIN_WAIT_FOR(taken, pending, it);
-                pending = 0;
-            }
-            if (active) {
-                if (pre) {
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        asm volatile("" : "+v"(nx[k]));
-                        lds[lds_slot(8 * k + (lane >> 3), lane & 7)] = make_float4(nx[k].x, nx[k].y, nx[k].z, nx[k].w);
-                    }
-                } else {
-                    // a tile that reaches past T (or holds the `lead` samples in front of the trace): untracked loads
-                    // from clamped addresses, zeros outside [lead, T)
-#pragma unroll 1
-                    for (int k = 0; k < 8; k++) {
-                        const long long p = tile + 256 * k + 4 * lane;
-                        auto at = [&](long long q) { return in + (q < lead ? lead : (q < T ? q : T - 1)); };
-                        auto ok = [&](long long q) { return q >= lead && q < T; };
-                        v4f t;
-                        t.x = asm_load4(at(p));
-                        t.y = asm_load4(at(p + 1));
-                        t.z = asm_load4(at(p + 2));
-                        t.w = asm_load4(at(p + 3));
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        asm volatile("" : "+v"(t));
-                        lds[lds_slot(8 * k + (lane >> 3), lane & 7)] =
-                            make_float4(ok(p) ? t.x : 0.f, ok(p + 1) ? t.y : 0.f, ok(p + 2) ? t.z : 0.f, ok(p + 3) ? t.w : 0.f);
-                    }
-                }
-            }
-            WAVE_SYNC();
-            // unconditional, like in sos_ckpt_kernel (a conditional fetch would turn `nx` into a phi
-            // whose copies read registers with loads in flight)
-            {
-                const long long next = tile + TILE;
-                pre = prefetchable(next);
-                fetch(pre ? next : top_full);
-            }
-            STAMP_AT(0);                                       // wait for H2 of the last tile, tile -> LDS, fetch issued
-            // Phase 1 of the envelope cascade rides on phase 3 of the band-pass: every filtered sample is
-            // multiplied into the envelope's G table while it is still a register -- |y| as a source modifier of
-            // the float64 multiply-add, the gain once per tile on the sums -- so that a quiet tile needs neither a
-            // pass over the tile in LDS nor a conversion or a multiplication per sample.  The value is the
-            // band-pass output AFTER its rounding to float32, converted back: the filtered trace in HBM is what the
-            // backward sweep recomputes the forward cascade from, so states and recomputation see the same input
-            // (ADVICE round 2).  Tiles that are not quiet (odd extension in reach) ignore the result and take the
-            // path through LDS.
-            double etap[DE];
-#pragma unroll
-            for (int r = 0; r < DE; r++) etap[r] = 0.0;
-            if (active && !(a.debug & 2)) {
-                const double tgain = a.c.gain;
-                const SosPlanDev *PEt = PLAN_OF(SE > 0 ? PE0 : PF0);
-#define CASC_S SF
-#define CASC_PLAN() PLAN_OF(PF0)
-#define CASC_CARRY cf_
-#define CASC_IN(v) (v)
-#define CASC_ROLLED_GROUPS
-#define CASC_STAMP(n) STAMP_AT(1 + (n))
-#define CASC_TAP(j, e, y)                                                               \
-    do {                                                                                \
-        if constexpr (SE > 0) {                                                         \
-            if (((j) & 3) == 0) PEt = PLAN_OF(PE0);                                     \
-            const double rd_ = fabs((double)(e));                                        \
-            _Pragma("unroll") for (int r_ = 0; r_ < DE; r_++) etap[r_] = fma(PEt->G[(j) * DE + r_], rd_, etap[r_]); \
-        }                                                                               \
-    } while (0)
-#include "sos_cascade.inc"
-#undef CASC_TAP
-#undef CASC_STAMP
-#undef CASC_ROLLED_GROUPS
-#undef CASC_S
-#undef CASC_PLAN
-#undef CASC_CARRY
-#undef CASC_IN
-#pragma unroll
-                for (int r = 0; r < DE; r++) etap[r] *= tgain;
-            }
-            WAVE_SYNC();
-            if (FLAGS) { if (active) CHAIN_POST(ready, it + 1); }
-            else __syncthreads();                              // B1: the tile holds the filtered samples
-            if (active && tile >= lo && tile + TILE <= hi && tile >= lead) {
-                // interior tile: exactly 8 vector stores, then the counted wait
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const float4 v = lds[lds_slot(8 * k + (lane >> 3), lane & 7)];
-                    f4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
-                    *reinterpret_cast<f4u *>(yf + tile + 256 * k + 4 * lane) = t;
-                }
-                asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-                STAMP_AT(4);                                   // H1, 8 stores of the filtered tile, wait for the prefetch
-            } else {
-                // border tile of the segment, warm-up or idle: whatever is stored, no stores to count
-                if (active && tile + TILE > lo && tile < hi) {
-#pragma unroll
-                    for (int k = 0; k < 8; k++)
-                        store_four(yf, tile + 256 * k + 4 * lane, lds[lds_slot(8 * k + (lane >> 3), lane & 7)],
-                                   lo > lead ? lo : lead, hi, 0);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            // An interior tile of the envelope sweep (neither it nor the next one touches T, no left
-            // extension) is not modified any more: the rectification rides on the cascade's input
-            // and, with the flags, H2 is only needed before the NEXT tile goes into LDS.
-            // (the last tile of a segment that is not the trace's last advances the state too: its end state is handed
-            // to the next segment by env_fix_kernel)
-            const bool last_tile = tile + TILE >= loop_end;
-            const bool quiet = SE > 0 && active && tile >= env_start && a.c.rectify && tile + 2 * TILE <= T &&
-                               !(env_true && tile == env_start) && (!last_tile || !last_seg) && !(a.debug & 2);
-            if (FLAGS) {
-                if (active) {
-                    if (quiet || SE == 0 || tile < env_start) pending = it + 1;   // (nothing touches the tile before the next one)
-                    else CHAIN_WAIT_FOR(taken, it + 1, it);
-                }
-            } else {
-                __syncthreads();                               // B2: the FFT wave has its copy
-            }
-            if constexpr (SE > 0) {
-            if (quiet) {
-                if ((tile > lo || env_true) && lane == 0) {     // (quiet: never the envelope's first tile)
-#pragma unroll
-                    for (int r = 0; r < DE; r++) ckpt[(tile / TILE) * DE + r] = ce_[r];
-                }
-#define CASC_S SE
-#define CASC_PLAN() PLAN_OF(PE0)
-#define CASC_CARRY ce_
-#define CASC_IN(v) (v)
-#define CASC_F_IN etap
-#define CASC_NO_OUTPUT
-#define CASC_ROLLED_GROUPS
-#define CASC_STAMP(n) STAMP_AT(5 + (n))
-#include "sos_cascade.inc"
-#undef CASC_STAMP
-#undef CASC_ROLLED_GROUPS
-#undef CASC_NO_OUTPUT
-#undef CASC_F_IN
-#undef CASC_S
-#undef CASC_PLAN
-#undef CASC_CARRY
-#undef CASC_IN
-                if (last_tile && lane == 0) {
-#pragma unroll
-                    for (int r = 0; r < DE; r++) ckpt[(tile / TILE + 1) * DE + r] = ce_[r];
-                }
-                WAVE_SYNC();
-            } else if (active && tile >= env_start && !(a.debug & 2)) {
-                // ---- envelope input in place: r = |y| (the gain rides on the cascade), then the odd extension past T
-                if (a.c.rectify) {
-#pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        float4 v = lds[lds_slot(lane, q)];
-                        v = make_float4(fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w));
-                        lds[lds_slot(lane, q)] = v;
-                    }
-                }
-                WAVE_SYNC();
-                auto rval = [&](long long j) -> float {
-                    return j >= tile ? ldsf[lds_float_index((int)(j - tile))] : rprev[64 - (int)(tile - j)];
-                };
-                if (tile + TILE > T) {
-                    float pv = 0.f;
-                    long long pj = -1;
-                    if (lane < edge) {
-                        pj = T + lane;
-                        if (pj >= tile && pj < tile + TILE) pv = 2.f * rval(T - 1) - rval(T - 2 - lane);
-                    }
-                    WAVE_SYNC();
-                    if (lane < edge && pj >= tile && pj < tile + TILE) ldsf[lds_float_index((int)(pj - tile))] = pv;
-                    WAVE_SYNC();
-                }
-                if (env_true && tile == env_start && a.c.env0 > 0) {
-                    // the envelope starts inside this tile, at q = env0 - tile (host: edge <= q < TILE - edge): scipy's
-                    // left odd extension ext[i] = 2 r(q) - r(q + edge - i), i < edge, goes into the edge samples in
-                    // front of q, and everything in front of THAT becomes ext[0] -- a constant input for which
-                    // zi * ext[0], the state sosfiltfilt starts from, is the cascade's steady state: the tile is then
-                    // scanned like any other and the state arrives at q as if the cascade had started at q - edge.
-                    // The backward sweep rebuilds exactly this tile from the filtered trace (env_left_fill).
-                    const SosPlanDev *Pz = PLAN_OF(PE0);
-                    const float e0 = env_left_fill(ldsf, lane, (int)(a.c.env0 - tile), edge);
-                    const double x0 = a.c.gain * (double)e0;
-#pragma unroll
-                    for (int r = 0; r < DE; r++) ce_[r] = Pz->zi[r] * x0;
-                } else if (env_true && tile == env_start) {
-                    const SosPlanDev *Pz = PLAN_OF(PE0);
-                    const double r0 = (double)ldsf[lds_float_index(0)];
-                    const double x0 = a.c.gain * (2.0 * r0 - (double)ldsf[lds_float_index(edge)]);
-#pragma unroll
-                    for (int r = 0; r < DE; r++) ce_[r] = Pz->zi[r] * x0;
-                    for (int i = 0; i < edge; i++) {
-                        double cur = a.c.gain * (2.0 * r0 - (double)ldsf[lds_float_index(edge - i)]);
-#pragma unroll
-                        for (int s2 = 0; s2 < SE; s2++) {
-                            const double y = fma(Pz->coef[s2][0], cur, ce_[2 * s2]);
-                            ce_[2 * s2] = fma(-Pz->coef[s2][3], y, fma(Pz->coef[s2][1], cur, ce_[2 * s2 + 1]));
-                            ce_[2 * s2 + 1] = fma(-Pz->coef[s2][4], y, Pz->coef[s2][2] * cur);
-                            cur = y;
-                        }
-                    }
-                }
-                if ((tile > lo || env_true) && lane == 0) {
-#pragma unroll
-                    for (int r = 0; r < DE; r++) ckpt[(tile / TILE) * DE + r] = ce_[r];
-                }
-                {   // (the trace's very last tile advances the state too: slot n_tiles, see sos_device.h: FloodArgs)
-                    {
-                        const float4 keep0 = lds[lds_slot(62 + ((lane >> 3) & 1), lane & 7)];
-                        WAVE_SYNC();
-                        if (lane < 16) {
-                            rprev[4 * lane] = keep0.x; rprev[4 * lane + 1] = keep0.y;
-                            rprev[4 * lane + 2] = keep0.z; rprev[4 * lane + 3] = keep0.w;
-                        }
-                    }
-#define CASC_S SE
-#define CASC_PLAN() PLAN_OF(PE0)
-#define CASC_CARRY ce_
-#define CASC_IN(v) (v)
-#define CASC_GAIN a.c.gain
-#define CASC_NO_OUTPUT
-#define CASC_ROLLED_GROUPS
-#include "sos_cascade.inc"
-#undef CASC_ROLLED_GROUPS
-#undef CASC_NO_OUTPUT
-#undef CASC_GAIN
-#undef CASC_S
-#undef CASC_PLAN
-#undef CASC_CARRY
-#undef CASC_IN
-                    if (last_tile && lane == 0) {
-#pragma unroll
-                        for (int r = 0; r < DE; r++) ckpt[(tile / TILE + 1) * DE + r] = ce_[r];
-                    }
-                }
-                WAVE_SYNC();
-            }
-            }   // SE > 0
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last (dummy) prefetch
-        if (unit_ok && a.c.flags != nullptr && lane == 0) a.c.flags[unit] = state_not_finite(cf_) ? 1 : 0;   // FloodArgs
-        STAMP_AT(7);
-        if ((a.debug & 16) && blockIdx.x == 0 && wave == 0 && lane == 0) {
-            long long *dbg = reinterpret_cast<long long *>(a.psd);
-            dbg[0] = clock64() - dbg_c0;
-            dbg[1] = wall_clock64() - dbg_w0;
-        }
-    } else {
-        // ================= FFT role ===================================================================
-        // The FFT wave is the critical path of its pair (tools/chain_stamps.py: 94 % of its clocks inside the two
-        // FFTs of a tile, while the IIR wave waits 44 % of its own for the hand-over): it asks for the SIMD's
-        // issue slots first, the IIR waves fill the gaps (-2.2 % for the launch; "chain_debug" bit 64 = off)
-        if (!(a.debug & 64)) __builtin_amdgcn_s_setprio(3);
-        float2 *fb = fbs[pair];
-        const float *tlf = reinterpret_cast<const float *>(tiles[pair]);
-        const float2 *tw2 = tab, *tw3 = tab + TW2, *twn = tab + TW2 + TW3, *win = tab + TW2 + TW3 + TWN;
-        float *oc = a.psd + ch * a.psd_pitch;
-        float *dc = DB ? a.db + ch * a.psd_pitch : nullptr;
-        // the tile as 16 registers (register j: samples 128 j + 2 lane, + 1) and the last PREV registers of the
-        // tile before it: frame m of a tile (the one that ends (m + 1) HOP samples into it) is the window of
-        // PPL consecutive registers that starts at register ((m + 1) HOP - NFFT) / 128 of the two
-        v2f cur_[16], prv_[PREV > 0 ? PREV : 1];
-#pragma unroll
-        for (int j = 0; j < 16; j++) cur_[j] = (v2f){0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < (PREV > 0 ? PREV : 1); j++) prv_[j] = (v2f){0.f, 0.f};
-        // G == 4 (256-sample frames, 16 lanes each): frame m of a tile is the two 128-sample blocks m - 1 and m.
-        // Lane group g takes the four frames m = 4 g + q, q < 4, and keeps THEIR five blocks 4 g - 1 .. 4 g + 3 in its
-        // own lanes -- block b as four values per lane (sample pairs l + 16 t, t < 4: the first-stage inputs of the
-        // 16-lane FFT), bb_[4 j + t] = block 4 g - 1 + j: no cross-lane move anywhere, 24 instead of 16 LDS loads
-        // per tile (a group's first block is its neighbour's last); pv_ carries block 15 into the next tile for
-        // group 0, whose block -1 it is.
-        v2f bb_[G == 4 ? 20 : 1], pv_[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) pv_[j] = (v2f){0.f, 0.f};
-        bool have_prev = false;
-        float piv = 0.f;                                       // psd_frame's pivot: the mean of the frame before (per lane group)
-        bool have_piv = false;
-        for (int it = 0; it < a.n_iter; it++) {
-            const long long tile = base + (long long)it * TILE;
-            const bool active = tile >= start && tile < loop_end;
-            // (which role stands above the other no longer matters once equals keep pace: IIR above FFT 10.95 ms,
-            // both on the same two levels 10.83 ms, FFT above IIR 10.85 ms in one process)
-            if (!(a.debug & 64)) CHAIN_FAIR(it, 3, 2);
-            if (FLAGS) { if (active) CHAIN_WAIT_FOR(ready, it + 1, it); }
-            else __syncthreads();                              // B1
-            STAMP_AT(8);                                       // waited for the IIR wave's tile
-            v2f pvn_[4];
-            if (active) {
-                if constexpr (G == 4) {
-                    const int gq = lane >> 4, l16 = lane & 15;
-#pragma unroll
-                    for (int j = 0; j < 5; j++)
-#pragma unroll
-                        for (int tt = 0; tt < 4; tt++) {
-                            const int b = 4 * gq - 1 + j;              // (-1: the block the last tile left in pv_)
-                            const v2f h = *reinterpret_cast<const v2f *>(tlf + lds_float_index(128 * (b < 0 ? 0 : b) + 2 * (l16 + 16 * tt)));
-                            bb_[4 * j + tt] = (j == 0 && b < 0) ? pv_[tt] : h;
-                        }
-#pragma unroll
-                    for (int tt = 0; tt < 4; tt++)
-                        pvn_[tt] = *reinterpret_cast<const v2f *>(tlf + lds_float_index(128 * 15 + 2 * (l16 + 16 * tt)));
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 16; j++)
-                        cur_[j] = *reinterpret_cast<const v2f *>(tlf + lds_float_index(2 * lane + 128 * j));
-                }
-            }
-            if (FLAGS) {                                        // (the release fence waits for the loads)
-                // "chain_debug" bit 8 (fault-path test): FFT wave 0 of workgroup 0 withholds the hand-over of
-                // its unit's first tile, so that IIR wave 0 runs into the timeout
-                const bool withhold = (a.debug & 8) && blockIdx.x == 0 && pair == 0 && tile == start;
-                if (active && !withhold) CHAIN_POST(taken, it + 1);
-            }
-            else __syncthreads();                              // B2
-            STAMP_AT(9);                                       // tile copied, hand-over posted
-            if (active) {
-                const long long t = tile / TILE;
-                if (tile >= lo && tile < hi) {                 // the unit that owns the tile writes its frames
-                  if (!(a.debug & 1)) {
-                   if constexpr (G == 4) {
-                    const int gq = lane >> 4;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        // lane group gq: frame m = 4 gq + q of the tile = its blocks q and q + 1
-                        const long long f = t * FPT + 4 * gq + q + 1 - NFFT / HOP - a.frame_off;
-                        const bool keep = (4 * gq + q > 0 || have_prev) && f >= 0 && f < a.n_valid;
-                        if (__builtin_amdgcn_ballot_w64(keep) != 0) {               // (wave-uniform: some group has a frame)
-                            v2f w[8];
-#pragma unroll
-                            for (int i = 0; i < 8; i++) w[i] = bb_[4 * q + i];
-                            const long long fc = keep ? f : 0;                      // a masked group still needs a legal address
-                            psd_frame<NFFT, LPF, R1, R2, R3, DB>(w, fb + gq * MP, tw2, tw3, twn, win, lane, a.scale, keep,
-                                                                 oc + fc * (long long)F, dc + fc * (long long)F, piv, have_piv);
-                        }
-                    }
-                   } else {
-#pragma unroll
-                    for (int m = 0; m < FPT; m += G) {
-                        const int j0 = ((m + 1) * HOP - NFFT) / 128;          // compile-time after unrolling
-                        auto reg = [&](int j) -> v2f { return j < 0 ? prv_[(PREV + j) < 0 ? 0 : (PREV + j)] : cur_[j < 0 ? 0 : j]; };
-                        if constexpr (G == 1) {
-                            const long long f = t * FPT + m + 1 - NFFT / HOP - a.frame_off;
-                            if ((j0 >= 0 || have_prev) && f >= 0 && f < a.n_valid && !(a.split && (f & 1))) {
-                                v2f w[PPL];
-#pragma unroll
-                                for (int i = 0; i < PPL; i++) w[i] = reg(j0 + i);
-                                if (STAMP) {
-                                    STAMP_AT(10);                  // (between the frames)
-                                    auto hook = [&](int n) { STAMP_AT(11 + n); };
-                                    psd_frame<NFFT, LPF, R1, R2, R3, DB>(w, fb, tw2, tw3, twn, win, lane, a.scale, true,
-                                                                         oc + f * (long long)F, dc + f * (long long)F, piv, have_piv, hook);
-                                    STAMP_AT(15);                  // split step, PSD, stores
-                                } else {
-                                    psd_frame<NFFT, LPF, R1, R2, R3, DB>(w, fb, tw2, tw3, twn, win, lane, a.scale, true,
-                                                                         oc + f * (long long)F, dc + f * (long long)F, piv, have_piv);
-                                }
-                            }
-                        } else {
-                            // two frames side by side: lanes 0-31 take frame m, lanes 32-63 frame m + 1 (HOP / 128 registers
-                            // further on).  Value t of a lane is samples 2l + 64 t of ITS frame, i.e. register t / 2 of that
-                            // frame, lower (t even) or upper (t odd) half of the wave: v_permlane32_swap of the two frames'
-                            // registers gives {X.lo | Y.lo} and {X.hi | Y.hi} in one instruction per dword.
-                            const int gq = lane / LPF;
-                            const long long f = t * FPT + m + gq + 1 - NFFT / HOP - a.frame_off;
-                            const bool ok0 = (j0 >= 0 || have_prev), ok1 = (j0 + HOP / 128 >= 0 || have_prev);
-                            const bool keep = (gq == 0 ? ok0 : ok1) && f >= 0 && f < a.n_valid;
-                            const long long fa = t * FPT + m + 1 - NFFT / HOP - a.frame_off;
-                            if ((ok0 && fa >= 0 && fa < a.n_valid) || (ok1 && fa + 1 >= 0 && fa + 1 < a.n_valid)) {
-                                v2f w[2 * PPL];
-#pragma unroll
-                                for (int u = 0; u < PPL; u++) {
-                                    const v2f X = reg(j0 + u), Y = reg(j0 + HOP / 128 + u);
-                                    const auto rx = __builtin_amdgcn_permlane32_swap(__float_as_int(X.x), __float_as_int(Y.x), false, false);
-                                    const auto ry = __builtin_amdgcn_permlane32_swap(__float_as_int(X.y), __float_as_int(Y.y), false, false);
-                                    w[2 * u] = (v2f){__int_as_float(rx[0]), __int_as_float(ry[0])};
-                                    w[2 * u + 1] = (v2f){__int_as_float(rx[1]), __int_as_float(ry[1])};
-                                }
-                                const long long fc = keep ? f : 0;            // a masked group still needs a legal address
-                                psd_frame<NFFT, LPF, R1, R2, R3, DB>(w, fb + gq * MP, tw2, tw3, twn, win, lane, a.scale, keep,
-                                                                     oc + fc * (long long)F, dc + fc * (long long)F, piv, have_piv);
-                            }
-                        }
-                    }
-                   }
-                  } else if (t == -12345) oc[lane] = cur_[0].x + cur_[9].y + prv_[0].x + bb_[0].x;
-                }
-                if constexpr (G == 4) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) pv_[j] = pvn_[j];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < PREV; j++) prv_[j] = cur_[16 - PREV + j];
-                }
-                have_prev = true;
-            }
-            STAMP_AT(10);                                      // the tile's (at most) two frames
-        }
-        if (unit_ok && last_seg && a.tail_end > a.n_valid) {
-            for (long long i = a.n_valid * F + lane; i < a.tail_end * F; i += 64) {
-                oc[i] = 0.f;
-                if (DB) dc[i] = -INFINITY;
-            }
-        }
-    }
-    if (STAMP && lane == 0) {
-        long long *dst = reinterpret_cast<long long *>(a.db) + ((long long)blockIdx.x * 2 * NP + wave) * 16;
-#pragma unroll
-        for (int i = 0; i < 16; i++) dst[i] = st_acc[i];
-    }
-#undef STAMP_AT
-}
 
 // ---- backward sweep of the batch chain with HALF of the spectrogram fused in ------------------------------
 // The forward sweep is bound by VALU issue (its FFT waves are the critical path of every pair), the backward
@@ -1043,8 +294,8 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_bwd_kernel(const SosPl
                 v2f w[16];
 #pragma unroll
                 for (int i = 0; i < 8; i++) { w[i] = cur_[8 + i]; w[8 + i] = nxt_[i]; }
-                psd_frame<NFFT, 64, R1, R2, R3, false>(w, fb, tw2, tw3, twn, win, lane, a.scale, true, oc + f * (long long)F,
-                                                       nullptr, piv, have_piv);
+                psd_frame_pivot<NFFT, 64, R1, R2, R3, false>(w, fb, tw2, tw3, twn, win, lane, a.scale, true, oc + f * (long long)F,
+                                                             nullptr, piv, have_piv);
             }
 #pragma unroll
             for (int j = 0; j < 8; j++) nxt_[j] = cur_[j];
@@ -1146,7 +397,7 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     a.debug = ctx->chain_debug;
     a.fault = ctx->fault_dev;
     a.split = (ctx->chain_split_frames && nfft == 2048 && hop == 1024 && !db_out && gs.lead == 0 && gs.env0 == 0) ? 1 : 0;
-    constexpr int P = 8;                                           // IIR waves (and FFT waves) per workgroup, one per CU
+    constexpr int P = CHAIN_P;                                     // IIR waves (and FFT waves) per workgroup, one per CU
     // (hipdsp_chain_plan reports exactly this segmentation)
     plan_segments_chain(ctx, T, channels, a.warm_total, &a.c.seg_len, &a.c.n_seg);
     a.units = channels * a.c.n_seg;
@@ -1175,68 +426,23 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
             hipLaunchKernelGGL(zero_rows_kernel, dim3(gx, (unsigned)channels), dim3(256), 0, ctx->stream,
                                db_out + n_valid * F, (long long)psd_pitch, n, -INFINITY);
     }
-    dim3 grid((unsigned)blocks), block(128 * P);
     const SosPlanDev *edev_ = eplan ? eplan->dev : nullptr;
     const bool flags = (ctx->chain_debug & 4) == 0;       // bit 4: workgroup barriers instead of the pairwise flags
-    if ((ctx->chain_debug & 32) && db_out && SF == 2 && SE == 1 && flags && nfft == 2048 && hop == 1024) {
-        // diagnostic build: db_out receives 16 clock sums per wave (needs >= blocks * 16 * 16 * 8 bytes)
-        hipLaunchKernelGGL((chain_fwd_kernel<2, 1, P, true, false, 2048, 1024, true>), grid, block, 0, ctx->stream,
-                           fplan->dev, edev_, a);
-        return hd_launch_status("chain_fwd_kernel");
+    // diagnostic build ("chain_debug" bit 32): db_out receives 16 clock sums per wave (needs >= blocks * 16 * 16 * 8 bytes)
+    const bool stamp = (ctx->chain_debug & 32) && db_out && SF == 2 && SE == 1 && flags && nfft == 2048 && hop == 1024;
+    // one translation unit per window shape holds the kernel's instantiations (chain_shape.inc): every shape with the
+    // pairwise flags, PSD only or with the fused dB image; 2048 / 1024 with plans of one or two sections also with
+    // workgroup barriers (the tests)
+    int (*launch)(int, int, int, int, int, unsigned, hipStream_t, const SosPlanDev *, const SosPlanDev *, const void *, size_t) =
+        (nfft == 2048 && hop == 1024) ? hd_chain_fwd_launch_2048_1024 : (nfft == 2048) ? hd_chain_fwd_launch_2048_512 :
+        (nfft == 1024 && hop == 512) ? hd_chain_fwd_launch_1024_512 : (nfft == 1024) ? hd_chain_fwd_launch_1024_256 :
+        (nfft == 512) ? hd_chain_fwd_launch_512_256 : hd_chain_fwd_launch_256_128;
+    if (launch(SF, SE, flags ? 1 : 0, (db_out && !stamp) ? 1 : 0, stamp ? 1 : 0, (unsigned)blocks, ctx->stream, fplan->dev, edev_,
+               &a, sizeof(a)) != 0) {
+        hipdsp_set_error("the barrier variant of the fused sweep is built for nfft 2048 / hop 1024 and plans of one or two sections");
+        return HIPDSP_ERR_UNSUPPORTED;
     }
-    // nfft 2048 / hop 1024 with plans of up to two sections: every variant (barriers for the tests, fused dB
-    // output for the display path); the other shapes and longer band-passes: pairwise flags, PSD only
-#define HD_CHAIN_FULL(A, B)                                                                                         \
-    case (A) * 8 + (B):                                                                                            \
-        if (db_out) {                                                                                              \
-            if (flags) hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, true>), grid, block, 0, ctx->stream, fplan->dev, edev_, a);  \
-            else hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, false, true>), grid, block, 0, ctx->stream, fplan->dev, edev_, a);       \
-        } else {                                                                                                   \
-            if (flags) hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, false>), grid, block, 0, ctx->stream, fplan->dev, edev_, a); \
-            else hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, false, false>), grid, block, 0, ctx->stream, fplan->dev, edev_, a);      \
-        }                                                                                                          \
-        break
-#define HD_CHAIN_LONG(A, B)                                                                                         \
-    case (A) * 8 + (B):                                                                                            \
-        if (db_out) hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, true>), grid, block, 0, ctx->stream, fplan->dev, edev_, a); \
-        else hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, false>), grid, block, 0, ctx->stream, fplan->dev, edev_, a);       \
-        break
-#define HD_CHAIN_SHAPE(A, B, N, H)                                                                                  \
-    case (A) * 8 + (B):                                                                                            \
-        if (db_out) hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, true, N, H>), grid, block, 0, ctx->stream, fplan->dev, edev_, a); \
-        else hipLaunchKernelGGL((chain_fwd_kernel<A, B, P, true, false, N, H>), grid, block, 0, ctx->stream, fplan->dev, edev_, a); \
-        break
-#define HD_CHAIN_ALL(N, H)                                                                                          \
-    switch (SF * 8 + SE) {                                                                                         \
-        HD_CHAIN_SHAPE(1, 0, N, H); HD_CHAIN_SHAPE(2, 0, N, H); HD_CHAIN_SHAPE(3, 0, N, H); HD_CHAIN_SHAPE(4, 0, N, H); \
-        HD_CHAIN_SHAPE(1, 1, N, H); HD_CHAIN_SHAPE(1, 2, N, H); HD_CHAIN_SHAPE(2, 1, N, H); HD_CHAIN_SHAPE(2, 2, N, H); \
-        HD_CHAIN_SHAPE(3, 1, N, H); HD_CHAIN_SHAPE(3, 2, N, H); HD_CHAIN_SHAPE(4, 1, N, H); HD_CHAIN_SHAPE(4, 2, N, H); \
-    }
-    if (nfft == 2048 && hop == 1024) {
-        if ((!flags) && (SF > 2 || SE == 0)) {
-            hipdsp_set_error("the barrier variant of the fused sweep is built for plans of one or two sections");
-            return HIPDSP_ERR_UNSUPPORTED;
-        }
-        switch (SF * 8 + SE) {
-            HD_CHAIN_FULL(1, 1); HD_CHAIN_FULL(1, 2); HD_CHAIN_FULL(2, 1); HD_CHAIN_FULL(2, 2);
-            HD_CHAIN_LONG(3, 1); HD_CHAIN_LONG(3, 2); HD_CHAIN_LONG(4, 1); HD_CHAIN_LONG(4, 2);
-            HD_CHAIN_LONG(1, 0); HD_CHAIN_LONG(2, 0); HD_CHAIN_LONG(3, 0); HD_CHAIN_LONG(4, 0);
-        }
-    } else if (nfft == 2048 && hop == 512) {
-        HD_CHAIN_ALL(2048, 512)
-    } else if (nfft == 1024 && hop == 512) {
-        HD_CHAIN_ALL(1024, 512)
-    } else if (nfft == 1024 && hop == 256) {
-        HD_CHAIN_ALL(1024, 256)
-    } else if (nfft == 512) {
-        HD_CHAIN_ALL(512, 256)
-    } else {
-        HD_CHAIN_ALL(256, 128)
-    }
-#undef HD_CHAIN_FULL
-#undef HD_CHAIN_LONG
-#undef HD_CHAIN_SHAPE
-#undef HD_CHAIN_ALL
+    if (stamp) return hd_launch_status("chain_fwd_kernel");
     rc = hd_launch_status("chain_fwd_kernel");
     if (rc != HIPDSP_OK) return rc;
     FloodArgs fl;
