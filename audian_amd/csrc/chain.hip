@@ -294,8 +294,8 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_bwd_kernel(const SosPl
                 v2f w[16];
 #pragma unroll
                 for (int i = 0; i < 8; i++) { w[i] = cur_[8 + i]; w[8 + i] = nxt_[i]; }
-                psd_frame_pivot<NFFT, 64, R1, R2, R3, false>(w, fb, tw2, tw3, twn, win, lane, a.scale, true, oc + f * (long long)F,
-                                                             nullptr, piv, have_piv);
+                psd_frame_pivot<NFFT, 64, R1, R2, R3, false>(w, fb, tw2, tw3, twn, win, lane, a.scale, true,
+                                                             bin_sink<false>(oc + f * (long long)F, nullptr, 0), piv, have_piv);
             }
 #pragma unroll
             for (int j = 0; j < 8; j++) nxt_[j] = cur_[j];
@@ -320,6 +320,7 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
 {
     HD_REQUIRE(ctx != nullptr && fplan != nullptr, "NULL argument");
     HD_REQUIRE(channels >= 0 && frames >= 0 && frames_out >= 0, "negative size");
+    HD_REQUIRE(frames_out < (1LL << 31) - (1LL << 16), "frames_out %lld: the fused sweep counts frames in 32 bits", (long long)frames_out);
     HD_REQUIRE(spec_first >= 0 && spec_first <= frames, "spec_first %lld not in [0, frames=%lld]", (long long)spec_first,
                (long long)frames);
     HD_REQUIRE(spec_frames >= 0 && spec_first + spec_frames <= frames, "spec_first %lld + spec_frames %lld beyond frames=%lld",

@@ -8,6 +8,7 @@
 // (buffereddata.py:149-153).
 #pragma once
 #include "sos_device.h"
+// (STOCKHAM_LOADS_FIRST: a window's own translation unit may define it -- fft_device.h, stockham_stage)
 #include "fft_device.h"
 #include <cmath>
 
@@ -22,6 +23,14 @@ HD_CHAIN_FWD_DECL(1024, 256);
 HD_CHAIN_FWD_DECL(512, 256);
 HD_CHAIN_FWD_DECL(256, 128);
 #undef HD_CHAIN_FWD_DECL
+
+#ifdef CHAIN_AB_PLAIN_SUM
+#define CHAIN_MSUM_ADD(x) do { } while (0)
+#define CHAIN_MSUM_ON false
+#else
+#define CHAIN_MSUM_ADD(x) msum_ += (x)
+#define CHAIN_MSUM_ON true
+#endif
 
 namespace {
 
@@ -100,13 +109,37 @@ struct ChainArgs {
 // stores of a lane group whose frame does not exist.  Same arithmetic as spec_fast_kernel<NFFT, LPF, R1, R2, R3, ...>.
 struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 
+// Where a call's bins go: buffer descriptors (SGPRs) whose base is the frame of lane group 0 -- the frames of the other
+// groups of a wave (512- and 256-sample windows: two and four side by side) lie `gstride` bytes further on each.  A bin is
+// then  descriptor + one 32-bit VGPR offset + a compile-time constant, the addressing mode of buffer_store_dword; with
+// 64-bit global pointers every lane carried two pointer pairs per frame (and, for the windows whose frame differs from
+// lane group to lane group, a 64-bit multiply per call), which is what pushed the 256-sample kernel's LDS addresses
+// into scratch.  num_records = 4 GiB - 1: a call reaches at most four frames beyond its base.
+struct BinSink {
+    __amdgpu_buffer_rsrc_t psd, db;
+    int gstride;
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bin_rsrc(float *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, -1, 0x00027000);
+}
+template <bool DB>
+__device__ __forceinline__ BinSink bin_sink(float *psd0, float *db0, int gstride)
+{
+    BinSink k;
+    k.psd = bin_rsrc(psd0);
+    k.db = bin_rsrc(DB ? db0 : psd0);
+    k.gstride = gstride;
+    return k;
+}
+
 // The transform behind the window: v = the frame's detrended, windowed values (value t of a lane), corr = what the split
 // step still has to take out of bins 0 and 1 (half the sum of what the detrending left: a residual mean m under the periodic
 // Hann window is m nfft / 2 in bin 0, -m nfft / 4 in bin 1 and nothing elsewhere).
 template <int NFFT, int LPF, int R1, int R2, int R3, bool DB, class Hook = NoHook>
 __device__ __forceinline__ void psd_frame_core(float2 *v, const float corr, float2 *fb, const float2 *tw2, const float2 *tw3,
                                                const float2 *twn, int lane, float scale, bool keep,
-                                               float *__restrict__ o, float *__restrict__ od, Hook hook = Hook());
+                                               const BinSink &out, Hook hook = Hook());
 
 // Detrending by an EXACT mean (round 5).  The IIR wave of the pair has every band-pass output in a float64 register in
 // phase 3 (sos_cascade.inc: CASC_TAP) and adds them up there -- the reference's own arithmetic for detrend='constant'
@@ -119,25 +152,41 @@ __device__ __forceinline__ void psd_frame_core(float2 *v, const float corr, floa
 template <int NFFT, int LPF, int R1, int R2, int R3, bool DB, class Hook = NoHook>
 __device__ __forceinline__ void psd_frame_mean(const v2f *w, float2 *fb, const float2 *tw2, const float2 *tw3,
                                                const float2 *twn, const float2 *win, int lane, float scale, bool keep,
-                                               float *__restrict__ o, float *__restrict__ od, const float2 mean_hc,
-                                               Hook hook = Hook())
+                                               const BinSink &out, const float2 mean_hc, Hook hook = Hook())
 {
 #pragma clang fp contract(fast)
     constexpr int M = NFFT / 2, PPL = M / LPF;
     const int l = lane % LPF;
     float2 v[PPL];
+#ifdef CHAIN_AB_PLAIN_SUM      // (A/B only, never shipped: round 3's plain float32 frame sum in the FFT wave)
+    v2f acc = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < R1; t++) acc += w[t];
+    float sum = acc.x + acc.y;
+    if (LPF == 64) sum = wave_sum(sum);
+    else {
+#pragma unroll
+        for (int d = LPF / 2; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    }
+    const float mean = sum * (1.0f / (float)NFFT);
+    const v2f mean2 = {mean, mean};
+#pragma unroll
+    for (int t = 0; t < R1; t++) v[t] = as_f2((w[t] - mean2) * as_v2f(win[l + LPF * t]));
+    hook(0);
+    psd_frame_core<NFFT, LPF, R1, R2, R3, DB, Hook>(v, 0.f, fb, tw2, tw3, twn, lane, scale, keep, out, hook);
+#else
     const v2f hi2 = {mean_hc.x, mean_hc.x};
 #pragma unroll
     for (int t = 0; t < R1; t++) v[t] = as_f2((w[t] - hi2) * as_v2f(win[l + LPF * t]));
     hook(0);                                   // mean and window
-    psd_frame_core<NFFT, LPF, R1, R2, R3, DB, Hook>(v, mean_hc.y, fb, tw2, tw3, twn, lane, scale, keep, o, od, hook);
+    psd_frame_core<NFFT, LPF, R1, R2, R3, DB, Hook>(v, mean_hc.y, fb, tw2, tw3, twn, lane, scale, keep, out, hook);
+#endif
 }
 
 template <int NFFT, int LPF, int R1, int R2, int R3, bool DB, class Hook = NoHook>
 __device__ __forceinline__ void psd_frame_pivot(const v2f *w, float2 *fb, const float2 *tw2, const float2 *tw3,
                                           const float2 *twn, const float2 *win, int lane, float scale, bool keep,
-                                          float *__restrict__ o, float *__restrict__ od, float &piv, bool &have_piv,
-                                          Hook hook = Hook())
+                                          const BinSink &out, float &piv, bool &have_piv, Hook hook = Hook())
 {
 #pragma clang fp contract(fast)
     constexpr int M = NFFT / 2, PPL = M / LPF;
@@ -197,13 +246,13 @@ __device__ __forceinline__ void psd_frame_pivot(const v2f *w, float2 *fb, const 
     }
     const float corr = 0.5f * gsum(rest.x + rest.y);
     hook(0);                                   // mean and window
-    psd_frame_core<NFFT, LPF, R1, R2, R3, DB, Hook>(v, corr, fb, tw2, tw3, twn, lane, scale, keep, o, od, hook);
+    psd_frame_core<NFFT, LPF, R1, R2, R3, DB, Hook>(v, corr, fb, tw2, tw3, twn, lane, scale, keep, out, hook);
 }
 
 template <int NFFT, int LPF, int R1, int R2, int R3, bool DB, class Hook>
 __device__ __forceinline__ void psd_frame_core(float2 *v, const float corr, float2 *fb, const float2 *tw2, const float2 *tw3,
                                                const float2 *twn, int lane, float scale, bool keep,
-                                               float *__restrict__ o, float *__restrict__ od, Hook hook)
+                                               const BinSink &out, Hook hook)
 {
 #pragma clang fp contract(fast)
     constexpr int M = NFFT / 2, PPL = M / LPF;
@@ -218,6 +267,20 @@ __device__ __forceinline__ void psd_frame_core(float2 *v, const float corr, floa
     // v[u*R3 + t] = Z[k], k = l + LPF*m, m = u + NB3*t; partner bin Z[M-k] from lane LPF-l of the same group
     constexpr int NB3 = PPL / R3;
     const int partner = g0 + ((LPF - l) & (LPF - 1));
+    // The two store streams of a lane, bins k = l + LPF m and M - k, as ONE 32-bit byte offset each (the lane's part, with
+    // its group's frame) plus a compile-time constant behind the call's descriptor (BinSink).  Written as o[M - k] on a
+    // 64-bit pointer, hipcc kept one index register per m alive across the whole tile loop and shifted each of them again
+    // in every frame (negative immediates are not folded behind a VGPR offset): seven VALU instructions per frame.
+    // (Opaque per call, then masked: a sum offset + constant that hipcc can see through is hoisted out of the tile loop
+    // as a value of its own -- nine offset registers per frame --, and one whose sign it does not know is not folded into
+    // the instruction's offset field.  The mask tells it the range: at most four frames of 1025 bins.)
+    const int gframe = (LPF == 64) ? 0 : (lane / LPF) * out.gstride;
+    int bo_k = 4 * l + gframe, bo_m = 4 * (M - l - LPF * (PPL / 2 - 1)) + gframe;
+    asm volatile("" : "+v"(bo_k), "+v"(bo_m));
+    bo_k &= 0xfffc; bo_m &= 0xfffc;
+    auto st_bin = [](__amdgpu_buffer_rsrc_t r, int boff, int imm, float val) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(val), r, boff + imm, 0, 0);
+    };
     float pk_last = 0.f;
     const v2f hscale2 = {0.5f * scale, 0.5f * scale};
 #pragma unroll
@@ -247,9 +310,9 @@ __device__ __forceinline__ void psd_frame_core(float2 *v, const float corr, floa
             pm = (l == 0) ? ny * ny * scale : pm;
         }
         if (LPF == 64 || keep) {
-            o[k] = pk;
-            o[M - k] = pm;
-            if (DB) { od[k] = to_db(pk); od[M - k] = to_db(pm); }
+            st_bin(out.psd, bo_k, 4 * LPF * m, pk);                              // bin k
+            st_bin(out.psd, bo_m, 4 * LPF * (PPL / 2 - 1 - m), pm);              // bin M - k
+            if (DB) { st_bin(out.db, bo_k, 4 * LPF * m, to_db(pk)); st_bin(out.db, bo_m, 4 * LPF * (PPL / 2 - 1 - m), to_db(pm)); }
         }
         pk_last = pk;
     }
@@ -257,11 +320,12 @@ __device__ __forceinline__ void psd_frame_core(float2 *v, const float corr, floa
         constexpr int mh = PPL / 2;
         const float2 z = v[(mh % NB3) * R3 + mh / NB3];
         const float ph = 2.f * scale * fmaf(z.x, z.x, z.y * z.y);
-        const int kk = (l == 0) ? M / 2 : l + LPF * (PPL / 2 - 1);
+        // (bin M / 2 is lane 0's; the other lanes write their last bin once more, under the same instruction)
+        const int bo_h = (l == 0) ? bo_k + 4 * (M / 2) : bo_k + 4 * LPF * (PPL / 2 - 1);        // (bo_k is 4 l + the group's frame)
         const float pv = (l == 0) ? ph : pk_last;
         if (LPF == 64 || keep) {
-            o[kk] = pv;
-            if (DB) od[kk] = to_db(pv);
+            st_bin(out.psd, bo_h, 0, pv);
+            if (DB) st_bin(out.db, bo_h, 0, to_db(pv));
         }
     }
 }
@@ -389,7 +453,18 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
     if (start < 0) start = 0;
     long long loop_end = last_seg ? T + edge : hi;
     if (!unit_ok) loop_end = start;                     // a pair without a unit only takes the barriers
-    const long long base = lo - a.warm_total;           // tile of iteration 0 (negative: idle iterations)
+    // (iteration 0 is tile lo - warm_total: negative = idle iterations)
+    // The loop bookkeeping in TILE INDICES of 32 bits (round 5): lo, seg_len and the warm-up are whole tiles, and gfx950's
+    // scalar unit compares 32-bit values only -- every `tile < hi` on 64-bit sample positions was a VALU compare, and each
+    // position two scalar registers of a kernel that has none to spare (hipcc parks what does not fit in VGPR lanes, and
+    // every such VGPR is taken from the FFT role's 128: with one more of them round 4's builds read their LDS operands
+    // one at a time).  tt = tile / TILE; only the paths of border tiles go back to sample positions.
+    const int TT = (int)(T / TILE);                                  // whole tiles inside the trace: tt < TT <=> tile + TILE <= T
+    const int lo_t = (int)(lo / TILE), start_t = (int)(start / TILE), base_t = lo_t - (int)(a.warm_total / TILE);
+    const int end_t = (int)((loop_end + TILE - 1) / TILE);           // active <=> start_t <= tt < end_t
+    const int hi_full_t = (int)(hi / TILE), hi_ceil_t = (int)((hi + TILE - 1) / TILE);
+    const int lead_t = lead > 0 ? 1 : 0;                             // tt >= lead_t <=> tile >= lead (lead < TILE)
+    const int env_start_t = env_start >= (1LL << 62) ? 0x7fffffff : (int)(env_start / TILE);
 
     // "chain_debug" bit 16: IIR wave 0 of workgroup 0 reports shader clocks and 100 MHz ticks spent in
     // the kernel into the first 16 bytes of the PSD (measurement of the engine clock under this load)
@@ -426,20 +501,20 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
         v4f nx[8];
         bool pre = false;
         int pending = 0;
-        const long long top_full = (T / TILE - 1) * TILE;            // host guarantees >= 0
-        auto fetch = [&](long long t0) {
+        const int top_full_t = TT - 1;                               // host guarantees >= 0
+        auto fetch = [&](int t0) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) nx[k] = asm_load16(in + t0 + 256 * k + 4 * lane);
+            for (int k = 0; k < 8; k++) nx[k] = asm_load16(in + (long long)t0 * TILE + 256 * k + 4 * lane);
         };
         // what iteration k + 1 will read: its tile if that is a full tile of this unit, else a dummy
-        auto prefetchable = [&](long long t0) { return t0 >= start && t0 < loop_end && t0 + TILE <= T && t0 >= lead; };
-        pre = prefetchable(base);
-        fetch(pre ? base : top_full);
+        auto prefetchable = [&](int t0) { return t0 >= start_t && t0 < end_t && t0 < TT && t0 >= lead_t; };
+        pre = prefetchable(base_t);
+        fetch(pre ? base_t : top_full_t);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
         for (int it = 0; it < a.n_iter; it++) {
-            const long long tile = base + (long long)it * TILE;
-            const bool active = tile >= start && tile < loop_end;
+            const int tt = base_t + it;
+            const bool active = tt >= start_t && tt < end_t;
             if (!(a.debug & 64)) CHAIN_FAIR(it, 1, 0);
             if (FLAGS && pending) {                            // H2 of the previous (quiet) tile
                 CHAIN_WAIT_FOR(taken, pending, it);
@@ -455,6 +530,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                 } else {
                     // a tile that reaches past T (or holds the `lead` samples in front of the trace): untracked loads
                     // from clamped addresses, zeros outside [lead, T)
+                    const long long tile = (long long)tt * TILE;
 #pragma unroll 1
                     for (int k = 0; k < 8; k++) {
                         const long long p = tile + 256 * k + 4 * lane;
@@ -476,9 +552,9 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             // unconditional, like in sos_ckpt_kernel (a conditional fetch would turn `nx` into a phi
             // whose copies read registers with loads in flight)
             {
-                const long long next = tile + TILE;
+                const int next = tt + 1;
                 pre = prefetchable(next);
-                fetch(pre ? next : top_full);
+                fetch(pre ? next : top_full_t);
             }
             STAMP_AT(0);                                       // wait for H2 of the last tile, tile -> LDS, fetch issued
             // Phase 1 of the envelope cascade rides on phase 3 of the band-pass: every filtered sample is
@@ -508,7 +584,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
 #define CASC_TAP(j, e, y)                                                               \
     do {                                                                                \
         const double ed_ = (double)(e);                                                 \
-        msum_ += ed_;                                                                   \
+        CHAIN_MSUM_ADD(ed_);                                                            \
         if constexpr (SE > 0) {                                                         \
             if (((j) & 3) == 0) PEt = PLAN_OF(PE0);                                     \
             const double rd_ = fabs(ed_);                                               \
@@ -526,7 +602,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
 #pragma unroll
                 for (int r = 0; r < DE; r++) etap[r] *= tgain;
             }
-            if (active) {
+            if (active && CHAIN_MSUM_ON) {
                 // ---- the means of the frames that end in this tile (psd_frame_mean): inclusive prefix sums of the rows
                 // over the lanes, a frame = LR rows that end at row e: P[e] - E[e - LR], E continued into the tile before
                 constexpr int LR = NFFT / 32, HR = HOP / 32;
@@ -543,19 +619,20 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             WAVE_SYNC();
             if (FLAGS) { if (active) CHAIN_POST(ready, it + 1); }
             else __syncthreads();                              // B1: the tile holds the filtered samples
-            if (active && tile >= lo && tile + TILE <= hi && tile >= lead) {
+            if (active && tt >= lo_t && tt < hi_full_t && tt >= lead_t) {
                 // interior tile: exactly 8 vector stores, then the counted wait
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     const float4 v = lds[lds_slot(8 * k + (lane >> 3), lane & 7)];
                     f4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
-                    *reinterpret_cast<f4u *>(yf + tile + 256 * k + 4 * lane) = t;
+                    *reinterpret_cast<f4u *>(yf + (long long)tt * TILE + 256 * k + 4 * lane) = t;
                 }
                 asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
                 STAMP_AT(4);                                   // H1, 8 stores of the filtered tile, wait for the prefetch
             } else {
                 // border tile of the segment, warm-up or idle: whatever is stored, no stores to count
-                if (active && tile + TILE > lo && tile < hi) {
+                if (active && tt >= lo_t && tt < hi_ceil_t) {
+                    const long long tile = (long long)tt * TILE;
 #pragma unroll
                     for (int k = 0; k < 8; k++)
                         store_four(yf, tile + 256 * k + 4 * lane, lds[lds_slot(8 * k + (lane >> 3), lane & 7)],
@@ -568,12 +645,12 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             // and, with the flags, H2 is only needed before the NEXT tile goes into LDS.
             // (the last tile of a segment that is not the trace's last advances the state too: its end state is handed
             // to the next segment by env_fix_kernel)
-            const bool last_tile = tile + TILE >= loop_end;
-            const bool quiet = SE > 0 && active && tile >= env_start && a.c.rectify && tile + 2 * TILE <= T &&
-                               !(env_true && tile == env_start) && (!last_tile || !last_seg) && !(a.debug & 2);
+            const bool last_tile = tt + 1 >= end_t;
+            const bool quiet = SE > 0 && active && tt >= env_start_t && a.c.rectify && tt + 1 < TT &&
+                               !(env_true && tt == env_start_t) && (!last_tile || !last_seg) && !(a.debug & 2);
             if (FLAGS) {
                 if (active) {
-                    if (quiet || SE == 0 || tile < env_start) pending = it + 1;   // (nothing touches the tile before the next one)
+                    if (quiet || SE == 0 || tt < env_start_t) pending = it + 1;   // (nothing touches the tile before the next one)
                     else CHAIN_WAIT_FOR(taken, it + 1, it);
                 }
             } else {
@@ -581,9 +658,9 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             }
             if constexpr (SE > 0) {
             if (quiet) {
-                if ((tile > lo || env_true) && lane == 0) {     // (quiet: never the envelope's first tile)
+                if ((tt > lo_t || env_true) && lane == 0) {     // (quiet: never the envelope's first tile)
 #pragma unroll
-                    for (int r = 0; r < DE; r++) ckpt[(tile / TILE) * DE + r] = ce_[r];
+                    for (int r = 0; r < DE; r++) ckpt[(long long)tt * DE + r] = ce_[r];
                 }
 #define CASC_S SE
 #define CASC_PLAN() PLAN_OF(PE0)
@@ -604,11 +681,12 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
 #undef CASC_IN
                 if (last_tile && lane == 0) {
 #pragma unroll
-                    for (int r = 0; r < DE; r++) ckpt[(tile / TILE + 1) * DE + r] = ce_[r];
+                    for (int r = 0; r < DE; r++) ckpt[(long long)(tt + 1) * DE + r] = ce_[r];
                 }
                 WAVE_SYNC();
-            } else if (active && tile >= env_start && !(a.debug & 2)) {
+            } else if (active && tt >= env_start_t && !(a.debug & 2)) {
                 // ---- envelope input in place: r = |y| (the gain rides on the cascade), then the odd extension past T
+                const long long tile = (long long)tt * TILE;
                 if (a.c.rectify) {
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
@@ -621,7 +699,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                 auto rval = [&](long long j) -> float {
                     return j >= tile ? ldsf[lds_float_index((int)(j - tile))] : rprev[64 - (int)(tile - j)];
                 };
-                if (tile + TILE > T) {
+                if (tt >= TT) {
                     float pv = 0.f;
                     long long pj = -1;
                     if (lane < edge) {
@@ -632,7 +710,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                     if (lane < edge && pj >= tile && pj < tile + TILE) ldsf[lds_float_index((int)(pj - tile))] = pv;
                     WAVE_SYNC();
                 }
-                if (env_true && tile == env_start && a.c.env0 > 0) {
+                if (env_true && tt == env_start_t && a.c.env0 > 0) {
                     // the envelope starts inside this tile, at q = env0 - tile (host: edge <= q < TILE - edge): scipy's
                     // left odd extension ext[i] = 2 r(q) - r(q + edge - i), i < edge, goes into the edge samples in
                     // front of q, and everything in front of THAT becomes ext[0] -- a constant input for which
@@ -644,7 +722,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                     const double x0 = a.c.gain * (double)e0;
 #pragma unroll
                     for (int r = 0; r < DE; r++) ce_[r] = Pz->zi[r] * x0;
-                } else if (env_true && tile == env_start) {
+                } else if (env_true && tt == env_start_t) {
                     const SosPlanDev *Pz = PLAN_OF(PE0);
                     const double r0 = (double)ldsf[lds_float_index(0)];
                     const double x0 = a.c.gain * (2.0 * r0 - (double)ldsf[lds_float_index(edge)]);
@@ -661,9 +739,9 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                         }
                     }
                 }
-                if ((tile > lo || env_true) && lane == 0) {
+                if ((tt > lo_t || env_true) && lane == 0) {
 #pragma unroll
-                    for (int r = 0; r < DE; r++) ckpt[(tile / TILE) * DE + r] = ce_[r];
+                    for (int r = 0; r < DE; r++) ckpt[(long long)tt * DE + r] = ce_[r];
                 }
                 {   // (the trace's very last tile advances the state too: slot n_tiles, see sos_device.h: FloodArgs)
                     {
@@ -691,7 +769,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
 #undef CASC_IN
                     if (last_tile && lane == 0) {
 #pragma unroll
-                        for (int r = 0; r < DE; r++) ckpt[(tile / TILE + 1) * DE + r] = ce_[r];
+                        for (int r = 0; r < DE; r++) ckpt[(long long)(tt + 1) * DE + r] = ce_[r];
                     }
                 }
                 WAVE_SYNC();
@@ -711,7 +789,17 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
         // The FFT wave is the critical path of its pair (tools/chain_stamps.py: 94 % of its clocks inside the two
         // FFTs of a tile, while the IIR wave waits 44 % of its own for the hand-over): it asks for the SIMD's
         // issue slots first, the IIR waves fill the gaps (-2.2 % for the launch; "chain_debug" bit 64 = off)
-        if (!(a.debug & 64)) __builtin_amdgcn_s_setprio(3);
+        // What the loop below needs of the kernel's arguments, as opaque scalar values: left as loads from the argument
+        // block, hipcc re-fetches them INSIDE the frames when scalar registers run short (round 4's grid shift added
+        // three) -- and with a scalar load in flight every wait for an LDS read becomes lgkmcnt(0), because scalar loads
+        // return out of order: nineteen full waits per frame instead of counted ones, 4 % of the launch at 1024 / 256
+        // and 256 / 128 (profiles/r05d_pmc_fwd_libs.txt: same instruction counts, longer launch).  An asm output
+        // cannot be rematerialised from memory; at worst it is parked in a VGPR lane.
+        float fscale = a.scale;
+        int foff = a.frame_off, fsplit = a.split, fdebug = a.debug, n_iter = a.n_iter;
+        int nvalid = (int)a.n_valid;                           // (the host keeps frames_out below 2^31 - 2^16)
+        asm volatile("" : "+s"(fscale), "+s"(foff), "+s"(fsplit), "+s"(fdebug), "+s"(n_iter), "+s"(nvalid));
+        if (!(fdebug & 64)) __builtin_amdgcn_s_setprio(3);
         float2 *fb = fbs[pair];
         const float *tlf = reinterpret_cast<const float *>(tiles[pair]);
         const float2 *tw2 = tab, *tw3 = tab + TW2, *twn = tab + TW2 + TW3, *win = tab + TW2 + TW3 + TWN;
@@ -735,30 +823,30 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
 #pragma unroll
         for (int j = 0; j < 4; j++) pv_[j] = (v2f){0.f, 0.f};
         bool have_prev = false;
-        for (int it = 0; it < a.n_iter; it++) {
-            const long long tile = base + (long long)it * TILE;
-            const bool active = tile >= start && tile < loop_end;
+        for (int it = 0; it < n_iter; it++) {
+            const int tt = base_t + it;
+            const bool active = tt >= start_t && tt < end_t;
             // (which role stands above the other no longer matters once equals keep pace: IIR above FFT 10.95 ms,
             // both on the same two levels 10.83 ms, FFT above IIR 10.85 ms in one process)
-            if (!(a.debug & 64)) CHAIN_FAIR(it, 3, 2);
+            if (!(fdebug & 64)) CHAIN_FAIR(it, 3, 2);
             if (FLAGS) { if (active) CHAIN_WAIT_FOR(ready, it + 1, it); }
             else __syncthreads();                              // B1
             STAMP_AT(8);                                       // waited for the IIR wave's tile
-            v2f pvn_[4];
             if (active) {
                 if constexpr (G == 4) {
                     const int gq = lane >> 4, l16 = lane & 15;
 #pragma unroll
                     for (int j = 0; j < 5; j++)
 #pragma unroll
-                        for (int tt = 0; tt < 4; tt++) {
+                        for (int tq = 0; tq < 4; tq++) {
                             const int b = 4 * gq - 1 + j;              // (-1: the block the last tile left in pv_)
-                            const v2f h = *reinterpret_cast<const v2f *>(tlf + lds_float_index(128 * (b < 0 ? 0 : b) + 2 * (l16 + 16 * tt)));
-                            bb_[4 * j + tt] = (j == 0 && b < 0) ? pv_[tt] : h;
+                            const v2f h = *reinterpret_cast<const v2f *>(tlf + lds_float_index(128 * (b < 0 ? 0 : b) + 2 * (l16 + 16 * tq)));
+                            bb_[4 * j + tq] = (j == 0 && b < 0) ? pv_[tq] : h;
                         }
+                    // (the old block 15 has just gone into group 0's registers: the new one takes its place)
 #pragma unroll
-                    for (int tt = 0; tt < 4; tt++)
-                        pvn_[tt] = *reinterpret_cast<const v2f *>(tlf + lds_float_index(128 * 15 + 2 * (l16 + 16 * tt)));
+                    for (int tq = 0; tq < 4; tq++)
+                        pv_[tq] = *reinterpret_cast<const v2f *>(tlf + lds_float_index(128 * 15 + 2 * (l16 + 16 * tq)));
                 } else {
 #pragma unroll
                     for (int j = 0; j < 16; j++)
@@ -768,29 +856,30 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             if (FLAGS) {                                        // (the release fence waits for the loads)
                 // "chain_debug" bit 8 (fault-path test): FFT wave 0 of workgroup 0 withholds the hand-over of
                 // its unit's first tile, so that IIR wave 0 runs into the timeout
-                const bool withhold = (a.debug & 8) && blockIdx.x == 0 && pair == 0 && tile == start;
+                const bool withhold = (fdebug & 8) && blockIdx.x == 0 && pair == 0 && tt == start_t;
                 if (active && !withhold) CHAIN_POST(taken, it + 1);
             }
             else __syncthreads();                              // B2
             STAMP_AT(9);                                       // tile copied, hand-over posted
             if (active) {
-                const long long t = tile / TILE;
-                if (tile >= lo && tile < hi) {                 // the unit that owns the tile writes its frames
-                  if (!(a.debug & 1)) {
+                const int t = tt;
+                if (tt >= lo_t && tt < hi_ceil_t) {            // the unit that owns the tile writes its frames
+                  if (!(fdebug & 1)) {
                    if constexpr (G == 4) {
                     const int gq = lane >> 4;
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         // lane group gq: frame m = 4 gq + q of the tile = its blocks q and q + 1
-                        const long long f = t * FPT + 4 * gq + q + 1 - NFFT / HOP - a.frame_off;
-                        const bool keep = (4 * gq + q > 0 || have_prev) && f >= 0 && f < a.n_valid;
+                        const int f = t * FPT + 4 * gq + q + 1 - NFFT / HOP - foff;
+                        const bool keep = (4 * gq + q > 0 || have_prev) && f >= 0 && f < nvalid;
                         if (__builtin_amdgcn_ballot_w64(keep) != 0) {               // (wave-uniform: some group has a frame)
                             v2f w[8];
 #pragma unroll
                             for (int i = 0; i < 8; i++) w[i] = bb_[4 * q + i];
-                            const long long fc = keep ? f : 0;                      // a masked group still needs a legal address
-                            psd_frame_mean<NFFT, LPF, R1, R2, R3, DB>(w, fb + gq * MP, tw2, tw3, twn, win, lane, a.scale, keep,
-                                                                      oc + fc * (long long)F, dc + fc * (long long)F,
+                            // (the descriptor's base is group 0's frame, the others lie four frames further on each)
+                            const long long f0 = (long long)(t * FPT + q + 1 - NFFT / HOP - foff) * F;
+                            psd_frame_mean<NFFT, LPF, R1, R2, R3, DB>(w, fb + gq * MP, tw2, tw3, twn, win, lane, fscale, keep,
+                                                                      bin_sink<DB>(oc + f0, dc + f0, 16 * F),
                                                                       fmeans[it & 1][pair][4 * gq + q]);
                         }
                     }
@@ -800,21 +889,21 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                         const int j0 = ((m + 1) * HOP - NFFT) / 128;          // compile-time after unrolling
                         auto reg = [&](int j) -> v2f { return j < 0 ? prv_[(PREV + j) < 0 ? 0 : (PREV + j)] : cur_[j < 0 ? 0 : j]; };
                         if constexpr (G == 1) {
-                            const long long f = t * FPT + m + 1 - NFFT / HOP - a.frame_off;
-                            if ((j0 >= 0 || have_prev) && f >= 0 && f < a.n_valid && !(a.split && (f & 1))) {
+                            const int f = t * FPT + m + 1 - NFFT / HOP - foff;
+                            if ((j0 >= 0 || have_prev) && f >= 0 && f < nvalid && !(fsplit && (f & 1))) {
                                 v2f w[PPL];
 #pragma unroll
                                 for (int i = 0; i < PPL; i++) w[i] = reg(j0 + i);
                                 if (STAMP) {
                                     STAMP_AT(10);                  // (between the frames)
                                     auto hook = [&](int n) { STAMP_AT(11 + n); };
-                                    psd_frame_mean<NFFT, LPF, R1, R2, R3, DB>(w, fb, tw2, tw3, twn, win, lane, a.scale, true,
-                                                                              oc + f * (long long)F, dc + f * (long long)F,
+                                    psd_frame_mean<NFFT, LPF, R1, R2, R3, DB>(w, fb, tw2, tw3, twn, win, lane, fscale, true,
+                                                                              bin_sink<DB>(oc + f * (long long)F, dc + f * (long long)F, 0),
                                                                               fmeans[it & 1][pair][m], hook);
                                     STAMP_AT(15);                  // split step, PSD, stores
                                 } else {
-                                    psd_frame_mean<NFFT, LPF, R1, R2, R3, DB>(w, fb, tw2, tw3, twn, win, lane, a.scale, true,
-                                                                              oc + f * (long long)F, dc + f * (long long)F,
+                                    psd_frame_mean<NFFT, LPF, R1, R2, R3, DB>(w, fb, tw2, tw3, twn, win, lane, fscale, true,
+                                                                              bin_sink<DB>(oc + f * (long long)F, dc + f * (long long)F, 0),
                                                                               fmeans[it & 1][pair][m]);
                                 }
                             }
@@ -824,11 +913,11 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                             // frame, lower (t even) or upper (t odd) half of the wave: v_permlane32_swap of the two frames'
                             // registers gives {X.lo | Y.lo} and {X.hi | Y.hi} in one instruction per dword.
                             const int gq = lane / LPF;
-                            const long long f = t * FPT + m + gq + 1 - NFFT / HOP - a.frame_off;
+                            const int f = t * FPT + m + gq + 1 - NFFT / HOP - foff;
                             const bool ok0 = (j0 >= 0 || have_prev), ok1 = (j0 + HOP / 128 >= 0 || have_prev);
-                            const bool keep = (gq == 0 ? ok0 : ok1) && f >= 0 && f < a.n_valid;
-                            const long long fa = t * FPT + m + 1 - NFFT / HOP - a.frame_off;
-                            if ((ok0 && fa >= 0 && fa < a.n_valid) || (ok1 && fa + 1 >= 0 && fa + 1 < a.n_valid)) {
+                            const bool keep = (gq == 0 ? ok0 : ok1) && f >= 0 && f < nvalid;
+                            const int fa = t * FPT + m + 1 - NFFT / HOP - foff;
+                            if ((ok0 && fa >= 0 && fa < nvalid) || (ok1 && fa + 1 >= 0 && fa + 1 < nvalid)) {
                                 v2f w[2 * PPL];
 #pragma unroll
                                 for (int u = 0; u < PPL; u++) {
@@ -838,9 +927,8 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                                     w[2 * u] = (v2f){__int_as_float(rx[0]), __int_as_float(ry[0])};
                                     w[2 * u + 1] = (v2f){__int_as_float(rx[1]), __int_as_float(ry[1])};
                                 }
-                                const long long fc = keep ? f : 0;            // a masked group still needs a legal address
-                                psd_frame_mean<NFFT, LPF, R1, R2, R3, DB>(w, fb + gq * MP, tw2, tw3, twn, win, lane, a.scale, keep,
-                                                                          oc + fc * (long long)F, dc + fc * (long long)F,
+                                psd_frame_mean<NFFT, LPF, R1, R2, R3, DB>(w, fb + gq * MP, tw2, tw3, twn, win, lane, fscale, keep,
+                                                                          bin_sink<DB>(oc + fa * (long long)F, dc + fa * (long long)F, 4 * F),
                                                                           fmeans[it & 1][pair][m + gq]);
                             }
                         }
@@ -848,10 +936,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                    }
                   } else if (t == -12345) oc[lane] = cur_[0].x + cur_[9].y + prv_[0].x + bb_[0].x;
                 }
-                if constexpr (G == 4) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) pv_[j] = pvn_[j];
-                } else {
+                if constexpr (G != 4) {
 #pragma unroll
                     for (int j = 0; j < PREV; j++) prv_[j] = cur_[16 - PREV + j];
                 }

@@ -237,7 +237,15 @@ __device__ __forceinline__ void stockham_stage(float2 *v, float2 *fb, const floa
     // instruction's offset field instead of a shift and two adds per access.
     constexpr bool SPLIT_LOAD = LPF % 16 == 0 && (M / R) % 16 == 0;
     constexpr bool STORE_R16 = NS == 1 && R == 16;                       // index = 17 j + t
-    constexpr bool STORE_NS16 = NS % 16 == 0 && LPF % NS == 0;           // k, j/NS split by lane
+    // pad16 of a store index as (per-lane part) + (compile-time part) wherever the digits allow it, so that a stage's
+    // stores are ONE address register and the offset fields of the DS instructions.  Left to hipcc, the 16-lane frames of
+    // nfft 256 kept six address registers alive across the tile loop of the fused sweep -- and reloaded them from scratch
+    // in every frame, with a full vmcnt(0) each (round 5: 14.3 instead of 11.1 ms).
+    //   NS == 1, R == 8:  pad16(8 j + t) = 8 j + j / 2 + t                                       (t < 8)
+    //   NS | 16 or 16 | NS, NS | LPF, 16 | NS R:  k = l % NS and j / NS = l / NS + u LPF / NS, and the pad of
+    //   (k + t NS) is that of t NS alone (k < NS does not reach the next multiple of NS)
+    constexpr bool STORE_R8 = NS == 1 && R == 8 && LPF % 2 == 0;
+    constexpr bool STORE_NS16 = NS > 1 && (NS % 16 == 0 || 16 % NS == 0) && LPF % NS == 0 && (NS * R) % 16 == 0;
     // all loads of the stage come before any store: the exchange is in place and one
     // butterfly's outputs land on another butterfly's inputs
     if (LOAD) {
@@ -249,6 +257,11 @@ __device__ __forceinline__ void stockham_stage(float2 *v, float2 *fb, const floa
                 const int c = LPF * u + t * (M / R);
                 v[u * R + t] = fb[SPLIT_LOAD ? pl + c + c / 16 : pad16(l + c)];
             }
+#ifdef STOCKHAM_LOADS_FIRST
+        // (the fused sweep's FFT role: hipcc's scheduler, short of registers next to the IIR role, otherwise issues these
+        // reads one at a time, each behind the multiplication of the value before it -- a full LDS round trip per value)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 #pragma unroll
     for (int u = 0; u < (COMPUTE ? NB : 0); u++) {
@@ -274,6 +287,7 @@ __device__ __forceinline__ void stockham_stage(float2 *v, float2 *fb, const floa
     if (STORE) {
         int sl = 0;                      // per-lane part of the store index
         if (STORE_R16) sl = 17 * l;
+        else if (STORE_R8) sl = 8 * l + l / 2;
         else if (STORE_NS16) sl = (l / NS) * (NS * R + NS * R / 16) + pad16(l % NS);
 #pragma unroll
         for (int u = 0; u < NB; u++) {
@@ -284,7 +298,8 @@ __device__ __forceinline__ void stockham_stage(float2 *v, float2 *fb, const floa
             for (int t = 0; t < R; t++) {
                 int idx;
                 if (STORE_R16) idx = sl + 17 * LPF * u + t;
-                else if (STORE_NS16) idx = sl + u * (LPF / NS) * (NS * R + NS * R / 16) + t * (NS + NS / 16);
+                else if (STORE_R8) idx = sl + u * (8 * LPF + LPF / 2) + t;
+                else if (STORE_NS16) idx = sl + u * (LPF / NS) * (NS * R + NS * R / 16) + t * NS + (t * NS) / 16;
                 else idx = pad16(base + t * NS);
                 fb[idx] = v[u * R + t];
             }

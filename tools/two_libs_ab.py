@@ -12,9 +12,13 @@ from audian_amd.design import butter_sos
 other = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'tools', '_ab', 'libnew.so')
 C = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 secs = float(sys.argv[3]) if len(sys.argv) > 3 else 600.0
-rate, nfft, hop = 96000.0, 2048, 1024
+rate = 96000.0
+# SHAPES="2048:1024,1024:256,256:128": the forward sweep of every listed window, one table per shape (the backward sweep
+# is timed with the first); default: the headline window only
+shapes = [tuple(int(v) for v in p.split(':')) for p in os.environ.get('SHAPES', '2048:1024').split(',')]
+nfft, hop = shapes[0]
 T = int(secs*rate)
-nd = (T + hop - 1)//hop
+nd = max((T + h - 1)//h for _, h in shapes)
 B = ctypes.CDLL(other)
 for name, (args, res) in _lib._SIGNATURES.items():
     fn = getattr(B, name); fn.argtypes = args; fn.restype = res
@@ -29,7 +33,7 @@ ctx = hipdsp.Context(0)
 sos, esos = butter_sos(2, (300.0, 3000.0), 'bandpass', rate), butter_sos(2, 20.0, 'lowpass', rate)
 fplan, eplan = hipdsp.SosPlan(ctx, sos), hipdsp.SosPlan(ctx, esos)
 dx, df, de, de2 = (hipdsp.DeviceArray(ctx, (C, T), np.float32) for _ in range(4))
-ds = hipdsp.DeviceArray(ctx, (C, nd, nfft//2 + 1), np.float32)
+ds = hipdsp.DeviceArray(ctx, (max(C*((T + h - 1)//h)*(n//2 + 1) for n, h in shapes),), np.float32)
 hipdsp.synth(ctx, dx, T, C, T, rate, 7)
 ctx.synchronize()
 vp = ctypes.c_void_p
@@ -40,9 +44,10 @@ for h, tab in ((pf, sos), (pe, esos)):
     tab = np.ascontiguousarray(tab, dtype=np.float64)
     okB(B.hipdsp_sosplan_set(cb, h, vp(tab.ctypes.data), len(tab)))
 P = lambda a: vp(a.ptr)
-fwdA = lambda: hipdsp.chain_forward(ctx, fplan, eplan, dx, T, df, T, C, T, nfft, hop, rate, ds, nd)
+nds = lambda h: (T + h - 1)//h
+fwdA = lambda n=nfft, h=hop: hipdsp.chain_forward(ctx, fplan, eplan, dx, T, df, T, C, T, n, h, rate, ds, nds(h))
 bwdA = lambda: hipdsp.sosfilt_envelope(ctx, fplan, eplan, dx, T, df, T, de, T, C, T, phase=2)
-fwdB = lambda: okB(B.hipdsp_chain_forward(cb, pf, pe, P(dx), T, P(df), T, C, T, 1, np.pi/2, nfft, hop, rate, P(ds), None, nd, 0, 0, 0, 0))     # (a build of ABI 101 ignores the two trailing arguments)
+fwdB = lambda n=nfft, h=hop: okB(B.hipdsp_chain_forward(cb, pf, pe, P(dx), T, P(df), T, C, T, 1, np.pi/2, n, h, rate, P(ds), None, nds(h), 0, 0, 0, 0))     # (a build of ABI 101 ignores the two trailing arguments)
 # SAME_OUT=1: both builds write the same envelope buffer (where a buffer lies in HBM moves the sweep by several per cent,
 # so two output buffers confound the comparison); the identity check then compares a copy taken after A's last run
 same_out = os.environ.get('SAME_OUT', '0') == '1'
@@ -72,3 +77,10 @@ print('largest difference of the two envelopes, relative to the largest value:',
 for k, v in res.items():
     print(f'{k}: median {np.median(v):7.3f} ms  {[round(x, 3) for x in v]}')
 print('A = audian_amd/libhip_dsp.so, B =', other, '| envelopes identical:', same)
+for n, h in shapes[1:]:
+    ra, rb = [], []
+    fwdA(n, h); ctx.synchronize(); fwdB(n, h); syncB()
+    for rnd in range(6):
+        ra.append(timed(lambda: fwdA(n, h), ctx.synchronize)); rb.append(timed(lambda: fwdB(n, h), syncB))
+    print(f'fwd {n}/{h} A: median {np.median(ra):7.3f} ms  {[round(x, 3) for x in ra]}')
+    print(f'fwd {n}/{h} B: median {np.median(rb):7.3f} ms  {[round(x, 3) for x in rb]}')
