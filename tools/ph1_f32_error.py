@@ -51,6 +51,10 @@ signals = {
     '50 Hz hum 1.0 + 1e-3 tone at 1 kHz': np.sin(2*np.pi*50*t) + 1e-3*np.sin(2*np.pi*1000*t),
     '20 kHz 1.0 + 1e-3 tone at 1 kHz': np.sin(2*np.pi*20000*t) + 1e-3*np.sin(2*np.pi*1000*t),
 }
+# a rectified trace whose level steps by 1000 sigma (the envelope's memory then holds the large level while the input is small)
+step = 1e-3*rng.standard_normal(N)
+step[N//2:N//2 + N//8] *= 1000.0
+signals['noise with a 1000 sigma burst'] = step
 bp = butter(2, (300.0, 3000.0), 'bandpass', fs=rate, output='sos')
 lp = butter(2, 20.0, 'lowpass', fs=rate, output='sos')
 for name, x in signals.items():
@@ -64,3 +68,14 @@ for name, x in signals.items():
     ee = inject(lp, r)
     print(f'{name:38s} band-pass: max|y| {ymax:.3e}, error {np.abs(e[skip:len(e)]).max()/ymax:.2e} of it | '
           f'envelope low-pass: max {np.abs(env[skip:]).max():.3e}, error {np.abs(ee[skip:]).max()/np.abs(env[skip:]).max():.2e} of it')
+
+# other envelope cut-offs (the reference's spin box: databrowser.py:545-566), same signals, raw trace rectified
+for fc in (5.0, 500.0):
+    lpc = butter(2, fc, 'lowpass', fs=rate, output='sos')
+    for name, x in signals.items():
+        r = (np.pi/2*np.abs(x.astype(np.float32))).astype(np.float32)
+        env = sosfilt(lpc, r.astype(np.float64))
+        ee = inject(lpc, r)
+        skip = N//4
+        print(f'{name:38s} envelope low-pass {fc:5.0f} Hz of |x|: max {np.abs(env[skip:]).max():.3e}, error {np.abs(ee[skip:]).max()/np.abs(env[skip:]).max():.2e} of it, '
+              f'worst error relative to the LOCAL envelope {np.max(np.abs(ee[skip:])/np.maximum(np.abs(env[skip:len(ee)]), 1e-300)):.2e}')
