@@ -11,6 +11,36 @@ from .design import butter_sos
 
 MIN_FUSED_FRAMES = 8192       # hipdsp_chain_forward / the prefetching sweeps want at least four 2048-sample tiles
 
+# The fused launch must not lose to the launches it replaces (round 4 shipped one that did: 14.7 against 12.4 ms at the
+# reference's default window, bufferedspectrogram.py:14-16).  fusion_costs.json holds both, measured per window and per
+# length of the two cascades at BASELINE configs[2]'s shape (tools/fusion_cost_bench.py, picoseconds per channel-sample);
+# tests/test_gpu_facade.py::test_fused_launch_never_loses re-measures on the box it runs on.
+_FUSION_COSTS = None
+FUSION_MARGIN = 1.0           # the fused launch is taken when it costs at most this times the separate launches
+
+
+def fusion_costs():
+    global _FUSION_COSTS
+    if _FUSION_COSTS is None:
+        import json
+        import os
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'fusion_costs.json')) as f:
+            _FUSION_COSTS = json.load(f)
+    return _FUSION_COSTS
+
+
+def fused_spectrogram_pays(nfft, hop, filter_sections, envelope_sections):
+    """Does hipdsp_chain_forward for this window and these cascades cost no more than the filter's own sweep
+    (hipdsp_sosfilt, or the forward sweep of hipdsp_sosfilt_envelope when an envelope rides along) plus
+    hipdsp_spectrogram?  Shapes the table does not hold: no."""
+    t = fusion_costs()
+    fused = t['fused'].get(f'{nfft}/{hop} {filter_sections}+{envelope_sections}')
+    alone = t['filter'].get(f'{filter_sections}+{envelope_sections}')
+    spec = t['spectrogram'].get(f'{nfft}/{hop}')
+    if fused is None or alone is None or spec is None:
+        return False
+    return fused <= FUSION_MARGIN*(alone + spec)
+
 
 def make_plans(ctx, sos, max_sections):
     """SOS table -> list of device plans of at most `max_sections` sections each.
@@ -135,6 +165,12 @@ class BufferedFilter(BufferedData):
                 env_first = dest._fusable_with(self)
                 if env_first is not None:
                     env = (dest, env_first)
+        if spec is not None:
+            # the cost gate: a fused launch that would be slower than the launches it replaces is not taken (the
+            # envelope's state sweep alone still rides on the filter: hipdsp_sosfilt_envelope, one pass over the slab)
+            n_env = len(env[0].sos) if env is not None else 0
+            if not fused_spectrogram_pays(spec[0].nfft, spec[0].hop, len(self.sos), n_env):
+                spec = None
         if spec is None and env is None:
             return None
         return {'spec': spec, 'env': env, 'done': False}

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_bwd_kernel(const SosPl
                 v2f w[16];
 #pragma unroll
                 for (int i = 0; i < 8; i++) { w[i] = cur_[8 + i]; w[8 + i] = nxt_[i]; }
-                psd_frame_pivot<NFFT, 64, R1, R2, R3, false>(w, fb, tw2, tw3, twn, win, lane, a.scale, true,
+                psd_frame_pivot<NFFT, 64, R1, R2, R3, false>(w, fb, tw2, tw3, twn, win, lane, PsdScale{a.scale, 0.5f * a.scale, 2.f * a.scale}, true,
                                                              bin_sink<false>(oc + f * (long long)F, nullptr, 0), piv, have_piv);
             }
 #pragma unroll
@@ -394,6 +394,7 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan, const hip
     a.c.lead = gs.lead; a.c.env0 = gs.env0; a.frame_off = gs.frame_off;
     a.psd = psd; a.db = db_out; a.psd_pitch = psd_pitch; a.n_valid = n_valid;
     a.scale = (float)(1.0 / (fs * wss));
+    a.scale_half = 0.5f * a.scale; a.scale_twice = 2.f * a.scale;
     a.warm_total = fplan->host->warm;              // the envelope's states are handed over exactly (env_fix_kernel)
     a.debug = ctx->chain_debug;
     a.fault = ctx->fault_dev;
@@ -506,7 +507,19 @@ int hipdsp_chain_backward(hipdsp_ctx *ctx, const hipdsp_sosplan *eplan, const fl
     const long long n_tiles = (frames + edge + TILE - 1) / TILE;
     const long long ckpt_pitch = (n_tiles + 1) * 2 * SE;           // where the forward sweep parked the tile states
     void *work = nullptr;
-    rc = hipdsp_scratch(ctx, sizeof(double) * (size_t)ckpt_pitch * (size_t)channels, &work);
+    // the tile states in the scratch belong to the grid of the forward sweep that left them: this sweep walks the
+    // unshifted grid only (after hipdsp_chain_forward with spec_first / env_first > 0 the states sit
+    // on a grid of frames + lead samples and the odd frames belong elsewhere)
+    if (ctx->sweep_frames != frames || ctx->sweep_channels != channels || ctx->sweep_sections != SE ||
+        ctx->sweep_lead != 0 || ctx->sweep_env0 != 0) {
+        hipdsp_set_error("hipdsp_chain_backward: the last forward sweep on this context left tile states for %lld channels x "
+                         "%lld frames, %d sections, grid shift %lld, envelope from %lld -- not for %lld x %lld, %d on the "
+                         "unshifted grid (hipdsp_chain_forward with spec_first = env_first = 0)",
+                         ctx->sweep_channels, ctx->sweep_frames, ctx->sweep_sections, ctx->sweep_lead, ctx->sweep_env0,
+                         (long long)channels, (long long)frames, SE);
+        return HIPDSP_ERR_INVALID;
+    }
+    rc = hd_scratch_parked(ctx, sizeof(double) * (size_t)ckpt_pitch * (size_t)channels, &work);
     if (rc != HIPDSP_OK) return rc;
     a.b.in = yf; a.b.in_pitch = yf_pitch;
     a.b.out = env; a.b.out_pitch = env_pitch;

@@ -90,6 +90,7 @@ struct ChainArgs {
                               // [n_valid, tail_end) (bufferedspectrogram.py:59) -- a few frames, not worth a launch of their own
     const float *tables;      // tw2 | tw3 | twn | window of the 2048-point PSD kernel (fft_tables)
     float scale;              // 1 / (fs * sum w^2)
+    float scale_half, scale_twice;   // (PsdScale)
     int n_iter;
     long long warm_total;     // band-pass + envelope warm-up samples
     long long units;          // channels * n_seg
@@ -109,6 +110,10 @@ struct ChainArgs {
 // stores of a lane group whose frame does not exist.  Same arithmetic as spec_fast_kernel<NFFT, LPF, R1, R2, R3, ...>.
 struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 
+// 1 / (fs sum w^2) and its half and double, from the host: gfx950's scalar unit has no float arithmetic, so 2 * scale
+// formed in the kernel is a VGPR that lives across the whole tile loop (the 256-sample kernel kept it in scratch)
+struct PsdScale { float one, half, twice; };
+
 // Where a call's bins go: buffer descriptors (SGPRs) whose base is the frame of lane group 0 -- the frames of the other
 // groups of a wave (512- and 256-sample windows: two and four side by side) lie `gstride` bytes further on each.  A bin is
 // then  descriptor + one 32-bit VGPR offset + a compile-time constant, the addressing mode of buffer_store_dword; with
@@ -121,7 +126,11 @@ struct BinSink {
 };
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t bin_rsrc(float *base)
 {
-    return __builtin_amdgcn_make_buffer_rsrc(base, 0, -1, 0x00027000);
+    // (wave-uniform by construction, but hipcc sometimes does the 64-bit arithmetic behind it on the VALU, and a
+    // descriptor in VGPRs costs a waterfall loop around EVERY store: pin it to scalar registers)
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float *>(((unsigned long long)hi << 32) | lo), 0, -1, 0x00027000);
 }
 template <bool DB>
 __device__ __forceinline__ BinSink bin_sink(float *psd0, float *db0, int gstride)
@@ -138,7 +147,7 @@ __device__ __forceinline__ BinSink bin_sink(float *psd0, float *db0, int gstride
 // Hann window is m nfft / 2 in bin 0, -m nfft / 4 in bin 1 and nothing elsewhere).
 template <int NFFT, int LPF, int R1, int R2, int R3, bool DB, class Hook = NoHook>
 __device__ __forceinline__ void psd_frame_core(float2 *v, const float corr, float2 *fb, const float2 *tw2, const float2 *tw3,
-                                               const float2 *twn, int lane, float scale, bool keep,
+                                               const float2 *twn, int lane, const PsdScale scale, bool keep,
                                                const BinSink &out, Hook hook = Hook());
 
 // Detrending by an EXACT mean (round 5).  The IIR wave of the pair has every band-pass output in a float64 register in
@@ -151,7 +160,7 @@ __device__ __forceinline__ void psd_frame_core(float2 *v, const float corr, floa
 // that was 32 reductions per tile and 37 % of the launch).
 template <int NFFT, int LPF, int R1, int R2, int R3, bool DB, class Hook = NoHook>
 __device__ __forceinline__ void psd_frame_mean(const v2f *w, float2 *fb, const float2 *tw2, const float2 *tw3,
-                                               const float2 *twn, const float2 *win, int lane, float scale, bool keep,
+                                               const float2 *twn, const float2 *win, int lane, const PsdScale scale, bool keep,
                                                const BinSink &out, const float2 mean_hc, Hook hook = Hook())
 {
 #pragma clang fp contract(fast)
@@ -185,7 +194,7 @@ __device__ __forceinline__ void psd_frame_mean(const v2f *w, float2 *fb, const f
 
 template <int NFFT, int LPF, int R1, int R2, int R3, bool DB, class Hook = NoHook>
 __device__ __forceinline__ void psd_frame_pivot(const v2f *w, float2 *fb, const float2 *tw2, const float2 *tw3,
-                                          const float2 *twn, const float2 *win, int lane, float scale, bool keep,
+                                          const float2 *twn, const float2 *win, int lane, const PsdScale scale, bool keep,
                                           const BinSink &out, float &piv, bool &have_piv, Hook hook = Hook())
 {
 #pragma clang fp contract(fast)
@@ -251,7 +260,7 @@ __device__ __forceinline__ void psd_frame_pivot(const v2f *w, float2 *fb, const 
 
 template <int NFFT, int LPF, int R1, int R2, int R3, bool DB, class Hook>
 __device__ __forceinline__ void psd_frame_core(float2 *v, const float corr, float2 *fb, const float2 *tw2, const float2 *tw3,
-                                               const float2 *twn, int lane, float scale, bool keep,
+                                               const float2 *twn, int lane, const PsdScale scale, bool keep,
                                                const BinSink &out, Hook hook)
 {
 #pragma clang fp contract(fast)
@@ -282,7 +291,7 @@ __device__ __forceinline__ void psd_frame_core(float2 *v, const float corr, floa
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(val), r, boff + imm, 0, 0);
     };
     float pk_last = 0.f;
-    const v2f hscale2 = {0.5f * scale, 0.5f * scale};
+    const v2f hscale2 = {scale.half, scale.half};
 #pragma unroll
     for (int m = 0; m < PPL / 2; m++) {
         const int k = l + LPF * m;
@@ -306,8 +315,8 @@ __device__ __forceinline__ void psd_frame_core(float2 *v, const float corr, floa
         float pk = pw.x, pm = pw.y;
         if (m == 0) {
             const float dc0 = zk.x + zk.y - corr, ny = zk.x - zk.y;
-            pk = (l == 0) ? dc0 * dc0 * scale : pk;
-            pm = (l == 0) ? ny * ny * scale : pm;
+            pk = (l == 0) ? dc0 * dc0 * scale.one : pk;
+            pm = (l == 0) ? ny * ny * scale.one : pm;
         }
         if (LPF == 64 || keep) {
             st_bin(out.psd, bo_k, 4 * LPF * m, pk);                              // bin k
@@ -319,7 +328,7 @@ __device__ __forceinline__ void psd_frame_core(float2 *v, const float corr, floa
     {
         constexpr int mh = PPL / 2;
         const float2 z = v[(mh % NB3) * R3 + mh / NB3];
-        const float ph = 2.f * scale * fmaf(z.x, z.x, z.y * z.y);
+        const float ph = scale.twice * fmaf(z.x, z.x, z.y * z.y);
         // (bin M / 2 is lane 0's; the other lanes write their last bin once more, under the same instruction)
         const int bo_h = (l == 0) ? bo_k + 4 * (M / 2) : bo_k + 4 * LPF * (PPL / 2 - 1);        // (bo_k is 4 l + the group's frame)
         const float pv = (l == 0) ? ph : pk_last;
@@ -795,10 +804,11 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
         // return out of order: nineteen full waits per frame instead of counted ones, 4 % of the launch at 1024 / 256
         // and 256 / 128 (profiles/r05d_pmc_fwd_libs.txt: same instruction counts, longer launch).  An asm output
         // cannot be rematerialised from memory; at worst it is parked in a VGPR lane.
-        float fscale = a.scale;
+        PsdScale fscale = {a.scale, a.scale_half, a.scale_twice};
         int foff = a.frame_off, fsplit = a.split, fdebug = a.debug, n_iter = a.n_iter;
         int nvalid = (int)a.n_valid;                           // (the host keeps frames_out below 2^31 - 2^16)
-        asm volatile("" : "+s"(fscale), "+s"(foff), "+s"(fsplit), "+s"(fdebug), "+s"(n_iter), "+s"(nvalid));
+        asm volatile("" : "+s"(fscale.one), "+s"(fscale.half), "+s"(fscale.twice), "+s"(foff), "+s"(fsplit), "+s"(fdebug),
+                     "+s"(n_iter), "+s"(nvalid));
         if (!(fdebug & 64)) __builtin_amdgcn_s_setprio(3);
         float2 *fb = fbs[pair];
         const float *tlf = reinterpret_cast<const float *>(tiles[pair]);

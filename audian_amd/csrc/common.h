@@ -114,6 +114,9 @@ static inline bool hd_planar_overlap(const float *a, long long a_pitch, long lon
     HD_REQUIRE(!hd_planar_overlap((a), (ap), (af), (b), (bp), (bf), (channels)), what " must not overlap")
 
 int hipdsp_scratch(hipdsp_ctx *ctx, size_t bytes, void **out);
+// the scratch as a forward sweep left it (tile states of the envelope): for the backward sweeps; HIPDSP_ERR_INVALID when
+// anything has asked for the scratch since (hipdsp_scratch() forgets the sweep's note)
+int hd_scratch_parked(hipdsp_ctx *ctx, size_t bytes, void **out);
 // tw2 | tw3 | twn | window of the three-stage PSD kernel, device memory (spectrogram.hip): served for nfft 2048
 // (radix 16 x 16 x 4), 1024 (8 x 8 x 8), 512 (8 x 8 x 4) and 256 (8 x 4 x 4) -- the sizes chain_fwd_kernel is built for
 int hd_fft_tables(hipdsp_ctx *ctx, int nfft, const float **dev);

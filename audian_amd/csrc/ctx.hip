@@ -219,7 +219,16 @@ int hipdsp_ctx_set_option(hipdsp_ctx *ctx, const char *name, long long value)
     if (strcmp(name, "spec_debug") == 0) { ctx->spec_debug = (int)value; return HIPDSP_OK; }
     if (strcmp(name, "chain_debug") == 0) { ctx->chain_debug = (int)value; return HIPDSP_OK; }
     if (strcmp(name, "sos_no_pin") == 0) { ctx->sos_no_pin = value != 0; return HIPDSP_OK; }
-    if (strcmp(name, "sos_split") == 0) { ctx->sos_split = value != 0; return HIPDSP_OK; }
+    if (strcmp(name, "sos_split") == 0) {
+#ifdef HIPDSP_WITH_ENVSPLIT
+        ctx->sos_split = value != 0;
+        return HIPDSP_OK;
+#else
+        if (value == 0) return HIPDSP_OK;
+        hipdsp_set_error("\"sos_split\": this library was built without envsplit.hip (make SPLIT=1)");
+        return HIPDSP_ERR_UNSUPPORTED;
+#endif
+    }
     if (strcmp(name, "sos_fair") == 0) { ctx->sos_fair = value != 0; return HIPDSP_OK; }
     if (strcmp(name, "sos_trace_rows") == 0) { ctx->sos_trace_rows = value; return HIPDSP_OK; }
     if (strcmp(name, "sos_trace") == 0) {
@@ -363,6 +372,14 @@ int hipdsp_pool_trim(hipdsp_ctx *ctx)
     HD_CHECK_HIP(hipSetDevice(ctx->device));
     HD_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     pool_trim(ctx->pool);
+    // ... and the scratch, which only ever grows (hipdsp_envelope_multi leaves two slabs of the trace's size there:
+    // tens of GB at BASELINE configs[2]) -- unless a captured graph still points into it
+    if (ctx->scratch && ctx->graphs_alive == 0) {
+        HD_CHECK_HIP(hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        ctx->sweep_frames = -1;
+    }
     return HIPDSP_OK;
 }
 
@@ -566,9 +583,25 @@ int hd_seg_flags(hipdsp_ctx *ctx, size_t units, unsigned char **out)
     return HIPDSP_OK;
 }
 
+int hd_scratch_parked(hipdsp_ctx *ctx, size_t bytes, void **out)
+{
+    HD_REQUIRE(ctx != nullptr && out != nullptr, "NULL argument");
+    if (ctx->sweep_frames < 0 || ctx->scratch == nullptr || bytes > ctx->scratch_bytes) {
+        hipdsp_set_error("no forward sweep's tile states are parked in this context's scratch (another call has used the "
+                         "scratch since, or none has run): run the forward sweep again");
+        return HIPDSP_ERR_INVALID;
+    }
+    *out = ctx->scratch;
+    return HIPDSP_OK;
+}
+
 int hipdsp_scratch(hipdsp_ctx *ctx, size_t bytes, void **out)
 {
     HD_REQUIRE(ctx != nullptr && out != nullptr, "NULL argument");
+    // Whoever asks for the scratch is about to write it: tile states a forward sweep parked there are gone (ADVICE
+    // round 4).  The forward sweeps note their grid again right after this call (hd_note_sweep); the backward sweeps,
+    // which READ the parked states, take the pointer through hd_scratch_parked() instead.
+    ctx->sweep_frames = -1;
     if (bytes > ctx->scratch_bytes) {
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
         if (ctx->stream) (void)hipStreamIsCapturing(ctx->stream, &st);

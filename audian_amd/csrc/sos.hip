@@ -964,7 +964,8 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
     const long long n_tiles = (frames + edge + TILE - 1) / TILE;
     const long long ckpt_pitch = (n_tiles + 1) * 2 * SE;     // (+ 1: the state the channel ends with, FloodArgs)
     void *work = nullptr;
-    int rc = hipdsp_scratch(ctx, sizeof(double) * (size_t)ckpt_pitch * (size_t)channels, &work);
+    int rc = phase == 2 ? hd_scratch_parked(ctx, sizeof(double) * (size_t)ckpt_pitch * (size_t)channels, &work)
+                        : hipdsp_scratch(ctx, sizeof(double) * (size_t)ckpt_pitch * (size_t)channels, &work);
     if (rc != HIPDSP_OK) return rc;
     if (phase != 2) {
         CkptArgs fa;
@@ -1040,7 +1041,9 @@ int launch_env_ckpt(hipdsp_ctx *ctx, const SosPlanDev *fdev, const SosPlanDev *e
     long long blocks = (b.units + WPB - 1) / WPB;            // four waves per workgroup: one per SIMD of a CU
     HD_REQUIRE(blocks <= 0x7fffffffLL, "grid too large");
     dim3 grid((unsigned)blocks), block(64 * WPB);
-    if (ctx->sos_split && SE <= 2 && frames >= 4 * TILE) return hd_launch_env_bwd_split(ctx, edev, SE, b);   // (A/B: envsplit.hip)
+#ifdef HIPDSP_WITH_ENVSPLIT
+    if (ctx->sos_split && SE <= 2 && frames >= 4 * TILE) return hd_launch_env_bwd_split(ctx, edev, SE, b);   // (A/B: envsplit.hip, make SPLIT=1)
+#endif
     if (ctx->sos_single_wave_wg) { grid = dim3((unsigned)b.units); block = dim3(64); }
     if (ctx->sos_single_wave_wg && SE == 1 && ctx->sos_prefetch && frames >= 4 * TILE && !ctx->sos_trace && !ctx->sos_no_pin) {
         hipLaunchKernelGGL((env_bwd_kernel<1, true, true, false, 1>), grid, block, 0, ctx->stream, edev, b);   // A/B
@@ -1283,7 +1286,6 @@ int hipdsp_envelope_multi(hipdsp_ctx *ctx, const hipdsp_sosplan *const *plans, i
     void *work = nullptr;
     int rc = hipdsp_scratch(ctx, 2 * slab + sizeof(float) * (size_t)channels, &work);
     if (rc != HIPDSP_OK) return rc;
-    ctx->sweep_frames = -1;                                  // (whatever tile states a forward sweep parked there are gone)
     buf[0] = (float *)work;
     buf[1] = (float *)((char *)work + slab);
     ref = (float *)((char *)work + 2 * slab);

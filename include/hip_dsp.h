@@ -137,7 +137,9 @@ int hipdsp_graph_destroy(hipdsp_ctx *ctx, hipdsp_graph *graph);
  * stream first waits for an event recorded at the free. */
 int hipdsp_malloc(hipdsp_ctx *ctx, size_t bytes, void **dptr);
 int hipdsp_free(hipdsp_ctx *ctx, void *dptr);
-/* Cache statistics (any pointer may be NULL) / give every cached block back to the driver. */
+/* Cache statistics (any pointer may be NULL) / give every cached block back to the driver -- and the context's scratch,
+ * which only grows otherwise (hipdsp_envelope_multi parks two slabs of the trace's size there), unless a captured graph
+ * of the context is alive (it holds the scratch's address). */
 int hipdsp_pool_stats(hipdsp_ctx *ctx, size_t *cached_bytes, uint64_t *hits, uint64_t *misses);
 int hipdsp_pool_trim(hipdsp_ctx *ctx);
 int hipdsp_memset(hipdsp_ctx *ctx, void *dptr, int value, size_t bytes);
@@ -290,8 +292,9 @@ int hipdsp_sosfilt_envelope(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan,
  * sosfilt_zi scaled by the DC gain of the sections in front of it, exactly as sosfilt_zi of the whole table
  * would give.  The hand-over between plans is float32.  Same arguments and errors as hipdsp_envelope
  * (HIPDSP_ERR_TOO_SHORT when frames <= padlen); 56 instead of 16 bytes per sample, two temporaries of
- * (channels, frames + 2 padlen) floats in the context's scratch (which grows to hold them once and keeps its size:
- * like every call that uses the scratch, not between hipdsp_sosfilt_envelope's phases 1 and 2). */
+ * (channels, frames + 2 padlen) floats in the context's scratch (which grows to hold them once and keeps its size
+ * until hipdsp_pool_trim(): like every call that uses the scratch, not between hipdsp_sosfilt_envelope's phases 1
+ * and 2 -- a backward sweep behind it returns HIPDSP_ERR_INVALID, the tile states are gone). */
 int hipdsp_envelope_multi(hipdsp_ctx *ctx, const hipdsp_sosplan *const *plans, int n_plans, const float *x,
                           int64_t x_pitch, float *y, int64_t y_pitch, int64_t channels, int64_t frames,
                           int64_t skip, int rectify, double gain, int clamp);
@@ -343,7 +346,9 @@ int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan,
  * FFT per tile instead of two in the forward sweep (which is bound by VALU issue) and none in the backward
  * sweep (which is not), and move 10 bytes per sample each.  Same psd / frames_out / psd_pitch as the
  * forward call; together the two calls write every frame below n_valid, the forward call the zero tail.
- * Covers envelope plans of one or two decaying sections; HIPDSP_ERR_UNSUPPORTED otherwise. */
+ * Covers envelope plans of one or two decaying sections; HIPDSP_ERR_UNSUPPORTED otherwise.  The forward call behind
+ * it must have walked the unshifted grid (spec_first = env_first = 0, the same channels / frames / sections) and
+ * nothing may have used the context's scratch in between: HIPDSP_ERR_INVALID otherwise. */
 int hipdsp_chain_backward(hipdsp_ctx *ctx, const hipdsp_sosplan *eplan, const float *yf, int64_t yf_pitch,
                           float *env, int64_t env_pitch, int64_t channels, int64_t frames, int rectify,
                           double gain, int clamp, int nfft, int hop, double fs, float *psd,

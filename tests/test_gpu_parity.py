@@ -1218,6 +1218,11 @@ def test_role_split_backward_sweep_is_the_same_envelope(oracle, T, C, env_first)
     rng = np.random.default_rng(T + C)
     x = synth(rng, T, C, rate)
     c = gh.ctx()
+    try:
+        c.set_option('sos_split', 1)
+        c.set_option('sos_split', 0)
+    except NotImplementedError:
+        pytest.skip('library built without envsplit.hip (make -C audian_amd/csrc SPLIT=1)')
     sos = butter_sos(2, (300.0, 3000.0), 'bandpass', rate)
     fplan = hipdsp.SosPlan(c, sos)
     dx = gh.to_planar(c, x)
@@ -1327,6 +1332,51 @@ def test_chain_frame_split_forward_and_backward(oracle, T, max_segments):
             hipdsp.chain_backward(c, eplan, yf, T, ye, T, C, T, 1024, 512, rate, ps, nd)
     finally:
         c.set_max_segments(0)
+        c.set_option('chain_split_frames', 0)
+
+
+def test_backward_sweeps_refuse_tile_states_that_are_not_theirs():
+    """hipdsp_chain_backward walks the unshifted tile grid only -- behind a forward sweep whose grid was
+    moved (spec_first / env_first > 0: the states sit on a grid of frames + lead samples) it must say so instead of
+    reading them with the wrong pitch; and no backward sweep (phase 2 or hipdsp_chain_backward) may run on tile states
+    another call has overwritten in the context's scratch since (here: the long-window spectrogram's work area)."""
+    from audian_amd import hipdsp, _lib
+    from audian_amd.design import butter_sos
+    rate, C, T, nfft, hop = 96000.0, 2, 40000, 2048, 1024
+    rng = np.random.default_rng(5)
+    x = synth(rng, T, C, rate)
+    c = gh.ctx()
+    dx = gh.to_planar(c, x)
+    nd = (T + hop - 1)//hop
+    fplan = hipdsp.SosPlan(c, butter_sos(2, (300.0, 3000.0), 'bandpass', rate))
+    eplan = hipdsp.SosPlan(c, butter_sos(2, 20.0, 'lowpass', rate))
+    yf, ye = (hipdsp.DeviceArray(c, (C, T), np.float32) for _ in range(2))
+    ps = hipdsp.DeviceArray(c, (C, nd, nfft//2 + 1), np.float32)
+    c.set_option('chain_split_frames', 1)
+    try:
+        for kw in ({'spec_first': 300}, {'env_first': 5000}):
+            hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, nfft, hop, rate, ps, nd - 1, **kw)
+            with pytest.raises(ValueError, match='unshifted grid'):       # (HIPDSP_ERR_INVALID)
+                hipdsp.chain_backward(c, eplan, yf, T, ye, T, C, T, nfft, hop, rate, ps, nd)
+        # the right forward sweep, but a call that uses the scratch in between
+        for backward in (lambda: hipdsp.chain_backward(c, eplan, yf, T, ye, T, C, T, nfft, hop, rate, ps, nd),
+                         lambda: hipdsp.sosfilt_envelope(c, fplan, eplan, dx, T, yf, T, ye, T, C, T, phase=2)):
+            hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, nfft, hop, rate, ps, nd)
+            gh.gpu_spectrogram(x, rate, 32768, 16384, 2)       # (long windows work in the scratch of their context)
+            c.reserve(1 << 20)                                  # hipdsp_ctx_reserve: asks for the scratch
+            with pytest.raises(ValueError, match='tile states'):
+                backward()
+            hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, nfft, hop, rate, ps, nd)
+            _lib.check(hipdsp.lib.hipdsp_pool_trim(c.handle))   # gives the scratch back altogether
+            with pytest.raises(ValueError, match='tile states'):
+                backward()
+        # and the pair that belongs together still works, twice over (a backward sweep does not consume the states)
+        hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, nfft, hop, rate, ps, nd)
+        hipdsp.chain_backward(c, eplan, yf, T, ye, T, C, T, nfft, hop, rate, ps, nd)
+        first = ye.to_host()
+        hipdsp.chain_backward(c, eplan, yf, T, ye, T, C, T, nfft, hop, rate, ps, nd)
+        assert np.array_equal(first, ye.to_host())
+    finally:
         c.set_option('chain_split_frames', 0)
 
 
