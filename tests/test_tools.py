@@ -136,3 +136,50 @@ def test_isa_tally_classifies_a_listing(tmp_path):
         assert want in out, (want, out)
     assert 'whole function: 11 instructions' in out
     assert '.LBB0_1: 9' in out
+
+
+# ---- tools/entry_points_gate.py: the regression gate over the per-entry-point timing logs (Missing 2)
+BASE_LOG = '''hipdsp_sosfilt, band-pass of 2 sections (BufferedFilter alone)                    5.528 ms    5335 GB/s
+hipdsp_chain_forward 2048/1024, 2 + 1 sections                                   10.379 ms    4263 GB/s
+hipdsp_chain_forward 256/128, 2 + 1 sections                                     10.683 ms    4152 GB/s
+hipdsp_spectrogram 8192/4096 (BufferedSpectrogram alone)                         11.322 ms    2605 GB/s
+nfft   2048 hop   1024 PSD   :    1.535 ms    4800 GB/s
+some chatter that is not a timing line
+'''
+
+
+def gate(tmp_path, new_text, *args):
+    (tmp_path/'base.log').write_text(BASE_LOG)
+    (tmp_path/'new.log').write_text(new_text)
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'entry_points_gate.py'), str(tmp_path/'base.log'),
+                           str(tmp_path/'new.log'), *args], capture_output=True, text=True)
+
+
+def test_entry_points_gate_flags_a_slower_line_and_nothing_else(tmp_path):
+    # round 4's own step: the fused launch at the reference's default window, 10.68 -> 14.68 ms
+    new = BASE_LOG.replace('10.683 ms    4152', '14.678 ms    3022').replace('5.528 ms', '5.630 ms').replace('11.322 ms', '7.815 ms')
+    r = gate(tmp_path, new)
+    assert r.returncode == 1, r.stdout
+    flagged = [l for l in r.stdout.splitlines() if 'SLOWER' in l]
+    assert len(flagged) == 1 and '256/128' in flagged[0] and '+37.4 %' in flagged[0], r.stdout
+    assert 'faster' in r.stdout and '1 slower than the tolerance' in r.stdout and 'FAILED' in r.stdout
+    # within the tolerance (here 1.8 %): passes; a tighter tolerance catches it
+    ok = BASE_LOG.replace('5.528 ms', '5.630 ms')
+    assert gate(tmp_path, ok).returncode == 0
+    assert gate(tmp_path, ok, '--tol', '0.01').returncode == 1
+    # an accepted regression is written down where the gate runs
+    r = gate(tmp_path, new, '--allow', '256/128=the reason')
+    assert r.returncode == 0 and '[the reason]' in r.stdout and 'allowed' in r.stdout, r.stdout
+
+
+def test_entry_points_gate_lines_that_come_and_go(tmp_path):
+    new = BASE_LOG.replace('hipdsp_spectrogram 8192/4096 (BufferedSpectrogram alone)                         11.322 ms    2605 GB/s\n', '') + \
+        'hipdsp_new_entry_point                                                            1.000 ms    1000 GB/s\n'
+    r = gate(tmp_path, new)
+    assert r.returncode == 0 and 'gone' in r.stdout and 'new ' in r.stdout and '1 missing' in r.stdout, r.stdout
+    assert gate(tmp_path, new, '--strict').returncode == 1
+    # a log without timing lines is an error of its own, not a pass
+    assert gate(tmp_path, 'nothing here\n').returncode == 2
+    # the spec_sizes format (name ends in a colon) is read too
+    r = gate(tmp_path, BASE_LOG.replace('1.535 ms', '1.700 ms'))
+    assert r.returncode == 1 and 'nfft 2048 hop 1024 PSD' in r.stdout, r.stdout
