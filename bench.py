@@ -114,6 +114,9 @@ def parse():
                     help='launcher check without a GPU: every rank joins a gloo process group, one all-reduce, rank 0 '
                          'prints a JSON line with the world size it saw -- tests/test_bench_contract.py uses it to '
                          'cover the self-launch of --gpus N on the CPU')
+    ap.add_argument('--rehearse-legs', action='store_true',
+                    help='the multi-rank bookkeeping of the N > 1 line without a GPU (gloo, host tensors): shards, tile '
+                         'geometry, the all-gathers into the merged tiles, max over ranks, the legs record; no kernel runs')
     ap.add_argument('--no-facade', action='store_true',
                     help='N=1: skip the leg (outside the timed region) that runs the same slab through the drop-in '
                          'surface -- ArrayLoader -> BufferedFilter.update() -> recompute_all() -- and reports '
@@ -481,6 +484,74 @@ class AbiGather:
         self.gctx.pool_trim()
 
 
+def tile_leg_record(name, seconds_of_recording, gb, world, steps, gdt, compute_dt, alone_s):
+    """One entry of legs['tiles']: the K steps with this tile gathered (gdt seconds, max over ranks), without any gather
+    (compute_dt) and the gather alone on the device (alone_s per gather); `gb` = GB of the tile per rank."""
+    return {'seconds_of_recording': seconds_of_recording,
+            'GB_per_rank': round(gb, 3), 'GB_received_per_rank': round(gb*(world - 1), 3),
+            'step_ms': round(gdt/steps*1e3, 4),                          # compute + gather, overlapped
+            'gather_ms': round(alone_s*1e3, 4),                          # the gather alone on the device
+            'gather_exposed_ms': round((gdt - compute_dt)/steps*1e3, 4),
+            'gather_GBps_per_rank_in': round(gb*(world - 1)/alone_s, 1) if world > 1 and alone_s > 0 else None}
+
+
+def rehearse_legs(args):
+    """--rehearse-legs: the N-rank BOOKKEEPING of the multi-GPU line without a GPU (gloo, host tensors) -- channel shards
+    (audian_amd.dist.shard_channels), tile geometry (tile_frames), the all-gather of each tile into the merged
+    (world x channels, frames', F) tensor with every rank's block checked where it must land, max-over-ranks times,
+    the legs' record (tile_leg_record, shared with the timed path) and rank 0's ONE JSON line.  No kernel runs: `value`
+    is null and the line says so.  tests/test_bench_contract.py runs it with eight ranks -- the driver's N = 8 -- which
+    no GPU box of a round may (at most six processes on the card)."""
+    import torch
+    import torch.distributed as dist
+    from audian_amd.dist import shard_channels, tile_frames as n_tile_frames
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29535')
+    os.environ.setdefault('RANK', '0')
+    os.environ.setdefault('WORLD_SIZE', '1')
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    C, T = args.channels, int(round(args.seconds*args.rate))
+    F, nd = args.nfft//2 + 1, (T + args.hop - 1)//args.hop
+    c0, c1 = shard_channels(world*C, rank, world)
+    assert (c0, c1) == (rank*C, rank*C + C), (c0, c1)            # equal shards: what synth()'s c0 / c_total assume
+    tiles = {}
+    for name in ('visible', 'window', 'full'):
+        tf = nd if TILES[name] is None else n_tile_frames(nd, args.rate, args.hop, TILES[name])
+        # every value names its rank, channel and frame: a block that lands in the wrong place is seen
+        ch = torch.arange(c0, c1, dtype=torch.float32).view(C, 1, 1)
+        fr = torch.arange(tf, dtype=torch.float32).view(1, tf, 1)
+        local = (ch*4096.0 + fr).expand(C, tf, F).contiguous()
+        merged = torch.empty((world*C, tf, F), dtype=torch.float32)
+        dist.barrier()
+        t0 = time.perf_counter()
+        k = 2
+        for _ in range(k):
+            dist.all_gather_into_tensor(merged, local)
+        alone = torch.tensor([(time.perf_counter() - t0)/k], dtype=torch.float64)
+        dist.all_reduce(alone, op=dist.ReduceOp.MAX)
+        want = (torch.arange(world*C, dtype=torch.float32).view(-1, 1)*4096.0 + torch.arange(tf, dtype=torch.float32).view(1, -1))
+        ok = torch.tensor([1.0 if torch.equal(merged[:, :, 0], want) and torch.equal(merged[:, :, F - 1], want) else 0.0])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        gb = 4.0*C*tf*F/1e9
+        rec = tile_leg_record(name, TILES[name] if TILES[name] is not None else args.seconds, gb, world, args.steps,
+                              float(alone.item())*args.steps, 0.0, float(alone.item()))
+        rec['frames'] = tf
+        rec['merged_ok_on_every_rank'] = bool(ok.item() == 1.0)
+        tiles[name] = rec
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'Msamples/s spectrogram+bandpass, 64ch x 96kHz', 'value': None, 'unit': 'Msamples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': None, 'higher_is_better': True,
+            'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32 I/O, f64 IIR state', 'data': 'synthetic',
+            'config': {'workload': f'{args.config_name}: {C} ch/GPU x {args.seconds:g} s x {args.rate/1000:g} kHz float32',
+                       'channels_per_gpu': C, 'frames': T, 'spectrogram_frames': nd,
+                       'parallelism': f'channel shard x{world}, all-gather (gloo, host tensors) of the spectrogram tiles'},
+            'legs': {'tile_in_timed_region': args.tile, 'tiles': tiles},
+            'invalid': 'rehearsal of the multi-rank bookkeeping on the CPU: no kernel ran'}), flush=True)
+    dist.destroy_process_group()
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves.  This process has not
     imported torch nor touched HIP (a process that has initialised the GPU must not be replaced or forked into
@@ -544,6 +615,8 @@ def main():
         self_launch(args)                                    # does not return
     if args.rendezvous_only:
         return rendezvous_only(args)
+    if args.rehearse_legs:
+        return rehearse_legs(args)
     # stdout carries exactly ONE line, the JSON result: whatever libraries print on the way (RCCL
     # writes a version banner to stdout when its communicator comes up) goes to stderr instead
     sys.stdout.flush()
@@ -896,14 +969,8 @@ def main():
                     g = main_gather if name == args.tile else make_gatherer(name)
                     gdt = timed_run(g, record=False)          # (without the HIP events of the timed region, like compute_ms)
                     alone_s = g.alone(max(2, min(args.steps, 5)))
-                    gb = tile_gb(name)
-                    legs['tiles'][name] = {
-                        'seconds_of_recording': TILES[name] if TILES[name] is not None else args.seconds,
-                        'GB_per_rank': round(gb, 3), 'GB_received_per_rank': round(gb*(world - 1), 3),
-                        'step_ms': round(gdt/args.steps*1e3, 4),                 # compute + gather, overlapped
-                        'gather_ms': round(alone_s*1e3, 4),                      # the gather alone on the device
-                        'gather_exposed_ms': round((gdt - compute_dt)/args.steps*1e3, 4),
-                        'gather_GBps_per_rank_in': round(gb*(world - 1)/alone_s, 1) if world > 1 else None}
+                    legs['tiles'][name] = tile_leg_record(name, TILES[name] if TILES[name] is not None else args.seconds,
+                                                          tile_gb(name), world, args.steps, gdt, compute_dt, alone_s)
                 except Exception as err:      # a leg must never cost the line of the timed region
                     legs['tiles'][name] = {'failed': f'{type(err).__name__}: {err}'[:300]}
                 if g is not None and g is not main_gather:

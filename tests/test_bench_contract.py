@@ -84,6 +84,53 @@ def test_under_a_launcher_world_size_wins():
     assert json.loads(out.stdout.splitlines()[-1])['n_gpus'] == 1 and 'starting' not in out.stderr
 
 
+def test_eight_rank_bookkeeping_of_the_multi_gpu_line():
+    """the driver's N = 8 bookkeeping -- shard bounds, tile sizes, the all-gather of every tile
+    into the merged tensor, max over ranks, ONE line from rank 0 -- had only ever run with 2 and 3 ranks.  Eight ranks
+    on the CPU (gloo, host tensors; a GPU box of a round may hold six processes at most): no kernel runs, the line says
+    so, everything else is the N = 8 line's shape (bench.py --rehearse-legs, tile_leg_record shared with the timed path)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--config', '3', '--backend', 'gloo',
+                          '--same-device', '--channels', '8', '--seconds', '5', '--rehearse-legs'],
+                         capture_output=True, text=True, env=_no_launcher_env(), timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1, out.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['scaling'] == 'weak' and d['value'] is None and 'no kernel ran' in d['invalid']
+    assert d['config']['channels_per_gpu'] == 8 and 'configs[3]' in d['config']['workload']
+    tiles = d['legs']['tiles']
+    assert set(tiles) == {'visible', 'window', 'full'}
+    nd = (int(5*96000) + 1023)//1024
+    for name, t in tiles.items():
+        assert t['merged_ok_on_every_rank'] is True, (name, t)
+        assert t['gather_GBps_per_rank_in'] is not None and t['gather_GBps_per_rank_in'] > 0, (name, t)
+        assert t['frames'] == nd                     # 5 s of recording: every tile is the whole spectrogram
+        assert abs(t['GB_per_rank'] - 4.0*8*nd*1025/1e9) < 1e-3 and abs(t['GB_received_per_rank'] - 7*4.0*8*nd*1025/1e9) < 1e-2
+        assert t['step_ms'] > 0 and t['gather_ms'] > 0
+
+
+@pytest.mark.gpu
+def test_six_ranks_on_one_gpu_through_the_real_path():
+    """... and the real path with as many ranks as a round's GPU box may hold (six processes on the card): compute on
+    GPU 0 in every rank, the tile gathers over gloo -- N > 3 for the first time through the kernels, the gatherers and
+    the legs."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '6', '--config', '3', '--backend', 'gloo',
+                          '--same-device', '--channels', '4', '--seconds', '20', '--steps', '2', '--warmup', '1'],
+                         capture_output=True, text=True, env=_no_launcher_env(), timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1, out.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 6 and d['scaling'] == 'weak' and d['config']['channels_per_gpu'] == 4
+    assert d['parity_max_rel_err'] < 1e-4 and 'invalid' not in d
+    legs = d['legs']
+    assert legs['compute_ms'] > 0 and set(legs['tiles']) == {'visible', 'window', 'full'}
+    for name in ('visible', 'window'):
+        t = legs['tiles'][name]
+        assert 'failed' not in t, t
+        assert t['gather_GBps_per_rank_in'] is not None and t['GB_received_per_rank'] > 0
+
+
 @pytest.mark.gpu
 def test_one_json_line_with_the_contract_keys():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--seconds', '20', '--steps', '2',
