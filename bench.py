@@ -1063,6 +1063,9 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved/HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_source,
+                         # (the PMC passes cannot run inside the timed command: `traffic` is the committed figure of the
+                         # rocprofv3 --pmc passes of this same command and shape, profiles/pmc_traffic.json)
+                         'traffic_measured_in_this_run': False,
                          'algorithmic_bytes': alg_bytes[dom],
                          'device_copy_GBps': round(copy_gbps, 1),         # float4-per-thread copy kernel (hipdsp_copy_probe)
                          'hipMemcpy_d2d_GBps': round(memcpy_gbps, 1),

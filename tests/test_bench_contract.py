@@ -110,18 +110,18 @@ def test_eight_rank_bookkeeping_of_the_multi_gpu_line():
 
 
 @pytest.mark.gpu
-def test_six_ranks_on_one_gpu_through_the_real_path():
-    """... and the real path with as many ranks as a round's GPU box may hold (six processes on the card): compute on
-    GPU 0 in every rank, the tile gathers over gloo -- N > 3 for the first time through the kernels, the gatherers and
-    the legs."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '6', '--config', '3', '--backend', 'gloo',
+def test_four_ranks_on_one_gpu_through_the_real_path():
+    """... and the real path with as many ranks as a round's GPU box holds next to the test runner (six processes on the
+    card at most, this one among them): compute on GPU 0 in every rank, the tile gathers over gloo -- N > 3 for the
+    first time through the kernels, the gatherers and the legs."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--config', '3', '--backend', 'gloo',
                           '--same-device', '--channels', '4', '--seconds', '20', '--steps', '2', '--warmup', '1'],
                          capture_output=True, text=True, env=_no_launcher_env(), timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = out.stdout.splitlines()
     assert len(lines) == 1, out.stdout[:2000]
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 6 and d['scaling'] == 'weak' and d['config']['channels_per_gpu'] == 4
+    assert d['n_gpus'] == 4 and d['scaling'] == 'weak' and d['config']['channels_per_gpu'] == 4
     assert d['parity_max_rel_err'] < 1e-4 and 'invalid' not in d
     legs = d['legs']
     assert legs['compute_ms'] > 0 and set(legs['tiles']) == {'visible', 'window', 'full'}
