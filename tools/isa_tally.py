@@ -41,6 +41,10 @@ for l in lines[start + 1:end]:
         continue
     parts = t.split(None, 1)
     cur[cls(parts[0], parts[1] if len(parts) > 1 else '')] += 1
+    if parts[0].startswith(('s_cbranch', 's_branch')):
+        # a branch ends a basic block although the fall-through path carries no label (round 5: a once-per-sweep
+        # selection loop behind `s_cbranch_scc1` read as part of the per-tile block in front of it)
+        blocks.append((name, cur)); cur, name = collections.Counter(), name.rstrip('+') + '+'
 blocks.append((name, cur))
 total = collections.Counter()
 for n, c in blocks: total.update(c)
