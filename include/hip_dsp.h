@@ -379,7 +379,13 @@ int hipdsp_chain_backward_plan(hipdsp_ctx *ctx, const hipdsp_sosplan *eplan, int
  * specitem.py:36) in the same layout.  nfft: any power of two in [8, 524288] (the reference's
  * nfft selector, databrowser.py:516; 65536 in the registers of one workgroup, 131072 of two, 262144 and 524288 as tasks of one or two passes of such a workgroup)
  * and, for the values the reference's clamp to len(source)//2 can produce, any other size up
- * to 131072 (direct DFT, O(nfft^2), meant for the rare short recording). */
+ * to 131072 (direct DFT, O(nfft^2), meant for the rare short recording).
+ * nfft 262144 and 524288 (windows of 2.7 and 5.5 s at 96 kHz) are covered, not streamed: NOT roofline kernels --
+ * every task re-reads the frame and the first pass parks its points in `out` and reads them back (4.8 x / 8.1 x the
+ * algorithmic bytes, 0.6 / 0.4 TB/s).  For these two sizes `out` is therefore also a WORK AREA while the call runs:
+ * ordinary device memory, nobody else reading or writing it until the call has completed on the context's stream.
+ * nfft 131072 has the two workgroups of a frame own interleaved bins (one radix-2 step in front of the transform):
+ * they share every 32-byte sector of the output, 1.1 x the algorithmic bytes for the PSD, 1.4 x with db_out. */
 int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pitch, int64_t channels,
                        int64_t frames, int nfft, int hop, double fs, float *out,
                        float *db_out, int64_t frames_out, int64_t out_pitch);
