@@ -123,6 +123,8 @@ struct PsdScale { float one, half, twice; };
 struct BinSink {
     __amdgpu_buffer_rsrc_t psd, db;
     int gstride;
+    int soff;                 // bytes from the descriptors' base to lane group 0's frame of THIS call (wave-uniform: the
+                              // store instruction's scalar offset -- the descriptors themselves are built once per tile)
 };
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t bin_rsrc(float *base)
 {
@@ -139,8 +141,10 @@ __device__ __forceinline__ BinSink bin_sink(float *psd0, float *db0, int gstride
     k.psd = bin_rsrc(psd0);
     k.db = bin_rsrc(DB ? db0 : psd0);
     k.gstride = gstride;
+    k.soff = 0;
     return k;
 }
+__device__ __forceinline__ BinSink bin_at(BinSink k, int soff) { k.soff = soff; return k; }
 
 // The transform behind the window: v = the frame's detrended, windowed values (value t of a lane), corr = what the split
 // step still has to take out of bins 0 and 1 (half the sum of what the detrending left: a residual mean m under the periodic
@@ -287,8 +291,9 @@ __device__ __forceinline__ void psd_frame_core(float2 *v, const float corr, floa
     int bo_k = 4 * l + gframe, bo_m = 4 * (M - l - LPF * (PPL / 2 - 1)) + gframe;
     asm volatile("" : "+v"(bo_k), "+v"(bo_m));
     bo_k &= 0xfffc; bo_m &= 0xfffc;
-    auto st_bin = [](__amdgpu_buffer_rsrc_t r, int boff, int imm, float val) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(val), r, boff + imm, 0, 0);
+    const int soff = out.soff;
+    auto st_bin = [soff](__amdgpu_buffer_rsrc_t r, int boff, int imm, float val) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(val), r, boff + imm, soff, 0);
     };
     float pk_last = 0.f;
     const v2f hscale2 = {scale.half, scale.half};
@@ -874,6 +879,12 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             if (active) {
                 const int t = tt;
                 if (tt >= lo_t && tt < hi_ceil_t) {            // the unit that owns the tile writes its frames
+                  // where the tile's frames go: descriptors based at the frame that ends HOP samples into the tile (number
+                  // t FPT + 1 - NFFT / HOP - foff of the output; below zero in the first tile: never stored through), once
+                  // per tile -- a frame is then a compile-time scalar offset of the store instruction, a lane group's
+                  // frame (512- and 256-sample windows) a part of the lane's own offset
+                  const long long f0 = (long long)(t * FPT + 1 - NFFT / HOP - foff) * F;
+                  const BinSink tsink = bin_sink<DB>(oc + f0, dc + f0, (G == 4 ? 16 : 4) * F);
                   if (!(fdebug & 1)) {
                    if constexpr (G == 4) {
                     const int gq = lane >> 4;
@@ -886,11 +897,9 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                             v2f w[8];
 #pragma unroll
                             for (int i = 0; i < 8; i++) w[i] = bb_[4 * q + i];
-                            // (the descriptor's base is group 0's frame, the others lie four frames further on each)
-                            const long long f0 = (long long)(t * FPT + q + 1 - NFFT / HOP - foff) * F;
+                            // (the descriptors' base is the tile's frame 0, group gq's frame lies 4 gq + q frames further on)
                             psd_frame_mean<NFFT, LPF, R1, R2, R3, DB>(w, fb + gq * MP, tw2, tw3, twn, win, lane, fscale, keep,
-                                                                      bin_sink<DB>(oc + f0, dc + f0, 16 * F),
-                                                                      fmeans[it & 1][pair][4 * gq + q]);
+                                                                      bin_at(tsink, 4 * F * q), fmeans[it & 1][pair][4 * gq + q]);
                         }
                     }
                    } else {
@@ -908,13 +917,11 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                                     STAMP_AT(10);                  // (between the frames)
                                     auto hook = [&](int n) { STAMP_AT(11 + n); };
                                     psd_frame_mean<NFFT, LPF, R1, R2, R3, DB>(w, fb, tw2, tw3, twn, win, lane, fscale, true,
-                                                                              bin_sink<DB>(oc + f * (long long)F, dc + f * (long long)F, 0),
-                                                                              fmeans[it & 1][pair][m], hook);
+                                                                              bin_at(tsink, 4 * F * m), fmeans[it & 1][pair][m], hook);
                                     STAMP_AT(15);                  // split step, PSD, stores
                                 } else {
                                     psd_frame_mean<NFFT, LPF, R1, R2, R3, DB>(w, fb, tw2, tw3, twn, win, lane, fscale, true,
-                                                                              bin_sink<DB>(oc + f * (long long)F, dc + f * (long long)F, 0),
-                                                                              fmeans[it & 1][pair][m]);
+                                                                              bin_at(tsink, 4 * F * m), fmeans[it & 1][pair][m]);
                                 }
                             }
                         } else {
@@ -938,8 +945,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                                     w[2 * u + 1] = (v2f){__int_as_float(rx[1]), __int_as_float(ry[1])};
                                 }
                                 psd_frame_mean<NFFT, LPF, R1, R2, R3, DB>(w, fb + gq * MP, tw2, tw3, twn, win, lane, fscale, keep,
-                                                                          bin_sink<DB>(oc + fa * (long long)F, dc + fa * (long long)F, 4 * F),
-                                                                          fmeans[it & 1][pair][m + gq]);
+                                                                          bin_at(tsink, 4 * F * m), fmeans[it & 1][pair][m + gq]);
                             }
                         }
                     }
