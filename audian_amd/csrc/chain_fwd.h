@@ -9,6 +9,7 @@
 #pragma once
 #include "sos_device.h"
 // (STOCKHAM_LOADS_FIRST: a window's own translation unit may define it -- fft_device.h, stockham_stage)
+#define STOCKHAM_SPLIT_MORE
 #include "fft_device.h"
 #include <cmath>
 

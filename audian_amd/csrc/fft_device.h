@@ -244,8 +244,16 @@ __device__ __forceinline__ void stockham_stage(float2 *v, float2 *fb, const floa
     //   NS == 1, R == 8:  pad16(8 j + t) = 8 j + j / 2 + t                                       (t < 8)
     //   NS | 16 or 16 | NS, NS | LPF, 16 | NS R:  k = l % NS and j / NS = l / NS + u LPF / NS, and the pad of
     //   (k + t NS) is that of t NS alone (k < NS does not reach the next multiple of NS)
+    // (STOCKHAM_SPLIT_MORE: the fused sweep's translation units only -- in the stand-alone PSD kernels the two new forms
+    // bought 2.8 % without the dB image and cost 12 % with it at nfft 1024, profiles/r05w_entry_points_gate.log: their
+    // register allocation is not this header's to disturb)
+#ifdef STOCKHAM_SPLIT_MORE
     constexpr bool STORE_R8 = NS == 1 && R == 8 && LPF % 2 == 0;
     constexpr bool STORE_NS16 = NS > 1 && (NS % 16 == 0 || 16 % NS == 0) && LPF % NS == 0 && (NS * R) % 16 == 0;
+#else
+    constexpr bool STORE_R8 = false;
+    constexpr bool STORE_NS16 = NS % 16 == 0 && LPF % NS == 0;           // k, j/NS split by lane
+#endif
     // all loads of the stage come before any store: the exchange is in place and one
     // butterfly's outputs land on another butterfly's inputs
     if (LOAD) {
