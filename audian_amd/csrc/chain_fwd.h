@@ -595,6 +595,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
 #define CASC_CARRY cf_
 #define CASC_IN(v) (v)
 #define CASC_ROLLED_GROUPS
+#define CASC_UNIT_OK (SF <= 2)
 #define CASC_STAMP(n) STAMP_AT(1 + (n))
 #define CASC_TAP(j, e, y)                                                               \
     do {                                                                                \
@@ -609,6 +610,7 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
 #include "sos_cascade.inc"
 #undef CASC_TAP
 #undef CASC_STAMP
+#undef CASC_UNIT_OK
 #undef CASC_ROLLED_GROUPS
 #undef CASC_S
 #undef CASC_PLAN

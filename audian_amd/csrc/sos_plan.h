@@ -20,6 +20,11 @@ struct SosPlanDev {
     long long warm;                 // warm-up samples, multiple of TILE
     int n_sections;
     int edge;                       // sosfiltfilt pad length
+    // scipy's Butterworth designs (butter(..., output='sos'): bufferedfilter.py:44-52, bufferedenvelope.py:47-52) put the
+    // gain into the first section and leave every other numerator at exactly [1, +-2, 1]: for those sections phase 3 runs
+    // y = x + z0; z0 = b1 x + z1 - a1 y; z1 = x - a2 y -- four operations per sample instead of five (the products with
+    // b0 = b2 = 1 are the operand itself).  Non-zero: every section behind the first is of that form.
+    int unit_tail;
 };
 
 // plan block from an SOS table (scipy layout, a0 == 1): HIPDSP_OK or an error with the message set

@@ -76,6 +76,9 @@ int fill_plan(SosPlanDev *p, const double *sos, int S)
         p->coef[s][0] = c[0]; p->coef[s][1] = c[1]; p->coef[s][2] = c[2];
         p->coef[s][3] = c[4]; p->coef[s][4] = c[5];
     }
+    p->unit_tail = S > 1 ? 1 : 0;
+    for (int s = 1; s < S; s++)
+        if (!(p->coef[s][0] == 1.0 && p->coef[s][2] == 1.0 && fabs(p->coef[s][1]) == 2.0)) p->unit_tail = 0;
     // state-space (A, B): columns of A from unit states with zero input, B from unit input
     Mat A = mat_identity(D);
     double B[MAXD] = {0};
