@@ -1335,6 +1335,81 @@ def test_chain_frame_split_forward_and_backward(oracle, T, max_segments):
         c.set_option('chain_split_frames', 0)
 
 
+@pytest.mark.parametrize('T,max_segments', [(70001, 0), (300000, 3)])
+def test_cascades_whose_numerators_are_not_scipys_take_the_general_phase_3(oracle, T, max_segments):
+    """Round 5: sections behind the first whose numerator is exactly [1, +-2, 1] -- every Butterworth design of scipy --
+    run a four-operation phase 3 (SosPlanDev::unit_tail); any other table takes the general five-operation loop, which
+    the Butterworth-only suite would no longer reach for cascades of two and more sections.  The same transfer function
+    with its gain spread differently over the sections (not unit any more), and a table that is no Butterworth design at
+    all: through hipdsp_sosfilt, hipdsp_envelope, hipdsp_sosfilt_envelope and hipdsp_chain_forward (which covers general
+    numerators for one and two band-pass sections), against the oracle and against the unit-form run."""
+    from audian_amd import hipdsp
+    from audian_amd.design import butter_sos
+    rate, C, nfft, hop = 48000.0, 2, 1024, 256
+    rng = np.random.default_rng(T)
+    x = synth(rng, T, C, rate)
+    c = gh.ctx()
+    nd, F = (T + hop - 1)//hop, nfft//2 + 1
+
+    def spread(sos):                                  # the same filter, gain moved between the sections
+        t = np.array(sos, dtype=np.float64)
+        for i in range(1, len(t)):
+            t[0, :3] *= 1.0/(1.5 + i)
+            t[i, :3] *= 1.5 + i
+        return t
+    for order in (2, 3, 4):
+        unit = butter_sos(order, (300.0, 3000.0), 'bandpass', rate)
+        for sos in (spread(unit), unit*np.array([1, 1, 1, 1, 0.999, 0.998])):   # (the second: poles moved, no design of anybody's)
+            want = oracle.sosfilt(sos, x.astype(np.float64))
+            got = gh.gpu_sosfilt(sos, x, max_segments=max_segments)
+            for ch in range(C):
+                assert rel_err(got[:, ch], want[:, ch]) < TOL, (order, ch)
+    # the envelope: a low-pass of order 4 (two sections) with the gain spread, both sweeps
+    eunit = butter_sos(4, 300.0, 'lowpass', rate)
+    esos = spread(eunit)
+    sos = spread(butter_sos(2, (300.0, 3000.0), 'bandpass', rate))
+    filt = oracle.sosfilt(sos, x.astype(np.float64))
+    yf32 = gh.gpu_sosfilt(sos, x).astype(np.float32)
+    want_e = np.zeros((T, C))
+    oracle.envelope_process(esos, yf32.astype(np.float64), want_e, 0)
+    got_e = gh.gpu_envelope(esos, yf32, max_segments=max_segments)
+    ref_e = gh.gpu_envelope(eunit, yf32, max_segments=max_segments)
+    for ch in range(C):
+        assert rel_err(got_e[:, ch], want_e[:, ch]) < TOL and rel_err(got_e[:, ch], ref_e[:, ch]) < 1e-5, ch
+    # the fused launches with general numerators in both cascades (two band-pass sections: the general loop; the unit run next to it)
+    c.set_max_segments(max_segments)
+    try:
+        dx = gh.to_planar(c, x)
+        outs = []
+        for fs_, es_ in ((sos, esos), (butter_sos(2, (300.0, 3000.0), 'bandpass', rate), eunit)):
+            fplan, eplan = hipdsp.SosPlan(c, fs_), hipdsp.SosPlan(c, es_)
+            yf, ye = (hipdsp.DeviceArray(c, (C, T), np.float32) for _ in range(2))
+            ps = hipdsp.DeviceArray(c, (C, nd, F), np.float32)
+            hipdsp.chain_forward(c, fplan, eplan, dx, T, yf, T, C, T, nfft, hop, rate, ps, nd)
+            hipdsp.sosfilt_envelope(c, fplan, eplan, dx, T, yf, T, ye, T, C, T, phase=2)
+            outs.append((yf.to_host(), ye.to_host(), ps.to_host()))
+            y2, e2 = (hipdsp.DeviceArray(c, (C, T), np.float32) for _ in range(2))
+            hipdsp.sosfilt_envelope(c, fplan, eplan, dx, T, y2, T, e2, T, C, T)          # sos_ckpt_kernel + env_bwd_kernel
+            assert np.array_equal(y2.to_host(), outs[-1][0])
+            for ch in range(C):
+                assert rel_err(e2.to_host()[ch], outs[-1][1][ch]) < 2e-6, ch
+        (gf, ge, gs), (uf, ue, us) = outs
+        want_s = np.zeros((nd, C, F))
+        oracle.spectrogram_process(gf.T.astype(np.float64), want_s, rate, nfft, hop)
+        want_env = np.zeros((T, C))
+        oracle.envelope_process(esos, gf.T.astype(np.float64), want_env, 0)
+        for ch in range(C):
+            assert rel_err(gf[ch], filt[:, ch]) < TOL and rel_err(gf[ch], uf[ch]) < 1e-5, ch
+            assert rel_err(ge[ch], want_env[:, ch]) < TOL and rel_err(ge[ch], ue[ch]) < 1e-4, ch
+            for j in range(nd):
+                if np.max(np.abs(want_s[j, ch])) == 0:
+                    assert np.all(gs[ch, j] == 0)
+                else:
+                    assert rel_err(gs[ch, j], want_s[j, ch]) < TOL, (j, ch)
+    finally:
+        c.set_max_segments(0)
+
+
 def test_backward_sweeps_refuse_tile_states_that_are_not_theirs():
     """hipdsp_chain_backward walks the unshifted tile grid only -- behind a forward sweep whose grid was
     moved (spec_first / env_first > 0: the states sit on a grid of frames + lead samples) it must say so instead of
