@@ -329,7 +329,10 @@ int hipdsp_envelope_multi(hipdsp_ctx *ctx, const hipdsp_sosplan *const *plans, i
  * hipdsp_sosfilt_envelope(..., phase = 2, env_first) belong to that envelope).  Any 0 <= spec_first, env_first <=
  * frames; the sweep shifts its tile grid (by less than one tile of zeros in front of the trace) so that frames stay
  * register windows of its tiles, and the tile the envelope starts in holds the odd extension in front of sample
- * env_first and the extension's first value in front of that, for which zi * value is the cascade's steady state. */
+ * env_first and the extension's first value in front of that, for which zi * value is the cascade's steady state.
+ * The sweep counts tiles and frames in 32 bits: frames_out < 2^31 - 65536 (HIPDSP_ERR_INVALID beyond; a spectrogram of
+ * that many frames is terabytes).  The spectrogram's frame means come from the band-pass's own float64 arithmetic (the
+ * reference's float64 mean, detrend='constant'), not from a float32 sum. */
 int hipdsp_chain_forward(hipdsp_ctx *ctx, const hipdsp_sosplan *fplan,
                          const hipdsp_sosplan *eplan, const float *x, int64_t x_pitch, float *yf,
                          int64_t yf_pitch, int64_t channels, int64_t frames, int rectify,
