@@ -350,6 +350,9 @@ __device__ __forceinline__ void psd_frame_core(float2 *v, const float corr, floa
 #define FPT_OK(hop, g) ((2048 / (hop)) % (g) == 0)
 // NFFT / HOP: the window lengths whose frames are register windows of a tile -- 2048 or 1024 samples, hops
 // that divide the tile and are multiples of 128 samples (one register of the FFT wave's tile copy).
+#ifndef CHAIN_FFT_STORES
+#define CHAIN_FFT_STORES 1
+#endif
 template <int SF, int SE, int NP, bool FLAGS, bool DB, int NFFT = 2048, int HOP = 1024, bool STAMP = false>
 __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPlanDev *__restrict__ PF0,
                                                                    const SosPlanDev *__restrict__ PE0, ChainArgs a)
@@ -369,6 +372,11 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
     static_assert(FPT_OK(HOP, G), "whole groups of frames per tile");
     constexpr int FPT = TILE / HOP;             // frames that END inside a tile (a multiple of G)
     constexpr int PREV = (NFFT - HOP) / 128;    // registers of the previous tile a frame can reach back into
+    // Who writes an interior tile of the filtered trace to HBM: the FFT wave, out of the sixteen registers it has just
+    // copied the tile into (round 5) -- the IIR wave, the pair's critical path (tools/chain_stamps.py), read the tile
+    // back from LDS through the one register quad it had left, eight reads and eight stores one after the other.
+    // Border tiles (segment ends, the `lead` samples) stay with the IIR wave and its bounds.
+    constexpr bool FFT_STORES = CHAIN_FFT_STORES && FLAGS && G != 4;
     __shared__ float4 tiles[NP][64 * 8];
     __shared__ float rprevs[NP][64];
     __shared__ float2 fbs[NP][G * MP];
@@ -636,7 +644,11 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
             WAVE_SYNC();
             if (FLAGS) { if (active) CHAIN_POST(ready, it + 1); }
             else __syncthreads();                              // B1: the tile holds the filtered samples
-            if (active && tt >= lo_t && tt < hi_full_t && tt >= lead_t) {
+            if (FFT_STORES && active && tt >= lo_t && tt < hi_full_t && tt >= lead_t) {
+                // interior tile, stored by the FFT wave: only the prefetch is in flight
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                STAMP_AT(4);
+            } else if (active && tt >= lo_t && tt < hi_full_t && tt >= lead_t) {
                 // interior tile: exactly 8 vector stores, then the counted wait
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
@@ -823,6 +835,8 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
         const float2 *tw2 = tab, *tw3 = tab + TW2, *twn = tab + TW2 + TW3, *win = tab + TW2 + TW3 + TWN;
         float *oc = a.psd + ch * a.psd_pitch;
         float *dc = DB ? a.db + ch * a.psd_pitch : nullptr;
+        float *yfc = a.c.yf + ch * a.c.yf_pitch;
+        const int st_lo_t = lo_t > lead_t ? lo_t : lead_t;
         // the tile as 16 registers (register j: samples 128 j + 2 lane, + 1) and the last PREV registers of the
         // tile before it: frame m of a tile (the one that ends (m + 1) HOP samples into it) is the window of
         // PPL consecutive registers that starts at register ((m + 1) HOP - NFFT) / 128 of the two
@@ -878,6 +892,13 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                 if (active && !withhold) CHAIN_POST(taken, it + 1);
             }
             else __syncthreads();                              // B2
+            if constexpr (FFT_STORES) {
+                if (active && tt >= st_lo_t && tt < hi_full_t) {
+                    float *dst = yfc + (long long)tt * TILE + 2 * lane;
+#pragma unroll
+                    for (int j = 0; j < 16; j++) *reinterpret_cast<v2f *>(dst + 128 * j) = cur_[j];
+                }
+            }
             STAMP_AT(9);                                       // tile copied, hand-over posted
             if (active) {
                 const int t = tt;

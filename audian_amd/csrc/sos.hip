@@ -220,9 +220,11 @@ __global__ __launch_bounds__(64 * WPB) void sos_ckpt_kernel(const SosPlanDev *__
             if (tile + TILE > lo && tile < hi) {
                 if (tile >= lo && tile + TILE <= hi && tile >= lead) {
                     // interior tile: exactly 8 vector stores, then the counted wait
+                    v4f rows[8];
+                    tile_rows_from_lds(lds, lane, rows);
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
-                        const float4 v = lds[lds_slot(8 * k + (lane >> 3), lane & 7)];
+                        const v4f v = rows[k];
                         f4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
                         *reinterpret_cast<f4u *>(yf + tile + 256 * k + 4 * lane) = t;
                     }
@@ -785,18 +787,20 @@ __global__ __launch_bounds__(64 * WPB_, REGW ? 2 : 1) void env_bwd_kernel(const 
             if (tile >= a.skip && tile + TILE <= T) {
                 // interior tile: exactly 8 vector stores (max(x, 0) as one instruction: fmaxf() costs a second one
                 // that only quiets signalling NaNs)
+                v4f rows[8];
+                tile_rows_from_lds(lds, lane, rows);
                 if (a.clamp) {
                     const long long tdst = (a.debug & 1) ? a.skip : tile;
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
-                        const float4 v = lds[lds_slot(8 * k + (lane >> 3), lane & 7)];
+                        const v4f v = rows[k];
                         f4u t; t.x = max_zero(v.x); t.y = max_zero(v.y); t.z = max_zero(v.z); t.w = max_zero(v.w);
                         *reinterpret_cast<f4u *>(out + (tdst + 256 * k + 4 * lane - a.skip)) = t;
                     }
                 } else {
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
-                        const float4 v = lds[lds_slot(8 * k + (lane >> 3), lane & 7)];
+                        const v4f v = rows[k];
                         f4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
                         *reinterpret_cast<f4u *>(out + (tile + 256 * k + 4 * lane - a.skip)) = t;
                     }

@@ -249,6 +249,19 @@ inline GridShift hd_grid_shift(long long spec_first, long long env_first, int ho
 // 16-byte global load the compiler does not track: the caller counts vmcnt by hand, so that the
 // wait for a prefetched tile does not also wait for the stores issued after it.
 typedef float v4f __attribute__((ext_vector_type(4)));
+// The lane's eight float4 of a tile in LDS (row 8 k + lane / 8, quarter lane % 8: 1 KB of the trace per k), ALL read
+// before anything is done with them: left to itself hipcc takes them one at a time through a single register quad --
+// ds_read, s_waitcnt lgkmcnt(0), global_store, eight times over: eight LDS latencies in a row per tile and wave
+// (round 5, the sweeps' store sequences in tools/isa_block.py).  The empty asm needs all of them in registers at once.
+__device__ __forceinline__ void tile_rows_from_lds(const float4 *lds, int lane, v4f (&v)[8])
+{
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float4 t = lds[lds_slot(8 * k + (lane >> 3), lane & 7)];
+        v[k] = (v4f){t.x, t.y, t.z, t.w};
+    }
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
 typedef double v2d __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v4f asm_load16(const void *p)
 {
