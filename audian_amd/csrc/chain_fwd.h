@@ -896,7 +896,10 @@ __global__ __launch_bounds__(128 * NP, NP / 2) void chain_fwd_kernel(const SosPl
                 if (active && tt >= st_lo_t && tt < hi_full_t) {
                     float *dst = yfc + (long long)tt * TILE + 2 * lane;
 #pragma unroll
-                    for (int j = 0; j < 16; j++) *reinterpret_cast<v2f *>(dst + 128 * j) = cur_[j];
+                    for (int j = 0; j < 16; j++) {             // (x and yf are shifted by -lead: 4-byte alignment only)
+                        f2u t; t.x = cur_[j].x; t.y = cur_[j].y;
+                        *reinterpret_cast<f2u *>(dst + 128 * j) = t;
+                    }
                 }
             }
             STAMP_AT(9);                                       // tile copied, hand-over posted

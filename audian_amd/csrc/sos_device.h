@@ -66,6 +66,7 @@ namespace {
 
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte aligned float4
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));   // 4-byte aligned float2
 
 struct SeqArgs {
     const float *in;        // channel 0 of the input
