@@ -140,7 +140,8 @@ __global__ __launch_bounds__(64 * WAVES, (NFFT <= 2048 ? (DB ? 2 : 3) : 1) * WAV
     // sets rotate by two quarters per frame: each sample is requested once instead of twice (PMC: 22.1 GB ->
     // 14.8 GB read per launch).  REUSE = 4 (hop == NFFT/4, the 75 % overlap of BASELINE configs[1]): the sets
     // rotate by one quarter and one quarter is fetched -- once instead of four times.
-    constexpr bool EARLY_PF = !DB;             // the dB epilogue needs the registers (it would spill)
+    // (the dB epilogue needs the registers of the long windows: it would spill; 512 and the 1024 without register reuse have them)
+    constexpr bool EARLY_PF = !DB || REUSE == 4;
     static_assert(R1 % 4 == 0, "quarters of the first radix");
     constexpr int R1Q = R1 / 4;
     constexpr int QP = PPL / 4;                            // points per quarter
@@ -1291,9 +1292,19 @@ extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pit
             return run_pack<256, 16, 8, 4, 4>(ctx, x, x_pitch, channels, frames, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
         case 512:
             if (want == 2) return run_fast2<512, 16, 16, 16, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
-            return run_fast<512, 32, 8, 8, 4, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+            // the stream through LDS as well (round 5: with the dB image 13 % ahead at 50 % overlap, 27 % at 75 %, 36 % at hop 100;
+            // profiles/r05at_spec_kernel_ab.log) -- except for the PSD alone at 50 % overlap, where the kernel it replaces ("spec_kernel"
+            // 3) is 5 % ahead
+            if (want == 3 || (want == 0 && db_out == nullptr && 2 * hop == nfft))
+                return run_fast<512, 32, 8, 8, 4, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+            return run_pack<512, 32, 8, 8, 4>(ctx, x, x_pitch, channels, frames, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
         case 1024:
             if (want == 2) return run_fast2<1024, 16, 32, 16, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
+            // with the dB image and a hop the register reuse does not cover (neither nfft / 2 nor nfft / 4): the stream through
+            // LDS, whose staged 16-byte stores carry both images (hop 100: 12.2 -> 8.7 ms, hop 700: 1.74 -> 1.53, hop = nfft:
+            // 1.32 -> 1.24 at 64 ch x 120 s; without the dB image it loses 3-20 %: profiles/r05at_spec_kernel_ab.log); "spec_kernel" 3
+            if (want == 3 || (want == 0 && db_out != nullptr && 2 * hop != nfft && 4 * hop != nfft))
+                return run_pack<1024, 64, 8, 8, 8>(ctx, x, x_pitch, channels, frames, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
             return run_fast<1024, 64, 8, 8, 8, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
         case 2048:
             if (want == 2) return run_fast2<2048, 32, 32, 32, 8>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);

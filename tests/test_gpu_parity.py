@@ -297,9 +297,10 @@ def test_spectrogram_fast_and_generic_vs_oracle(oracle, nfft, hop):
                     assert rel_err(res[j, ch], want[j, ch]) < TOL, (nfft, hop, j, ch)
 
 
-@pytest.mark.parametrize('nfft', [8, 16, 32, 64, 128, 256])
+@pytest.mark.parametrize('nfft', [8, 16, 32, 64, 128, 256, 512, 1024])
 def test_short_windows_stream_runs_of_frames_through_lds(oracle, nfft):
-    """nfft 8 ... 256 (the reference's default is 256 / 128; its selector starts at 8, databrowser.py:516): a wave
+    """nfft 8 ... 1024 (the reference's default is 256 / 128; its selector starts at 8, databrowser.py:516; 512 and 1024 take
+    this path for part of their hops only: spectrogram.hip's dispatch): a wave
     streams a run of consecutive frames through an LDS ring and stores whole batches of frames (spec_pack.h).  Every
     overlap the spin box can produce (databrowser.py:522-529: hop 1 ... nfft), runs long enough that every wave walks
     many batches and the ring wraps many times, odd channel pitches (4-byte aligned rows only), more output frames than
