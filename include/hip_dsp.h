@@ -79,7 +79,10 @@ int hipdsp_ctx_set_max_segments(hipdsp_ctx *ctx, int max_segments);
  *                        rows, waves beyond it do not report
  *   "sos_fair"           0: the single-wave sweeps without rotating issue priorities (A/B)
  *   "force_generic_fft"  non-zero: every nfft takes the generic radix-2 / four-step kernels
- *   "spec_kernel"        0 = default per size, 2 = two-stage, 3 = three-stage FFT kernel
+ *   "spec_kernel"        cross-check paths (results equal within the parity bar): 0 = default per size, 2 = the kernel a
+ *                        size's default replaced (two-stage FFT, workgroup per frame, four-step path through HBM), 3 = the
+ *                        other of a size's two candidates (nfft 256, 512: one frame per lane group instead of the stream
+ *                        through LDS; 1024: the stream for every hop; 4096: one wave per frame); tools/spec_kernel_ab.py
  *   "spec_fpw"           consecutive frames per wave (0 = automatic)
  *   "spec_no_half"       non-zero: do not reuse the overlapped half frame at 50 % overlap
  *   "chain_debug"        measurements only (results become wrong): 1 = the FFT waves of
