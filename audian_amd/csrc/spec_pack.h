@@ -1,7 +1,7 @@
 // spec_pack.h -- the short windows of BufferedSpectrogram.process (nfft 8 ... 256: the reference's default is 256 / 128,
 // src/audian/bufferedspectrogram.py:14-16; its selector offers 2^3 ... 2^19, src/audian/databrowser.py:516) for any hop;
-// since round 5 also nfft 512 (except the PSD alone at 50 % overlap) and nfft 1024 with the dB image at hops other than
-// nfft / 2 and nfft / 4 (spectrogram.hip's dispatch has the measurements): G x nfft <= 1024 samples is all it asks for.
+// since round 5 also nfft 512 (except the PSD alone at 50 % overlap) and nfft 1024 with the dB image (spectrogram.hip's
+// dispatch has the measurements): G x nfft <= 1024 samples is all it asks for.
 // Included by spectrogram.hip inside its anonymous namespace.
 //
 // A frame of a short window is a few hundred bytes in and out: kernels that let every lane group fetch ITS frame from

@@ -1300,10 +1300,11 @@ extern "C" int hipdsp_spectrogram(hipdsp_ctx *ctx, const float *x, int64_t x_pit
             return run_pack<512, 32, 8, 8, 4>(ctx, x, x_pitch, channels, frames, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
         case 1024:
             if (want == 2) return run_fast2<1024, 16, 32, 16, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
-            // with the dB image and a hop the register reuse does not cover (neither nfft / 2 nor nfft / 4): the stream through
-            // LDS, whose staged 16-byte stores carry both images (hop 100: 12.2 -> 8.7 ms, hop 700: 1.74 -> 1.53, hop = nfft:
-            // 1.32 -> 1.24 at 64 ch x 120 s; without the dB image it loses 3-20 %: profiles/r05at_spec_kernel_ab.log); "spec_kernel" 3
-            if (want == 3 || (want == 0 && db_out != nullptr && 2 * hop != nfft && 4 * hop != nfft))
+            // with the dB image: the stream through LDS, whose staged 16-byte stores carry both images (separate processes, 64 ch
+            // x 120 s: hop 100 12.2 -> 8.7 ms, hop 700 1.74 -> 1.53, hop = nfft 1.32 -> 1.24; in one process level to 3 % ahead at
+            // every hop, nfft / 2 and nfft / 4 -- where the other kernel reuses its registers -- included: 1.96 -> 1.90, 3.55 ->
+            // 3.50; without the dB image it loses 3-20 %: profiles/r05at_spec_kernel_ab.log); "spec_kernel" 3: for the PSD alone too
+            if (want == 3 || (want == 0 && db_out != nullptr))
                 return run_pack<1024, 64, 8, 8, 8>(ctx, x, x_pitch, channels, frames, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
             return run_fast<1024, 64, 8, 8, 8, 4>(ctx, x, x_pitch, channels, n_valid, frames_out, out_pitch, hop, scale, out, db_out);
         case 2048:
