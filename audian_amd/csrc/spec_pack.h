@@ -52,7 +52,7 @@ __device__ __forceinline__ float2 group_partner(float2 z, int partner)
 }
 
 template <int NFFT, int LPF, int R1, int R2, int R3, bool DB>
-__global__ __launch_bounds__(256, 3) void spec_pack_kernel(
+__global__ __launch_bounds__(256, NFFT >= 1024 ? 2 : 3) void spec_pack_kernel(
     const float *__restrict__ x, long long x_pitch, long long frames, long long n_valid, long long frames_out,
     long long out_pitch, int hop, float scale, const float *__restrict__ tables, float *__restrict__ out,
     float *__restrict__ db_out, int batches_per_wave, int debug)
