@@ -81,6 +81,7 @@ _SIGNATURES = {
     'hipdsp_graph_launch': ([_vp, _vp], _int),
     'hipdsp_graph_destroy': ([_vp, _vp], _int),
     'hipdsp_malloc': ([_vp, _sz, _pp], _int),
+    'hipdsp_malloc_probed': ([_vp, _sz, _int, _pp], _int),
     'hipdsp_free': ([_vp, _vp], _int),
     'hipdsp_pool_stats': ([_vp, ctypes.POINTER(_sz), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)], _int),
     'hipdsp_pool_trim': ([_vp], _int),

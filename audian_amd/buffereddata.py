@@ -27,6 +27,9 @@ import numpy as np
 from .bufferedarray import BufferedArray
 
 _TRACE = bool(os.environ.get('AUDIAN_AMD_TRACE'))
+# A trace's device mirror is what the kernels write into: the best of this many allocations by the time of a memset over
+# each (hipdsp_malloc_probed; mirrors under 64 MiB: a plain allocation).  AUDIAN_AMD_WRITE_PROBE=1 turns the search off.
+WRITE_PROBE = int(os.environ.get('AUDIAN_AMD_WRITE_PROBE', '4'))
 
 
 class _Call(object):
@@ -294,7 +297,7 @@ class BufferedData(BufferedArray):
             view, pitch, valid = self._dev, self._alias_pitch, list(self._dev_valid)
             self._dev, self._alias_pitch = None, None
             n = max(1, len(self._hostbuf)*self._inner())
-            self._dev = hipdsp.DeviceArray(self.ctx, (max(1, self.channels), n), np.float32)
+            self._dev = hipdsp.DeviceArray(self.ctx, (max(1, self.channels), n), np.float32, write_probe=WRITE_PROBE)
             for a, b in valid:
                 hipdsp.memcpy2d(self.ctx, self._dev.view(a, (1,)), 4*n, view.view(a, (1,)), 4*pitch, 4*(b - a),
                                 self.channels)
@@ -302,7 +305,7 @@ class BufferedData(BufferedArray):
             self.ctx.synchronize()
         if self._dev is None:
             n = max(1, len(self._hostbuf)*self._inner())
-            self._dev = hipdsp.DeviceArray(self.ctx, (max(1, self.channels), n), np.float32)
+            self._dev = hipdsp.DeviceArray(self.ctx, (max(1, self.channels), n), np.float32, write_probe=WRITE_PROBE)
             self._dev_valid = []
         return self._dev
 

@@ -314,6 +314,59 @@ int hipdsp_malloc(hipdsp_ctx *ctx, size_t bytes, void **dptr)
     return HIPDSP_OK;
 }
 
+// Up to `tries` blocks are allocated side by side, a hipMemsetAsync over each is timed, the fastest stays.  Where an
+// allocation lies in HBM decides how fast a WRITE stream into it runs (profiles/r03_placement_probe.log: three loose
+// classes, whatever the size, the alignment or the offset inside the block; profiles/r05be_placement_shop.log: memset 2.28 /
+// 2.35 / 2.40 ms over 14.7 GB <-> the envelope's backward sweep 5.50 / 5.68 / 6.15 ms into the same block, correlation
+// 0.94 over six blocks) -- the whole run-to-run spread of that sweep in the bench lines of rounds 1-4.
+int hipdsp_malloc_probed(hipdsp_ctx *ctx, size_t bytes, int tries, void **dptr)
+{
+    HD_REQUIRE(ctx != nullptr && dptr != nullptr, "NULL argument");
+    *dptr = nullptr;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (ctx->stream) (void)hipStreamIsCapturing(ctx->stream, &capturing);
+    if (tries > 8) tries = 8;
+    // small blocks (the differences are a few per cent of a stream over the block) and captures: a plain allocation
+    if (tries <= 1 || bytes < ((size_t)64 << 20) || capturing != hipStreamCaptureStatusNone) return hipdsp_malloc(ctx, bytes, dptr);
+    void *cand[8];
+    float ms[8];
+    int n = 0;
+    for (; n < tries; n++) {
+        const int rc = hipdsp_malloc(ctx, bytes, &cand[n]);
+        if (rc != HIPDSP_OK) {
+            if (n == 0) return rc;
+            (void)hipGetLastError();
+            break;                                     // out of memory on the way: choose among what there is
+        }
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    int best = 0;
+    if (e == hipSuccess) {
+        for (int i = 0; i < n && e == hipSuccess; i++) {
+            e = hipMemsetAsync(cand[i], 0, bytes, ctx->stream);                       // (first touch)
+            if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
+            for (int k = 0; k < 3 && e == hipSuccess; k++) e = hipMemsetAsync(cand[i], 0, bytes, ctx->stream);
+            if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            ms[i] = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms[i], e0, e1);
+            if (e == hipSuccess && ms[i] < ms[best]) best = i;
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    for (int i = 0; i < n; i++)
+        if (i != best) (void)hipdsp_free(ctx, cand[i]);
+    if (e != hipSuccess) {
+        (void)hipdsp_free(ctx, cand[best]);
+        HD_CHECK_HIP(e);
+    }
+    *dptr = cand[best];
+    return HIPDSP_OK;
+}
+
 int hipdsp_free(hipdsp_ctx *ctx, void *dptr)
 {
     HD_REQUIRE(ctx != nullptr, "ctx is NULL");

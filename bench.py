@@ -97,6 +97,9 @@ def parse():
                          "multi-rank path on a one-GPU box")
     ap.add_argument('--same-device', action='store_true',
                     help='rehearsal: every rank uses GPU 0 (needs --backend gloo)')
+    ap.add_argument('--write-probe', type=int, default=4,
+                    help='the envelope buffer is the best of this many allocations by the time of a memset over each '
+                         '(hipdsp_malloc_probed, what BufferedData does for its device mirrors; 1: a plain allocation)')
     ap.add_argument('--no-fuse', action='store_true',
                     help='four launches (band-pass, spectrogram, envelope forward, backward) instead '
                          'of fusing the envelope forward pass into the band-pass kernel')
@@ -691,7 +694,9 @@ def main():
 
     dx = hipdsp.DeviceArray(ctx, (C, T), np.float32)
     df = hipdsp.DeviceArray(ctx, (C, T), np.float32)
-    de = hipdsp.DeviceArray(ctx, (C, T), np.float32)
+    # (the envelope is the one output whose sweep is bound by its write stream: where its buffer lies in HBM moves that
+    # sweep by up to 12 %; the facade allocates its mirrors the same way, audian_amd/buffereddata.py: WRITE_PROBE)
+    de = hipdsp.DeviceArray(ctx, (C, T), np.float32, write_probe=args.write_probe)
     if multi:
         tspec = torch.empty((C, nd, F), dtype=torch.float32, device='cuda')
         ds = hipdsp.DeviceArray(ctx, (C, nd, F), np.float32, ptr=tspec.data_ptr(), owner=tspec)
@@ -1058,6 +1063,8 @@ def main():
                 'streams': ('spectrogram on a second stream next to the envelope backward sweep '
                             '(their event-bracketed times overlap)' if overlap else 'one compute stream'),
                 'envelope_forward': ('state checkpoints, ' + ('fused into the band-pass kernel' if fused else 'own launch')),
+                'envelope_buffer': (f'best of {args.write_probe} allocations by memset time (hipdsp_malloc_probed)'
+                                    if args.write_probe > 1 else 'plain allocation'),
                 'spectrogram': ('FFT waves inside the forward sweep (filtered tiles from LDS)' if fuse3 else 'own launch'),
             },
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 1),

@@ -140,6 +140,13 @@ int hipdsp_graph_destroy(hipdsp_ctx *ctx, hipdsp_graph *graph);
  * stream first waits for an event recorded at the free. */
 int hipdsp_malloc(hipdsp_ctx *ctx, size_t bytes, void **dptr);
 int hipdsp_free(hipdsp_ctx *ctx, void *dptr);
+/* A block for a trace that kernels WRITE (the buffers BufferedData.allocate_buffer creates, src/audian/buffereddata.py:69-70,
+ * 112-114): up to `tries` (<= 8) blocks are allocated side by side, a memset over each is timed on the context's stream
+ * (which is synchronised), the fastest stays, the others go back through hipdsp_free.  Which physical pages a block got
+ * moves a write stream into it by up to 12 % on this part (the envelope's backward sweep: 5.5 ... 6.2 ms into blocks of
+ * one process, and the memset predicts it); nothing in user space chooses them, but it can choose among them.  Blocks
+ * under 64 MiB, tries <= 1 and calls inside a stream capture are plain hipdsp_malloc calls.  The block is zeroed. */
+int hipdsp_malloc_probed(hipdsp_ctx *ctx, size_t bytes, int tries, void **dptr);
 /* Cache statistics (any pointer may be NULL) / give every cached block back to the driver -- and the context's scratch,
  * which only grows otherwise (hipdsp_envelope_multi parks two slabs of the trace's size there), unless a captured graph
  * of the context is alive (it holds the scratch's address). */

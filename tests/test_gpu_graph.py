@@ -153,6 +153,31 @@ def test_block_cache_reuses_freed_blocks():
     c.pool_trim()
 
 
+def test_probed_allocation_keeps_one_block_and_returns_the_others():
+    """hipdsp_malloc_probed (the trace buffers kernels write into: BufferedData's device mirrors, buffereddata.py:69-70,
+    112-114): the best of N blocks by a timed memset stays, zeroed, the others are back in the cache or with the driver;
+    small blocks and N <= 1 are plain allocations."""
+    from audian_amd import hipdsp
+    c = hipdsp.Context(0)
+    c.set_option('pool_limit_mb', 2048)
+    n = 96 << 20                                                 # 96 MiB: above the 64 MiB threshold, cacheable
+    a = hipdsp.DeviceArray(c, (n,), np.uint8, write_probe=3)
+    cached, hits, misses = c.pool_stats()
+    assert misses == 3 and cached >= 2*n                         # three blocks were tried, two went back
+    assert np.all(a.to_host()[::4099] == 0)
+    b = hipdsp.DeviceArray(c, (n,), np.uint8)                    # the next plain request is served by one of them
+    assert b.ptr != a.ptr and c.pool_stats()[1] == 1
+    small = hipdsp.DeviceArray(c, (1 << 20,), np.uint8, write_probe=8)
+    assert c.pool_stats()[2] == 4                                # one block only
+    for arr in (a, b, small):
+        arr.free()
+    c.set_option('pool_limit_mb', 0)
+    c.pool_trim()
+    # the facade's mirrors come through it
+    from audian_amd import buffereddata
+    assert buffereddata.WRITE_PROBE == 4
+
+
 def test_live_sliding_window_in_captured_graphs(oracle):
     """configs[4] with live data: per frame a chunk of 16-bit PCM is appended to the resident window
     (slide into the other of two windows + hipdsp_pcm_unpack, both captured) and the chain is
